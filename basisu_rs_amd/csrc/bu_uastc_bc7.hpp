@@ -1,0 +1,460 @@
+// UASTC -> BC7 block repack for the gfx950 kernels (the north-star target).
+// Replaces src/target_formats/bc7.rs:9-553 of the reference:
+//   :18-59, 312-375   solid-colour blocks (UASTC mode 8 -> BC7 mode 6, or mode 5 when neither p-bit is lossless)
+//   :61-107           front-end (shared, bu_uastc_front.hpp) + weight-width remap (:377-398)
+//   :116-247          partition remap, subset permutation, anchor-MSB inversion, plane rotation
+//   :249-273, 408-553 p-bit selection / endpoint scaling -- integer forms (see the notes at each)
+//   :276-307          emit
+// Weights never leave their packed form: the UASTC weight stream is regularised (front-end), width-
+// converted by SWAR bit spreading, inverted per subset with a partition mask, and has the BC7 anchor
+// MSBs squeezed out again -- a handful of shift/and/or per block instead of a loop over 16 texels.
+#pragma once
+#include "bu_uastc_front.hpp"
+
+// UASTC mode -> BC7 mode (bc7.rs:582-589)
+constexpr int BU_BC7_OF[19] = {6, 3, 1, 2, 3, 6, 5, 2, -1, 7, 6, 5, 6, 5, 6, 6, 7, 5, 6};
+
+// ---- SWAR helpers -------------------------------------------------------------------------------
+// 16 bits -> 32 bits, bit i -> bit 2i
+BU_DEV uint32_t bu_spread1(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+// 8 fields of 2 bits (16 bits) -> 8 slots of 4 bits
+BU_DEV uint32_t bu_spread2to4(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    return v;
+}
+// 8 fields of 3 bits (24 bits) -> 8 slots of 4 bits
+BU_DEV uint32_t bu_spread3to4(uint32_t v)
+{
+    v = (v & 0x00000FFFu) | ((v & 0x00FFF000u) << 4);
+    v = (v & 0x003F003Fu) | ((v & 0x0FC00FC0u) << 2);
+    v = (v & 0x07070707u) | ((v & 0x38383838u) << 1);
+    return v;
+}
+// 8 slots of 4 bits holding a 2-bit field each -> 16 bits
+BU_DEV uint32_t bu_compact4to2(uint32_t v)
+{
+    v &= 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+// delete bit q of x (bits above move down by one)
+BU_DEV uint32_t bu_del_rt32(uint32_t x, uint32_t q)
+{
+    const uint32_t high = 0xFFFFFFFFu << q;
+    return (x & ~high) | ((x >> 1) & high);
+}
+BU_DEV uint64_t bu_del_rt64(uint64_t x, uint32_t q)
+{
+    const uint64_t high = ~0ull << q;
+    return (x & ~high) | ((x >> 1) & high);
+}
+BU_DEV uint32_t bu_sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+
+// ---- p-bit selection ---------------------------------------------------------------------------
+// determine_unique_pbits (bc7.rs:478-553) for 8 total bits (BC7 modes 3 and 6), one endpoint, all
+// channels at once on the packed RGBA word.  With S = 255 the reference's quantiser reduces to
+//   p = 0: q = 2*floor((x+1)/2) clamped to 254, error 1 iff x is odd
+//   p = 1: q = 2*floor(x/2)+1,                     error 1 iff x is even
+// so err0 = #odd channels, err1 = #even channels and p = 1 iff err1 < err0 (strict, ties -> 0).
+// (exact for every input: SURVEY.md appendix A; tests/test_float_sites.py re-proves it against the
+// oracle's f32 form.)  Returns the 7-bit endpoint values packed in bytes; *p receives the p-bit.
+template <int NCOMP>
+BU_DEV uint32_t bu_pbit8(uint32_t c, uint32_t* p)
+{
+    constexpr uint32_t cm = NCOMP == 4 ? 0x01010101u : 0x00010101u;
+    const uint32_t odd = bu_popc(c & cm);
+    const bool p1 = (uint32_t)NCOMP < 2u * odd;
+    const uint32_t half = (c >> 1) & 0x7F7F7F7Fu;
+    uint32_t q0 = half + (c & 0x01010101u);
+    q0 -= (q0 >> 7) & 0x01010101u;
+    *p = p1 ? 1u : 0u;
+    return p1 ? half : q0;
+}
+
+// ---- emit helpers ------------------------------------------------------------------------------
+BU_DEV uint32_t bu_byte(uint32_t c, int ch) { return (c >> (8 * ch)) & 0xFFu; }
+
+template <int M>
+BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if constexpr (M == 8) {
+        // ---- solid colour (bc7.rs:18-59, 312-375) ----
+        const uint32_t c = bu_bits(b, 5, 32);
+        uint32_t n255 = 0, n0 = 0;
+        BU_UNROLL
+        for (int ch = 0; ch < 4; ch++) {
+            n255 += bu_byte(c, ch) == 255u;  // mode_6_optimal_endpoint_err(c, p=0)
+            n0 += bu_byte(c, ch) == 0u;      // mode_6_optimal_endpoint_err(c, p=1)
+        }
+        if (n255 > 0 && n0 > 0) {
+            // BC7 mode 5: colour weights all 1, alpha weights all 0, rotation 0
+            bu_put(out, 0, 6, 1u << 5);
+            int pos = 8;
+            BU_UNROLL
+            for (int ch = 0; ch < 3; ch++) {
+                const uint32_t o = T.m5opt[bu_byte(c, ch)];
+                bu_put(out, pos, 7, o & 0xFFu);
+                bu_put(out, pos + 7, 7, o >> 8);
+                pos += 14;
+            }
+            bu_put(out, pos, 8, bu_byte(c, 3));
+            bu_put(out, pos + 8, 8, bu_byte(c, 3));
+            pos += 16;                    // = 66
+            bu_put(out, pos, 1, 1u);      // anchor: 1 bit
+            bu_put(out, pos + 1, 30, 0x15555555u);  // 15 x 0b01
+        } else {
+            const uint32_t p = n0 < n255 ? 1u : 0u;  // best_err1 < best_err0
+            bu_put(out, 0, 7, 1u << 6);
+            int pos = 7;
+            BU_UNROLL
+            for (int ch = 0; ch < 4; ch++) {
+                const uint32_t o = T.m6opt[bu_byte(c, ch) + (p ^ 1u)];
+                bu_put(out, pos, 7, o & 0xFFu);
+                bu_put(out, pos + 7, 7, o >> 8);
+                pos += 14;
+            }
+            bu_put(out, pos, 2, p * 3u);  // = 63
+            // weights all 5: anchor 3 bits (0b101) then 15 x 0b0101, from bit 65
+            bu_put(out, 65, 3, 5u);
+            bu_put(out, 68, 28, 0x5555555u);
+            bu_put(out, 96, 32, 0x55555555u);
+        }
+        return BU_ST_OK;
+    } else {
+        using L = BuLayout<M>;
+        constexpr int BM = BU_BC7_OF[M];
+        constexpr int wb = L::d.wb, planes = L::d.planes, fmt = L::d.fmt;
+        constexpr int bwb = (BM == 6) ? 4 : (BM == 1 ? 3 : 2);       // BC7 weight bits (bc7.rs:570-579)
+        constexpr int bsub = (BM == 1 || BM == 3 || BM == 7) ? 2 : (BM == 2 ? 3 : 1);  // BC7 subsets
+
+        uint32_t pat = 0;
+        if constexpr (L::pat_bits > 0) {
+            pat = bu_bits(b, L::pos_pat, L::pat_bits);
+            if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;
+        }
+        BuPart pr = {};
+        if constexpr (bsub > 1) pr = T.part[L::part_base + pat];
+        const uint32_t compsel = L::compsel_bits ? bu_bits(b, L::pos_compsel, 2) : 3u;
+
+        // ---- endpoints: quantised digits, then per UASTC subset packed lo/hi RGBA -------------
+        uint32_t tq[18], eb[18];
+        bu_decode_quant<M>(T, b, tq, eb);
+
+        // ---- weights in BC7 width: WB[plane] = 16 fields of bwb bits -------------------------
+        uint32_t W[3];
+        bu_decode_weights<M>(b, pr.uanch, W);
+        uint32_t w0lo = 0, w0hi = 0, w1lo = 0;  // plane 0: up to 64 bits; plane 1: 32 bits (bwb = 2)
+        if constexpr (planes == 1) {
+            if constexpr (wb == bwb) {
+                w0lo = W[0];
+                w0hi = W[1];
+            } else if constexpr (wb == 2 && bwb == 4) {  // [0,5,10,15] = x | x<<2 (bc7.rs:379)
+                w0lo = bu_spread2to4(W[0] & 0xFFFFu);
+                w0hi = bu_spread2to4(W[0] >> 16);
+                w0lo |= w0lo << 2;
+                w0hi |= w0hi << 2;
+            } else if constexpr (wb == 3 && bwb == 4) {  // [0,2,4,6,9,11,13,15] = x<<1 | x>>2 (bc7.rs:380)
+                w0lo = bu_spread3to4(W[0] & 0xFFFFFFu);
+                w0hi = bu_spread3to4((W[0] >> 24) | (W[1] << 8));
+                w0lo = (w0lo << 1) | ((w0lo >> 2) & 0x11111111u);
+                w0hi = (w0hi << 1) | ((w0hi >> 2) & 0x11111111u);
+            } else {  // 5 -> 4 bits: x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
+                static_assert(wb == 5 && bwb == 4, "unexpected weight remap");
+                BU_UNROLL
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t x = bu_wfield<5>(W, i);
+                    const uint32_t v = (x >> 1) - (x == 14u) + (x == 17u);
+                    if (i < 8) w0lo |= v << (4 * i);
+                    else w0hi |= v << (4 * (i - 8));
+                }
+            }
+        } else {
+            static_assert(planes == 1 || bwb == 2, "dual-plane modes map to BC7 mode 5");
+            if constexpr (wb == 1) {  // [0,3]: replicate the bit (bc7.rs:378); texel i plane p at bit 2i+p
+                w0lo = W[0] & 0x55555555u;
+                w0lo |= w0lo << 1;
+                w1lo = (W[0] >> 1) & 0x55555555u;
+                w1lo |= w1lo << 1;
+            } else {  // 2-bit, texel i: plane 0 at bit 4i, plane 1 at bit 4i+2
+                w0lo = bu_compact4to2(W[0]) | (bu_compact4to2(W[1]) << 16);
+                w1lo = bu_compact4to2(W[0] >> 2) | (bu_compact4to2(W[1] >> 2) << 16);
+            }
+        }
+
+        // ---- packed endpoint colours per UASTC subset ------------------------------------------
+        // BC7 mode 2 scales to 5 bits straight from the quantised digits (deq5 LUT); BC7 mode 1 and
+        // mode 7 (from UASTC mode 9) index their p-bit LUTs by the raw 4-bit value.
+        uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};       // bytes R,G,B,A
+        if constexpr (BM != 1) {
+            uint32_t e[18];
+            BU_UNROLL
+            for (int i = 0; i < 18; i++) {
+                if (i < L::ep_count) {
+                    if constexpr (BM == 2) e[i] = T.deq5[(L::d.range == 7 ? 0 : 16) + ((tq[i] << L::ebits) | eb[i])];
+                    else e[i] = bu_deq<L::d.range>(T, tq[i], eb[i]);
+                } else e[i] = 0;
+            }
+            BU_UNROLL
+            for (int s = 0; s < L::d.subsets; s++) {
+                if constexpr (fmt == BU_FMT_RGB) {
+                    constexpr uint32_t A = BM == 2 ? 0u : 0xFF000000u;
+                    lo[s] = e[6 * s] | (e[6 * s + 2] << 8) | (e[6 * s + 4] << 16) | A;
+                    hi[s] = e[6 * s + 1] | (e[6 * s + 3] << 8) | (e[6 * s + 5] << 16) | A;
+                } else if constexpr (fmt == BU_FMT_RGBA) {
+                    lo[s] = e[8 * s] | (e[8 * s + 2] << 8) | (e[8 * s + 4] << 16) | (e[8 * s + 6] << 24);
+                    hi[s] = e[8 * s + 1] | (e[8 * s + 3] << 8) | (e[8 * s + 5] << 16) | (e[8 * s + 7] << 24);
+                } else {
+                    lo[s] = e[4 * s] * 0x010101u | (e[4 * s + 2] << 24);
+                    hi[s] = e[4 * s + 1] * 0x010101u | (e[4 * s + 3] << 24);
+                }
+            }
+        } else {  // UASTC mode 2: keep the raw 4-bit values (they index pbit7)
+            BU_UNROLL
+            for (int s = 0; s < 2; s++) {
+                lo[s] = eb[6 * s] | (eb[6 * s + 2] << 8) | (eb[6 * s + 4] << 16);
+                hi[s] = eb[6 * s + 1] | (eb[6 * s + 3] << 8) | (eb[6 * s + 5] << 16);
+            }
+        }
+
+        // ---- partition remap, permutation, inversion (bc7.rs:116-247) ----------------------------
+        uint32_t blo[3] = {lo[0], 0, 0}, bhi[3] = {hi[0], 0, 0};  // per BC7 subset
+        if constexpr (bsub > 1) {
+            // permute: BC7 subset s <- UASTC subset perm[s]   (bc7.rs:163-169, 400-405)
+            BU_UNROLL
+            for (int s = 0; s < bsub; s++) {
+                const uint32_t src = (pr.perm >> (2 * s)) & 3u;
+                if constexpr (L::d.subsets == 1) {
+                    blo[s] = lo[0];
+                    bhi[s] = hi[0];
+                } else if constexpr (L::d.subsets == 2) {
+                    blo[s] = bu_sel(src == 1, lo[1], lo[0]);
+                    bhi[s] = bu_sel(src == 1, hi[1], hi[0]);
+                } else {
+                    blo[s] = bu_sel(src == 2, lo[2], bu_sel(src == 1, lo[1], lo[0]));
+                    bhi[s] = bu_sel(src == 2, hi[2], bu_sel(src == 1, hi[1], hi[0]));
+                }
+            }
+            // anchor MSB set -> swap that subset's endpoints and complement its weights (bc7.rs:171-195)
+            const uint32_t a1 = (pr.banch >> 4) & 15u, a2 = (pr.banch >> 8) & 15u;
+            constexpr uint32_t msb = bwb - 1;
+            bool inv0, inv1, inv2 = false;
+            if constexpr (bwb == 3) {
+                const uint64_t w = (uint64_t)w0lo | ((uint64_t)w0hi << 32);
+                inv0 = (w0lo >> msb) & 1u;
+                inv1 = (uint32_t)(w >> (a1 * 3 + msb)) & 1u;
+            } else {
+                inv0 = (w0lo >> msb) & 1u;
+                inv1 = (w0lo >> (a1 * 2 + msb)) & 1u;
+                if constexpr (bsub == 3) inv2 = (w0lo >> (a2 * 2 + msb)) & 1u;
+            }
+            {
+                uint32_t t;
+                t = blo[0]; blo[0] = bu_sel(inv0, bhi[0], blo[0]); bhi[0] = bu_sel(inv0, t, bhi[0]);
+                t = blo[1]; blo[1] = bu_sel(inv1, bhi[1], blo[1]); bhi[1] = bu_sel(inv1, t, bhi[1]);
+                if constexpr (bsub == 3) {
+                    t = blo[2]; blo[2] = bu_sel(inv2, bhi[2], blo[2]); bhi[2] = bu_sel(inv2, t, bhi[2]);
+                }
+            }
+            if constexpr (bwb == 3) {  // BC7 mode 1: 48-bit masks from the table
+                const uint32_t m1lo = T.w3mask[pat][0], m1hi = T.w3mask[pat][1];
+                w0lo ^= bu_sel(inv1, m1lo, 0u) ^ bu_sel(inv0, ~m1lo, 0u);
+                w0hi ^= (bu_sel(inv1, m1hi, 0u) ^ bu_sel(inv0, ~m1hi, 0u)) & 0xFFFFu;
+            } else {  // 2 bits per texel: masks straight from the 2-bit pattern word
+                const uint32_t m1 = (pr.bpat & 0x55555555u) * 3u;
+                const uint32_t m2 = ((pr.bpat >> 1) & 0x55555555u) * 3u;
+                const uint32_t m0 = ~(m1 | m2);
+                w0lo ^= bu_sel(inv0, m0, 0u) ^ bu_sel(inv1, m1, 0u) ^ bu_sel(inv2, m2, 0u);
+            }
+            // squeeze out the (now zero) anchor MSBs, highest position first (bc7.rs:296-307)
+            if constexpr (bwb == 3) {
+                uint64_t w = (uint64_t)w0lo | ((uint64_t)w0hi << 32);
+                w = bu_del_rt64(w, a1 * 3 + msb);
+                w = bu_del_rt64(w, msb);
+                w0lo = (uint32_t)w;
+                w0hi = (uint32_t)(w >> 32);
+            } else {
+                if constexpr (bsub == 3) {
+                    const uint32_t ahi = a1 > a2 ? a1 : a2, alo = a1 > a2 ? a2 : a1;
+                    w0lo = bu_del_rt32(w0lo, ahi * 2 + msb);
+                    w0lo = bu_del_rt32(w0lo, alo * 2 + msb);
+                } else {
+                    w0lo = bu_del_rt32(w0lo, a1 * 2 + msb);
+                }
+                w0lo = bu_del_rt32(w0lo, msb);
+            }
+        } else {
+            // single BC7 subset: the anchor is texel 0 in both formats and every remap keeps its MSB
+            // clear, so the inversion tests of bc7.rs:200-236 are never taken; only the dual-plane
+            // channel rotation remains (bc7.rs:217-219, 239).
+            if constexpr (planes == 2 && fmt != BU_FMT_LA) {
+                const uint32_t sh = compsel * 8u;
+                BU_UNROLL
+                for (int k = 0; k < 2; k++) {
+                    uint32_t& c = k ? bhi[0] : blo[0];
+                    const uint32_t cs = (c >> sh) & 0xFFu, al = c >> 24;
+                    c = (c & ~(0xFFu << sh)) | (al << sh);       // compsel channel <- alpha
+                    c = (c & 0x00FFFFFFu) | (cs << 24);           // alpha <- compsel channel
+                }
+            }
+            // drop texel 0's MSB per plane
+            if constexpr (bwb == 4) {
+                w0lo = (w0lo & 7u) | ((w0lo >> 1) & ~7u) | (w0hi << 31);
+                w0hi >>= 1;
+            } else {
+                w0lo = (w0lo & 1u) | ((w0lo >> 1) & ~1u);
+                w1lo = (w1lo & 1u) | ((w1lo >> 1) & ~1u);
+            }
+        }
+
+        // ---- quantise endpoints / choose p-bits, then emit ---------------------------------------
+        int pos = 0;
+        bu_put(out, 0, BM + 1, 1u << BM);  // unary mode prefix (bc7.rs:109)
+        pos = BM + 1;
+        if constexpr (bsub > 1) {
+            bu_put(out, pos, 6, pr.bpart);
+            pos += 6;
+        }
+        if constexpr (BM == 6) {
+            uint32_t p0, p1;
+            const uint32_t q0 = bu_pbit8<4>(blo[0], &p0), q1 = bu_pbit8<4>(bhi[0], &p1);
+            BU_UNROLL
+            for (int ch = 0; ch < 4; ch++) {
+                bu_put(out, pos, 7, bu_byte(q0, ch));
+                bu_put(out, pos + 7, 7, bu_byte(q1, ch));
+                pos += 14;
+            }
+            bu_put(out, pos, 2, p0 | (p1 << 1));
+            pos += 2;  // = 65
+            bu_put(out, pos, 31, w0lo & 0x7FFFFFFFu);
+            bu_put(out, pos + 31, 32, (w0lo >> 31) | (w0hi << 1));
+        } else if constexpr (BM == 3) {
+            uint32_t p[2][2], q[2][2];
+            BU_UNROLL
+            for (int s = 0; s < 2; s++) {
+                q[s][0] = bu_pbit8<3>(blo[s], &p[s][0]);
+                q[s][1] = bu_pbit8<3>(bhi[s], &p[s][1]);
+            }
+            BU_UNROLL
+            for (int ch = 0; ch < 3; ch++)
+                BU_UNROLL
+                for (int s = 0; s < 2; s++) {
+                    bu_put(out, pos, 7, bu_byte(q[s][0], ch));
+                    bu_put(out, pos + 7, 7, bu_byte(q[s][1], ch));
+                    pos += 14;
+                }
+            bu_put(out, pos, 4, p[0][0] | (p[0][1] << 1) | (p[1][0] << 2) | (p[1][1] << 3));
+            pos += 4;  // = 98
+            bu_put(out, pos, 30, w0lo);
+        } else if constexpr (BM == 7) {
+            // determine_unique_pbits at 6 total bits through the pbit6 LUT (bc7.rs:478-553):
+            // entry = q0>>1 | (q1>>1)<<8 | err0<<16 | err1<<24; the 4 channel entries are summed so
+            // the two error totals fall out of one word (max 4*16 < 256, no carry between fields)
+            uint32_t pb = 0;
+            uint32_t qv[2][2][4];
+            BU_UNROLL
+            for (int s = 0; s < 2; s++)
+                BU_UNROLL
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t c = k ? bhi[s] : blo[s];
+                    uint32_t en[4], sum = 0;
+                    BU_UNROLL
+                    for (int ch = 0; ch < 4; ch++) {
+                        en[ch] = T.pbit6[bu_byte(c, ch)];
+                        sum += en[ch] >> 16;
+                    }
+                    const bool p1 = (sum >> 8) < (sum & 0xFFu);  // err1 < err0
+                    pb |= (p1 ? 1u : 0u) << (2 * s + k);
+                    BU_UNROLL
+                    for (int ch = 0; ch < 4; ch++) qv[s][k][ch] = p1 ? ((en[ch] >> 8) & 0xFFu) : (en[ch] & 0xFFu);
+                }
+            BU_UNROLL
+            for (int ch = 0; ch < 4; ch++)
+                BU_UNROLL
+                for (int s = 0; s < 2; s++) {
+                    bu_put(out, pos, 5, qv[s][0][ch]);
+                    bu_put(out, pos + 5, 5, qv[s][1][ch]);
+                    pos += 10;
+                }
+            bu_put(out, pos, 4, pb);
+            pos += 4;  // = 98
+            bu_put(out, pos, 30, w0lo);
+        } else if constexpr (BM == 1) {
+            // determine_shared_pbits at 7 total bits (bc7.rs:408-475).  Inputs are 4-bit UASTC endpoints
+            // (multiples of 17), so a 16-entry LUT indexed by the raw value holds both quantisations
+            // and their squared errors; integer comparison == the reference's f32 comparison on this
+            // domain (exhaustive proof: tests/test_float_sites.py).
+            uint32_t sp = 0;
+            uint32_t qv[2][2][3];
+            BU_UNROLL
+            for (int s = 0; s < 2; s++) {
+                uint32_t en[2][3], sum = 0;
+                BU_UNROLL
+                for (int k = 0; k < 2; k++)
+                    BU_UNROLL
+                    for (int ch = 0; ch < 3; ch++) {
+                        en[k][ch] = T.pbit7[bu_byte(k ? bhi[s] : blo[s], ch)];
+                        sum += en[k][ch] >> 16;
+                    }
+                const bool p1 = (sum >> 8) < (sum & 0xFFu);
+                sp |= (p1 ? 1u : 0u) << s;
+                BU_UNROLL
+                for (int k = 0; k < 2; k++)
+                    BU_UNROLL
+                    for (int ch = 0; ch < 3; ch++) qv[s][k][ch] = p1 ? ((en[k][ch] >> 8) & 0xFFu) : (en[k][ch] & 0xFFu);
+            }
+            BU_UNROLL
+            for (int ch = 0; ch < 3; ch++)
+                BU_UNROLL
+                for (int s = 0; s < 2; s++) {
+                    bu_put(out, pos, 6, qv[s][0][ch]);
+                    bu_put(out, pos + 6, 6, qv[s][1][ch]);
+                    pos += 12;
+                }
+            bu_put(out, pos, 2, sp);
+            pos += 2;  // = 82
+            bu_put(out, pos, 32, w0lo);
+            bu_put(out, pos + 32, 14, w0hi & 0x3FFFu);
+        } else if constexpr (BM == 2) {
+            // endpoints are already (e*31+127)/255 from the deq5 LUT (bc7.rs:262-272)
+            BU_UNROLL
+            for (int ch = 0; ch < 3; ch++)
+                BU_UNROLL
+                for (int s = 0; s < 3; s++) {
+                    bu_put(out, pos, 5, bu_byte(blo[s], ch));
+                    bu_put(out, pos + 5, 5, bu_byte(bhi[s], ch));
+                    pos += 10;
+                }
+            bu_put(out, pos, 29, w0lo);  // pos = 99
+        } else {
+            static_assert(BM == 5, "unhandled BC7 mode");
+            bu_put(out, pos, 2, (compsel + 1u) & 3u);  // rotation (bc7.rs:239); LA: compsel = 3 -> 0
+            pos += 2;
+            // (e*127+127)/255 == e>>1 for every e in 0..255; alpha keeps 8 bits (bc7.rs:262-272)
+            BU_UNROLL
+            for (int ch = 0; ch < 3; ch++) {
+                bu_put(out, pos, 7, bu_byte(blo[0], ch) >> 1);
+                bu_put(out, pos + 7, 7, bu_byte(bhi[0], ch) >> 1);
+                pos += 14;
+            }
+            bu_put(out, pos, 8, blo[0] >> 24);
+            bu_put(out, pos + 8, 8, bhi[0] >> 24);
+            pos += 16;  // = 66
+            bu_put(out, pos, 31, w0lo);
+            bu_put(out, pos + 31, 31, w1lo);
+        }
+        return BU_ST_OK;
+    }
+}

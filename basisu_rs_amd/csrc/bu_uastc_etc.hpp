@@ -1,0 +1,202 @@
+// UASTC -> ETC1 and UASTC -> ETC2 RGBA (EAC alpha + ETC1 colour) for the gfx950 kernels.
+// Replaces src/target_formats/etc.rs:11-341 of the reference:
+//   :43-76    UASTC mode 8 uses its stored ETC1 flags directly
+//   :78-111   full RGBA decode, optional transpose, per-half average
+//   :113-158  bias (apply_etc1_bias :203-259), individual / differential base colours, header byte
+//   :160-198  selectors by luma thresholds; Selector::set_selector bit planes (:363-393)
+//   :261-341  EAC alpha block (solid / searched); the f32 centre is evaluated as exact integers
+// The transpose is never materialised: the two ETC1 sub-blocks are sums of 2x2 quadrants, and the
+// flip bit only chooses which quadrants pair up.
+#pragma once
+#include "bu_uastc_front.hpp"
+
+BU_DEV int bu_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// etc.rs:261-275: {value, 0x1D, 0x92, 0x49, 0x24, 0x92, 0x49, 0x24}
+BU_DEV void bu_eac_solid(uint32_t out[2], uint32_t value)
+{
+    out[0] = 0x49921D00u | value;
+    out[1] = 0x24499224u;
+}
+
+// etc.rs:277-341
+BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, const uint32_t px[16])
+{
+    uint32_t mn = 255, mx = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        const uint32_t a = px[i] >> 24;
+        mn = a < mn ? a : mn;
+        mx = a > mx ? a : mx;
+    }
+    if (etc2tm == 0) {
+        bu_eac_solid(out, 255);
+        return;
+    }
+    if (mn == mx) {
+        bu_eac_solid(out, mn);
+        return;
+    }
+    const uint32_t table = etc2tm & 15u;
+    const int mult = (int)(etc2tm >> 4);
+    const int mm = T.eac_mod_min[table], range = T.eac_range[table];
+    // round(lerp(min, max, -mod_min/range)) == floor((2*(min*(range+mm) - max*mm) + range) / (2*range)):
+    // every range is odd, so there are no .5 ties (tests/test_float_sites.py)
+    const uint32_t num = (uint32_t)(2 * ((int)mn * (range + mm) - (int)mx * mm) + range);
+    const int center = (int)((num * T.eac_magic[table]) >> 20);  // num <= 14791, 2*range <= 58: exact
+    int values[8];
+    BU_UNROLL
+    for (int k = 0; k < 8; k++) values[k] = bu_clampi(center + T.etc2_amod[8 * table + k] * mult, 0, 255);
+    uint64_t selectors = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        const int a = (int)(px[i] >> 24);
+        uint32_t best = 0xFFFFFFFFu;
+        BU_UNROLL
+        for (int k = 0; k < 8; k++) {  // min_by_key keeps the first minimum: distance*8 + index
+            const int dlt = values[k] - a;
+            const uint32_t key = (uint32_t)(dlt < 0 ? -dlt : dlt) * 8u + (uint32_t)k;
+            best = key < best ? key : best;
+        }
+        const int id = (i % 4) * 4 + i / 4;  // column-major (etc.rs:324-327)
+        selectors |= (uint64_t)(best & 7u) << (45 - 3 * id);
+    }
+    const uint32_t shi = (uint32_t)(selectors >> 32), slo = (uint32_t)selectors;
+    out[0] = (uint32_t)center | (etc2tm << 8) | (((shi >> 8) & 0xFFu) << 16) | ((shi & 0xFFu) << 24);
+    out[1] = (slo >> 24) | (((slo >> 16) & 0xFFu) << 8) | (((slo >> 8) & 0xFFu) << 16) | ((slo & 0xFFu) << 24);
+}
+
+// apply_etc1_bias for one channel (etc.rs:236-255); delta in -2..1
+BU_DEV int bu_etc1_bias1(int v, int delta, int limit)
+{
+    if (v == 0) return v + (delta == -2 ? 3 : delta + 1);
+    if (v == limit) return v + delta - 1;
+    int r = v + delta;
+    if (r < 0 || r > limit) r = v - delta;
+    return r;
+}
+
+// out: ETC1 -> out[0..1]; ETC2 -> out[0..1] alpha, out[2..3] colour (etc.rs:19-30)
+template <int M, bool ETC2>
+BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
+{
+    uint32_t* col = ETC2 ? out + 2 : out;
+    if constexpr (M == 8) {
+        const uint32_t c = bu_bits(b, 5, 32);
+        if constexpr (ETC2) bu_eac_solid(out, c >> 24);
+        // uastc.rs:400-409: etc1d(1) etc1i(3) etc1s(2) etc1r(5) etc1g(5) etc1b(5) from bit 37
+        const uint32_t d = bu_bits(b, 37, 1), in = bu_bits(b, 38, 3), s = bu_bits(b, 41, 2);
+        const uint32_t r = bu_bits(b, 43, 5), g = bu_bits(b, 48, 5), bl = bu_bits(b, 53, 5);
+        uint32_t b0, b1, b2;
+        if (!d) {  // u8 arithmetic, release-build wrapping (etc.rs:54-56)
+            b0 = ((r << 4) | r) & 0xFFu;
+            b1 = ((g << 4) | g) & 0xFFu;
+            b2 = ((bl << 4) | bl) & 0xFFu;
+        } else {
+            b0 = (r << 3) & 0xFFu;
+            b1 = (g << 3) & 0xFFu;
+            b2 = (bl << 3) & 0xFFu;
+        }
+        const uint32_t b3 = ((in << 5) | (in << 2) | (d << 1)) & 0xFFu;
+        col[0] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        // selector id -> ETC1 code [3,2,0,1]; high plane in bytes 4-5, low plane in bytes 6-7 (etc.rs:68-73)
+        const uint32_t code = (0x4Bu >> (2 * s)) & 3u;  // 0b01_00_10_11
+        col[1] = ((code & 2u) ? 0x0000FFFFu : 0u) | ((code & 1u) ? 0xFFFF0000u : 0u);
+        return BU_ST_OK;
+    } else {
+        using L = BuLayout<M>;
+        uint32_t px[16];
+        const int st = bu_block_rgba<M>(T, b, px);
+        if (st) return st;
+        const uint32_t f = bu_bits(b, L::pos_etc1f, 1), d = bu_bits(b, L::pos_etc1d, 1);
+        const uint32_t i0 = bu_bits(b, L::pos_etc1i0, 3), i1 = bu_bits(b, L::pos_etc1i1, 3);
+        if constexpr (ETC2) {
+            if constexpr (L::has_alpha) bu_eac_block(T, out, bu_bits(b, L::pos_etc2tm, 8), px);
+            else bu_eac_solid(out, 255);  // etc2tm = 0 for RGB modes (uastc.rs:430-434)
+        }
+        // quadrant sums: R and B in 16-bit lanes of one word, G separately
+        uint32_t qrb[4] = {0, 0, 0, 0}, qg[4] = {0, 0, 0, 0};
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const int q = ((i >> 3) << 1) | ((i >> 1) & 1);  // row>=2, col>=2
+            qrb[q] += px[i] & 0x00FF00FFu;
+            qg[q] += (px[i] >> 8) & 0xFFu;
+        }
+        // flip (etc1f) : halves are rows 0-1 / 2-3; otherwise columns 0-1 / 2-3 (etc.rs:86-95)
+        const uint32_t srb0 = qrb[0] + (f ? qrb[1] : qrb[2]), srb1 = qrb[3] + (f ? qrb[2] : qrb[1]);
+        const uint32_t sg0 = qg[0] + (f ? qg[1] : qg[2]), sg1 = qg[3] + (f ? qg[2] : qg[1]);
+        const int limit = d ? 31 : 15;
+        int c[2][3];
+        {
+            const uint32_t sums[2][3] = {{srb0 & 0xFFFFu, sg0, srb0 >> 16}, {srb1 & 0xFFFFu, sg1, srb1 >> 16}};
+            BU_UNROLL
+            for (int sb = 0; sb < 2; sb++)
+                BU_UNROLL
+                for (int ch = 0; ch < 3; ch++) {
+                    // (sum*limit + 1020) / 2040  (etc.rs:109) = floor(floor(x/8)/255)
+                    const uint32_t y = (sums[sb][ch] * (uint32_t)limit + 1020u) >> 3;
+                    c[sb][ch] = (int)((y + 1u + (y >> 8)) >> 8);
+                }
+        }
+        if constexpr (!L::m1012) {
+            const uint32_t packed = T.etc1_bias[bu_bits(b, L::pos_etc1bias, 5)];
+            BU_UNROLL
+            for (int sb = 0; sb < 2; sb++)
+                BU_UNROLL
+                for (int ch = 0; ch < 3; ch++) c[sb][ch] = bu_etc1_bias1(c[sb][ch], (int)((packed >> (2 * (sb * 3 + ch))) & 3u) - 2, limit);
+        }
+        int base[2][3];
+        uint32_t hdr = 0;
+        BU_UNROLL
+        for (int ch = 0; ch < 3; ch++) {
+            uint32_t byte;
+            if (!d) {  // individual 4+4 bits (etc.rs:122-129)
+                byte = (((uint32_t)c[0][ch] << 4) | (uint32_t)c[1][ch]) & 0xFFu;
+                base[0][ch] = c[0][ch] * 17;
+                base[1][ch] = c[1][ch] * 17;
+            } else {  // differential 5 bits + clamped 3-bit delta (etc.rs:130-149)
+                const int dl = bu_clampi(c[1][ch] - c[0][ch], -4, 3);
+                byte = (((uint32_t)c[0][ch] << 3) | ((uint32_t)dl & 7u)) & 0xFFu;
+                const int c1 = (c[0][ch] + dl) & 0xFF;
+                base[0][ch] = ((c[0][ch] << 3) | (c[0][ch] >> 2)) & 0xFF;
+                base[1][ch] = ((c1 << 3) | (c1 >> 2)) & 0xFF;
+            }
+            hdr |= byte << (8 * ch);
+        }
+        hdr |= (((i0 << 5) | (i1 << 2) | (d << 1) | f) & 0xFFu) << 24;  // etc.rs:151-158
+        col[0] = hdr;
+
+        // luma thresholds per half (etc.rs:165-177)
+        int thr[2][3];
+        BU_UNROLL
+        for (int sb = 0; sb < 2; sb++) {
+            const uint32_t inten = sb ? i1 : i0;
+            int lum[4];
+            BU_UNROLL
+            for (int k = 0; k < 4; k++) {
+                const int md = T.etc1_mod[inten * 4 + k];
+                lum[k] = bu_clampi(base[sb][0] + md, 0, 255) * 108 + bu_clampi(base[sb][1] + md, 0, 255) * 366 +
+                         bu_clampi(base[sb][2] + md, 0, 255) * 38;
+            }
+            thr[sb][0] = (lum[0] + lum[1]) >> 1;
+            thr[sb][1] = (lum[1] + lum[2]) >> 1;
+            thr[sb][2] = (lum[2] + lum[3]) >> 1;
+        }
+        uint32_t msbp = 0, lsbp = 0;  // bit pixel_id = x*4 + y (etc.rs:376-392)
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const int y = i >> 2, x = i & 3;
+            const bool sb = f ? (y >= 2) : (x >= 2);
+            const int t0 = sb ? thr[1][0] : thr[0][0], t1 = sb ? thr[1][1] : thr[0][1], t2 = sb ? thr[1][2] : thr[0][2];
+            const int lum = (int)(px[i] & 0xFFu) * 108 + (int)((px[i] >> 8) & 0xFFu) * 366 + (int)((px[i] >> 16) & 0xFFu) * 38;
+            const uint32_t ge0 = lum >= t0, ge1 = lum >= t1, ge2 = lum >= t2;
+            // sel = ge0+ge1+ge2; ETC1 code [3,2,0,1][sel]: high bit = sel<2, low bit = sel==0 || sel==3
+            const uint32_t hi = ge1 ^ 1u, lo = (ge0 ^ 1u) | ge2;
+            const int pid = x * 4 + y;
+            msbp |= hi << pid;
+            lsbp |= lo << pid;
+        }
+        col[1] = ((msbp >> 8) & 0xFFu) | ((msbp & 0xFFu) << 8) | (((lsbp >> 8) & 0xFFu) << 16) | ((lsbp & 0xFFu) << 24);
+        return BU_ST_OK;
+    }
+}

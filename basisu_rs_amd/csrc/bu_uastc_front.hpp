@@ -1,0 +1,334 @@
+// UASTC block front-end for the gfx950 kernels: mode layout, field extraction, endpoint and weight
+// decode.  Replaces (as register bit-field code, one lane per block) the reference's
+//   src/uastc.rs:329-441   decode_mode / trans flags / compsel / pattern index
+//   src/uastc.rs:585-695   decode_endpoints + unquant_endpoint
+//   src/uastc.rs:721-740   decode_weights
+//   src/uastc.rs:176-327   assemble_endpoint_pairs / astc_interpolate / decode_block_to_rgba
+//   src/bitreader.rs:3-61  (all field positions are compile-time per mode, so there is no cursor)
+//
+// Everything is a template on the UASTC mode: a mode fixes every field position, so after inlining
+// the code for one mode is straight-line bit-field extraction with immediate operands.  The same
+// source compiles as plain C++ (BU_HOST_EMUL, tests only) so the exact kernel logic can be checked
+// against the oracle on a machine without a GPU.
+#pragma once
+#include "bu_tables_dev.hpp"
+
+#if defined(__HIPCC__)
+#define BU_DEV __device__ __forceinline__
+#define BU_UNROLL _Pragma("unroll")
+#else
+#define BU_DEV static inline __attribute__((always_inline))
+#define BU_UNROLL _Pragma("GCC unroll 32")
+#endif
+
+enum { BU_ST_OK = 0, BU_ST_BAD_MODE = 1, BU_ST_BAD_PATTERN = 2 };
+enum { BU_FMT_RGB = 0, BU_FMT_RGBA = 1, BU_FMT_LA = 2 };
+
+struct BuBlk {
+    uint32_t w[4];
+};
+
+BU_DEV uint32_t bu_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+BU_DEV uint32_t bu_brev(uint32_t v)
+{
+#if defined(__HIPCC__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+
+// n bits at bit position pos of the 128-bit block; bits past the end read as 0 (bitreader.rs:45,55).
+// pos and n are compile-time constants at every call site after unrolling, so this folds to one
+// shift/alignbit + and.
+BU_DEV uint32_t bu_bits(const BuBlk& b, int pos, int n)
+{
+    if (n <= 0 || pos >= 128) return 0;
+    const int wi = pos >> 5, sh = pos & 31;
+    const uint32_t lo = b.w[wi];
+    const uint32_t hi = (wi < 3) ? b.w[wi < 3 ? wi + 1 : 3] : 0u;
+    uint32_t v = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+    return n < 32 ? (v & ((1u << n) - 1u)) : v;
+}
+
+// OR an n-bit value into a zeroed 128-bit output at a compile-time position (bitwriter.rs:23-51).
+// v must already be < 2^n.
+BU_DEV void bu_put(uint32_t out[4], int pos, int n, uint32_t v)
+{
+    if (n <= 0 || pos >= 128) return;
+    const int wi = pos >> 5, sh = pos & 31;
+    out[wi] |= v << sh;
+    if (sh + n > 32 && wi < 3) out[wi < 3 ? wi + 1 : 3] |= v >> (32 - sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mode facts (uastc.rs:528-557) and the field layout they imply.
+struct BuModeDesc {
+    int code_size, range, fmt, wb, planes, subsets, tf_bits;
+};
+constexpr BuModeDesc BU_MODE_DESC[19] = {
+    {4, 19, BU_FMT_RGB, 4, 1, 1, 15},  {6, 20, BU_FMT_RGB, 2, 1, 1, 15},  {5, 8, BU_FMT_RGB, 3, 1, 2, 15},
+    {5, 7, BU_FMT_RGB, 2, 1, 3, 15},   {5, 12, BU_FMT_RGB, 2, 1, 2, 15},  {5, 20, BU_FMT_RGB, 3, 1, 1, 15},
+    {5, 18, BU_FMT_RGB, 2, 2, 1, 15},  {5, 12, BU_FMT_RGB, 2, 1, 2, 15},  {5, 0, BU_FMT_RGBA, 0, 1, 1, 0},
+    {5, 8, BU_FMT_RGBA, 2, 1, 2, 23},  {3, 13, BU_FMT_RGBA, 4, 1, 1, 17}, {2, 13, BU_FMT_RGBA, 2, 2, 1, 17},
+    {3, 19, BU_FMT_RGBA, 3, 1, 1, 17}, {5, 20, BU_FMT_RGBA, 1, 2, 1, 23}, {5, 20, BU_FMT_RGBA, 2, 1, 1, 23},
+    {7, 20, BU_FMT_LA, 4, 1, 1, 23},   {6, 20, BU_FMT_LA, 2, 1, 2, 23},   {6, 20, BU_FMT_LA, 2, 2, 1, 23},
+    {4, 11, BU_FMT_RGB, 5, 1, 1, 15},
+};
+
+// BISE range facts for the ranges UASTC uses (astc.rs:309-331)
+constexpr int bu_bise_bits(int r) { return r == 7 ? 2 : r == 8 ? 4 : r == 11 ? 5 : r == 12 ? 3 : r == 13 ? 4 : r == 18 ? 5 : r == 19 ? 6 : r == 20 ? 8 : 0; }
+constexpr bool bu_bise_trits(int r) { return r == 7 || r == 13 || r == 19; }
+constexpr bool bu_bise_quints(int r) { return r == 12 || r == 18; }
+
+template <int M>
+struct BuLayout {
+    static constexpr BuModeDesc d = BU_MODE_DESC[M];
+    static constexpr int channels = d.fmt == BU_FMT_RGB ? 3 : d.fmt == BU_FMT_RGBA ? 4 : 2;
+    static constexpr int ep_count = channels * d.subsets * 2;
+    static constexpr int ebits = bu_bise_bits(d.range);
+    static constexpr bool trits = bu_bise_trits(d.range);
+    static constexpr bool quints = bu_bise_quints(d.range);
+    static constexpr bool m1012 = (M >= 10 && M <= 12);
+    static constexpr bool has_alpha = d.fmt != BU_FMT_RGB;
+    // transcoding flags (uastc.rs:411-436), positions relative to the block
+    static constexpr int pos_tf = d.code_size;
+    static constexpr int pos_etc1f = pos_tf + (m1012 ? 1 : 2);
+    static constexpr int pos_etc1d = pos_etc1f + 1;
+    static constexpr int pos_etc1i0 = pos_etc1d + 1;
+    static constexpr int pos_etc1i1 = pos_etc1i0 + 3;
+    static constexpr int pos_etc1bias = pos_etc1i1 + 3;            // 5 bits, absent for modes 10-12
+    static constexpr int pos_etc2tm = pos_etc1bias + (m1012 ? 0 : 5);  // 8 bits if has_alpha
+    static constexpr int pos_compsel = pos_tf + d.tf_bits;
+    static constexpr int compsel_bits = (d.planes == 2 && d.fmt != BU_FMT_LA) ? 2 : 0;
+    static constexpr int pos_pat = pos_compsel + compsel_bits;
+    static constexpr int pat_bits = (M == 7 || d.subsets == 2) ? 5 : (d.subsets == 3 ? 4 : 0);
+    static constexpr int pat_count = M == 7 ? 19 : (d.subsets == 2 ? 30 : (d.subsets == 3 ? 11 : 1));
+    static constexpr int part_base = M == 7 ? BU_PART_BASE23 : (d.subsets == 2 ? BU_PART_BASE2 : (d.subsets == 3 ? BU_PART_BASE3 : BU_PART_MODE1));
+    static constexpr int pos_ep = pos_pat + pat_bits;
+    static constexpr int tq_rem = quints ? ep_count % 3 : (trits ? ep_count % 5 : 0);
+    static constexpr int tq_full = quints ? ep_count / 3 : (trits ? ep_count / 5 : 0);
+    static constexpr int tq_rem_bits = quints ? (tq_rem == 1 ? 3 : tq_rem == 2 ? 5 : 0)
+                                              : (trits ? (tq_rem == 1 ? 2 : tq_rem == 2 ? 4 : tq_rem == 3 ? 5 : tq_rem == 4 ? 7 : 0) : 0);
+    static constexpr int tq_bits = tq_full * (quints ? 7 : 8) + tq_rem_bits;
+    static constexpr int pos_epbits = pos_ep + tq_bits;
+    static constexpr int pos_w = pos_epbits + ep_count * ebits;
+    static constexpr int n_anch = d.subsets == 1 ? d.planes : d.subsets;  // weight MSBs that are not stored
+    static constexpr int w_total = 16 * d.planes * d.wb;                   // bits after regularisation
+    static constexpr int w_raw = w_total - n_anch;
+    static constexpr int w_words = (w_total + 31) / 32;
+    static_assert(M == 8 || pos_w + w_raw <= 128, "mode does not fit in 128 bits");
+};
+
+// ------------------------------------------------------------------------------------------------
+// Quantised endpoints (uastc.rs:616-695): tq[i] = trit/quint digit, eb[i] = plain bits.
+template <int M>
+BU_DEV void bu_decode_quant(const BuTables& T, const BuBlk& b, uint32_t tq[18], uint32_t eb[18])
+{
+    using L = BuLayout<M>;
+    BU_UNROLL
+    for (int i = 0; i < 18; i++) {
+        tq[i] = 0;
+        eb[i] = 0;
+    }
+    if constexpr (L::quints) {
+        BU_UNROLL
+        for (int g = 0; g < L::tq_full; g++) {
+            const uint32_t dg = T.quint3[bu_bits(b, L::pos_ep + 7 * g, 7)];
+            BU_UNROLL
+            for (int k = 0; k < 3; k++) tq[3 * g + k] = (dg >> (3 * k)) & 7u;
+        }
+        if constexpr (L::tq_rem > 0) {
+            const uint32_t dg = T.quint3[bu_bits(b, L::pos_ep + 7 * L::tq_full, L::tq_rem_bits)];
+            BU_UNROLL
+            for (int k = 0; k < L::tq_rem; k++) tq[3 * L::tq_full + k] = (dg >> (3 * k)) & 7u;
+        }
+    }
+    if constexpr (L::trits) {
+        BU_UNROLL
+        for (int g = 0; g < L::tq_full; g++) {
+            const uint32_t dg = T.trit5[bu_bits(b, L::pos_ep + 8 * g, 8)];
+            BU_UNROLL
+            for (int k = 0; k < 5; k++) tq[5 * g + k] = (dg >> (2 * k)) & 3u;
+        }
+        if constexpr (L::tq_rem > 0) {
+            const uint32_t dg = T.trit5[bu_bits(b, L::pos_ep + 8 * L::tq_full, L::tq_rem_bits)];
+            BU_UNROLL
+            for (int k = 0; k < L::tq_rem; k++) tq[5 * L::tq_full + k] = (dg >> (2 * k)) & 3u;
+        }
+    }
+    BU_UNROLL
+    for (int i = 0; i < L::ep_count; i++) eb[i] = bu_bits(b, L::pos_epbits + L::ebits * i, L::ebits);
+}
+
+// Dequantised endpoint (uastc.rs:585-614): bit replication for the plain-bit ranges, LUT otherwise.
+template <int RANGE>
+BU_DEV uint32_t bu_deq(const BuTables& T, uint32_t tq, uint32_t eb)
+{
+    if constexpr (RANGE == 20) return eb;
+    else if constexpr (RANGE == 8) return eb * 17u;
+    else if constexpr (RANGE == 11) return (eb << 3) | (eb >> 2);
+    else return T.deq[bu_deq_ofs(RANGE) + ((tq << bu_bise_bits(RANGE)) | eb)];
+}
+
+template <int M>
+BU_DEV void bu_decode_endpoints(const BuTables& T, const BuBlk& b, uint32_t e[18])
+{
+    using L = BuLayout<M>;
+    uint32_t tq[18], eb[18];
+    bu_decode_quant<M>(T, b, tq, eb);
+    BU_UNROLL
+    for (int i = 0; i < 18; i++) e[i] = i < L::ep_count ? bu_deq<L::d.range>(T, tq[i], eb[i]) : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weights (uastc.rs:721-740).  The stored stream drops the MSB of one anchor weight per subset (per
+// plane).  We re-insert those zero bits so that texel i / plane p sits at bit (i*planes+p)*wb of a
+// regular bit string W (up to 80 bits in 3 words): every later step is then plain SWAR.
+BU_DEV void bu_ins0_static(uint32_t W[3], int nw, int q)  // nw, q compile-time
+{
+    const int k = q >> 5, s = q & 31;
+    for (int j = nw - 1; j > k; j--) W[j] = (W[j] << 1) | (W[j - 1] >> 31);
+    const uint32_t low = (1u << s) - 1u;
+    W[k] = (W[k] & low) | ((W[k] & ~low) << 1);
+}
+BU_DEV uint32_t bu_ins0_rt32(uint32_t x, uint32_t q) { return x + (x & (0xFFFFFFFFu << q)); }
+BU_DEV void bu_ins0_rt64(uint32_t W[3], uint32_t q)
+{
+    uint64_t x = (uint64_t)W[0] | ((uint64_t)W[1] << 32);
+    x = x + (x & (~0ull << q));
+    W[0] = (uint32_t)x;
+    W[1] = (uint32_t)(x >> 32);
+}
+
+// uanch: UASTC anchor texels, nibble s = anchor of subset s (multi-subset modes only)
+template <int M>
+BU_DEV void bu_decode_weights(const BuBlk& b, uint32_t uanch, uint32_t W[3])
+{
+    using L = BuLayout<M>;
+    constexpr int wb = L::d.wb;
+    W[0] = bu_bits(b, L::pos_w, L::w_raw < 32 ? L::w_raw : 32);
+    W[1] = L::w_raw > 32 ? bu_bits(b, L::pos_w + 32, L::w_raw - 32 < 32 ? L::w_raw - 32 : 32) : 0u;
+    W[2] = L::w_raw > 64 ? bu_bits(b, L::pos_w + 64, L::w_raw - 64) : 0u;
+    // texel 0 is an anchor in every pattern (uastc.rs:792-811 always list a 0)
+    bu_ins0_static(W, L::w_words, wb - 1);
+    if constexpr (L::d.planes == 2) bu_ins0_static(W, L::w_words, 2 * wb - 1);
+    if constexpr (L::d.subsets == 2) {
+        const uint32_t a = (uanch | (uanch >> 4)) & 15u;  // the non-zero one of the two
+        if constexpr (L::w_words == 1) W[0] = bu_ins0_rt32(W[0], a * wb + (wb - 1));
+        else bu_ins0_rt64(W, a * wb + (wb - 1));
+    }
+    if constexpr (L::d.subsets == 3) {
+        const uint32_t x = uanch & 15u, y = (uanch >> 4) & 15u, z = (uanch >> 8) & 15u;
+        uint32_t hi = x > y ? x : y;
+        hi = hi > z ? hi : z;
+        const uint32_t lo = x + y + z - hi;
+        static_assert(L::d.subsets != 3 || L::w_words == 1, "3-subset modes have 2-bit weights");
+        W[0] = bu_ins0_rt32(W[0], lo * wb + (wb - 1));
+        W[0] = bu_ins0_rt32(W[0], hi * wb + (wb - 1));
+    }
+}
+
+// raw weight k (k = texel*planes + plane) out of the regular string; k compile-time
+template <int WB>
+BU_DEV uint32_t bu_wfield(const uint32_t W[3], int k)
+{
+    const int pos = k * WB, wi = pos >> 5, sh = pos & 31;
+    uint32_t v = W[wi] >> sh;
+    if (sh + WB > 32) v |= W[wi + 1] << (32 - sh);
+    return v & ((1u << WB) - 1u);
+}
+
+// uastc.rs:697-719 as arithmetic (LUT1..LUT5 are reproduced exactly by these forms)
+template <int WB>
+BU_DEV uint32_t bu_wdeq(uint32_t r)
+{
+    if constexpr (WB == 1) return r << 6;
+    else if constexpr (WB == 2) return r * 21u + (r >> 1);
+    else if constexpr (WB == 3) return r * 9u + (r >> 2);
+    else if constexpr (WB == 4) return r * 4u + (r >> 2) + (r >> 3);
+    else return r * 2u + ((r >> 4) << 1);
+}
+
+// uastc.rs:218-235 with l64 = 64*l, d = h-l:  ((l*257)*(64-w) + (h*257)*w + 32) >> 14
+BU_DEV uint32_t bu_lerp(int l64, int d, uint32_t w) { return (uint32_t)((l64 + (int)w * d) * 257 + 32) >> 14; }
+
+// ------------------------------------------------------------------------------------------------
+// Full unpack to 16 RGBA8 texels, row-major inside the block, little-endian R,G,B,A
+// (uastc.rs:237-327; color.rs:22-24).
+template <int M>
+BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
+{
+    using L = BuLayout<M>;
+    if constexpr (M == 8) {
+        const uint32_t c = bu_bits(b, 5, 32);  // R,G,B,A bytes right after the 5-bit code (uastc.rs:387-394)
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) px[i] = c;
+        return BU_ST_OK;
+    } else {
+        constexpr int wb = L::d.wb, planes = L::d.planes, subsets = L::d.subsets, fmt = L::d.fmt;
+        uint32_t pat = 0, upat = 0, uanch = 0;
+        if constexpr (L::pat_bits > 0) {
+            pat = bu_bits(b, L::pos_pat, L::pat_bits);
+            if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;  // uastc.rs:360-365
+            upat = T.part[L::part_base + pat].upat;
+            uanch = T.part[L::part_base + pat].uanch;
+        }
+        const uint32_t compsel = L::compsel_bits ? bu_bits(b, L::pos_compsel, 2) : 3u;  // uastc.rs:343-350
+
+        uint32_t e[18];
+        bu_decode_endpoints<M>(T, b, e);
+        uint32_t W[3];
+        bu_decode_weights<M>(b, uanch, W);
+
+        // per subset, per output channel: 64*lo and hi-lo (uastc.rs:176-216 gives the channel order)
+        constexpr int NC = fmt == BU_FMT_RGB ? 3 : (fmt == BU_FMT_RGBA ? 4 : 2);  // distinct interpolations
+        int l64[3][4], dd[3][4];
+        BU_UNROLL
+        for (int s = 0; s < subsets; s++) {
+            BU_UNROLL
+            for (int c = 0; c < NC; c++) {
+                const int lo = (int)e[(2 * L::channels) * s + 2 * c], hi = (int)e[(2 * L::channels) * s + 2 * c + 1];
+                l64[s][c] = lo * 64;
+                dd[s][c] = hi - lo;
+            }
+        }
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            uint32_t sid = 0;
+            if constexpr (subsets > 1) sid = (upat >> (2 * i)) & 3u;
+            const uint32_t w0 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes));
+            uint32_t w1 = w0;
+            if constexpr (planes == 2) w1 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes + 1));
+            uint32_t v[4];
+            BU_UNROLL
+            for (int c = 0; c < NC; c++) {
+                int L0 = l64[0][c], D0 = dd[0][c];
+                if constexpr (subsets >= 2) {
+                    L0 = sid == 1 ? l64[1][c] : L0;
+                    D0 = sid == 1 ? dd[1][c] : D0;
+                }
+                if constexpr (subsets == 3) {
+                    L0 = sid == 2 ? l64[2][c] : L0;
+                    D0 = sid == 2 ? dd[2][c] : D0;
+                }
+                // plane-1 weight drives the compsel channel (uastc.rs:293-296); for LA the second
+                // interpolation is alpha and compsel is fixed to A
+                uint32_t w = w0;
+                if constexpr (planes == 2) {
+                    if constexpr (fmt == BU_FMT_LA) w = (c == 1) ? w1 : w0;
+                    else w = (compsel == (uint32_t)c) ? w1 : w0;
+                }
+                v[c] = bu_lerp(L0, D0, w);
+            }
+            if constexpr (fmt == BU_FMT_RGB) px[i] = v[0] | (v[1] << 8) | (v[2] << 16) | 0xFF000000u;
+            else if constexpr (fmt == BU_FMT_RGBA) px[i] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            else px[i] = v[0] * 0x010101u | (v[1] << 24);
+        }
+        return BU_ST_OK;
+    }
+}

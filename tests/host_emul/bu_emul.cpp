@@ -1,0 +1,46 @@
+// TEST-ONLY host build of the kernels' per-block code (the same headers the HIP kernels include,
+// compiled as plain C++).  It lets the CPU test-suite compare the exact device logic with the
+// oracle on millions of blocks in a container that has no GPU.  It is never part of the product
+// library and nothing under basisu_rs_amd/ loads it.
+#include "bu_uastc_dispatch.hpp"
+
+static BuTables g_tables;
+static bool g_init = false;
+static const BuTables& tables()
+{
+    if (!g_init) {
+        bu_build_tables(&g_tables);
+        g_init = true;
+    }
+    return g_tables;
+}
+
+extern "C" {
+// returns 0 ok / 1 bad mode / 2 bad pattern; out sized 16/16/8/16/64 bytes
+int bu_emul_block(int target, const uint8_t* in, uint8_t* out)
+{
+    const BuTables& T = tables();
+    BuBlk b;
+    memcpy(b.w, in, 16);
+    const uint32_t mode = T.mode_lut[b.w[0] & 127u];
+    uint32_t o[16] = {0};
+    int st;
+    switch (target) {
+    case BU_TGT_ASTC: st = bu_block_any<BU_TGT_ASTC>(T, mode, b, o); break;
+    case BU_TGT_BC7: st = bu_block_any<BU_TGT_BC7>(T, mode, b, o); break;
+    case BU_TGT_ETC1: st = bu_block_any<BU_TGT_ETC1>(T, mode, b, o); break;
+    case BU_TGT_ETC2: st = bu_block_any<BU_TGT_ETC2>(T, mode, b, o); break;
+    default: st = bu_block_any<BU_TGT_RGBA>(T, mode, b, o); break;
+    }
+    const int n = target == BU_TGT_ETC1 ? 8 : (target == BU_TGT_RGBA ? 64 : 16);
+    memcpy(out, o, n);
+    return st;
+}
+// block-linear batch (RGBA = 64 bytes per block); stops at nothing, statuses in st[]
+void bu_emul_batch(int target, const uint8_t* in, size_t n_blocks, uint8_t* out, uint8_t* st)
+{
+    const size_t obs = target == BU_TGT_ETC1 ? 8 : (target == BU_TGT_RGBA ? 64 : 16);
+    for (size_t i = 0; i < n_blocks; i++) st[i] = (uint8_t)bu_emul_block(target, in + 16 * i, out + obs * i);
+}
+size_t bu_emul_tables_size(void) { return sizeof(BuTables); }
+}
