@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI (include/basisu_hip.h).  There is no fallback: if the HIP shared
+library is missing this module raises, and every call needs a gfx950 device."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbasisu_hip.so")
+
+# bu_target
+ASTC, BC7, ETC1, ETC2, RGBA32 = 0, 1, 2, 3, 4
+BLOCK_BYTES = {ASTC: 16, BC7: 16, ETC1: 8, ETC2: 16, RGBA32: 64}
+# bu_status
+OK, ERR_INVALID_MODE, ERR_INVALID_PATTERN, ERR_LENGTH, ERR_OUTPUT_SIZE, ERR_ARGUMENT, ERR_INDEX_RANGE, ERR_NO_DEVICE, ERR_HIP = range(9)
+STATUS_WORD_CLEAR = 0xFFFFFFFFFFFFFFFF
+
+# every symbol include/basisu_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "bu_context_create", "bu_context_destroy", "bu_status_string", "bu_last_error", "bu_target_block_bytes",
+    "bu_uastc_transcode", "bu_uastc_decode_to_rgba",
+    "bu_unpack_uastc_block_to_rgba", "bu_transcode_uastc_block_to_astc", "bu_transcode_uastc_block_to_bc7",
+    "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2",
+    "bu_uastc_transcode_device", "bu_status_word_reset", "bu_status_word_decode",
+    "bu_etc1s_selector_from_rows", "bu_etc1s_transcode_etc1_device", "bu_etc1s_decode_rgba_device",
+    "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
+    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_copy_launches",
+]
+
+_lib = None
+
+
+def load():
+    """Load libbasisu_hip.so (built by basisu_rs_amd/build.py).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "basisu_rs_amd: %s is missing -- build it with `python -m basisu_rs_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, sz, u64p, u32 = c.c_void_p, c.c_size_t, c.POINTER(c.c_uint64), c.c_uint32
+    lib.bu_context_create.argtypes = [c.c_int, c.POINTER(vp)]
+    lib.bu_context_create.restype = c.c_int
+    lib.bu_context_destroy.argtypes = [vp]
+    lib.bu_context_destroy.restype = None
+    lib.bu_status_string.argtypes = [c.c_int]
+    lib.bu_status_string.restype = c.c_char_p
+    lib.bu_last_error.argtypes = [vp]
+    lib.bu_last_error.restype = c.c_char_p
+    lib.bu_target_block_bytes.argtypes = [c.c_int]
+    lib.bu_target_block_bytes.restype = sz
+    lib.bu_uastc_transcode.argtypes = [vp, c.c_int, vp, sz, vp, sz, u64p]
+    lib.bu_uastc_transcode.restype = c.c_int
+    lib.bu_uastc_decode_to_rgba.argtypes = [vp, vp, sz, sz, vp, sz, u64p]
+    lib.bu_uastc_decode_to_rgba.restype = c.c_int
+    for name in ("bu_unpack_uastc_block_to_rgba", "bu_transcode_uastc_block_to_astc", "bu_transcode_uastc_block_to_bc7",
+                 "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2"):
+        getattr(lib, name).argtypes = [vp, vp, vp]
+        getattr(lib, name).restype = c.c_int
+    lib.bu_uastc_transcode_device.argtypes = [vp, c.c_int, vp, sz, vp, sz, c.c_uint64, vp, vp]
+    lib.bu_uastc_transcode_device.restype = c.c_int
+    lib.bu_status_word_reset.argtypes = [vp, vp, vp]
+    lib.bu_status_word_reset.restype = c.c_int
+    lib.bu_status_word_decode.argtypes = [c.c_uint64, u64p]
+    lib.bu_status_word_decode.restype = c.c_int
+    lib.bu_etc1s_selector_from_rows.argtypes = [vp, vp]
+    lib.bu_etc1s_selector_from_rows.restype = None
+    lib.bu_etc1s_transcode_etc1_device.argtypes = [vp, vp, sz, vp, u32, vp, u32, vp, vp, vp]
+    lib.bu_etc1s_transcode_etc1_device.restype = c.c_int
+    lib.bu_etc1s_decode_rgba_device.argtypes = [vp, vp, vp, sz, sz, vp, u32, vp, u32, vp, vp, vp]
+    lib.bu_etc1s_decode_rgba_device.restype = c.c_int
+    lib.bu_etc1s_transcode_etc1.argtypes = [vp, vp, sz, vp, u32, vp, u32, vp, sz, u64p]
+    lib.bu_etc1s_transcode_etc1.restype = c.c_int
+    lib.bu_etc1s_decode_rgba.argtypes = [vp, vp, vp, sz, sz, vp, u32, vp, u32, vp, sz, u64p]
+    lib.bu_etc1s_decode_rgba.restype = c.c_int
+    lib.bu_copy_ceiling_device.argtypes = [vp, vp, sz, vp, vp]
+    lib.bu_copy_ceiling_device.restype = c.c_int
+    lib.bu_time_uastc_launches.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
+    lib.bu_time_uastc_launches.restype = c.c_int
+    lib.bu_time_copy_launches.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), sz, sz, c.c_int, vp, c.POINTER(c.c_float)]
+    lib.bu_time_copy_launches.restype = c.c_int
+    _lib = lib
+    return lib

@@ -1,0 +1,241 @@
+"""Python driver over the C ABI, shaped like the reference crate's API for the hot path so that the
+parity tests read like the reference's own tests (tests/transcode_uastc_block.rs).
+
+Reference items mirrored (file:line in /root/reference):
+  lib.rs:29-53      unpack_uastc_block_to_rgba, transcode_uastc_block_to_{astc,bc7,etc1,etc2}
+  uastc.rs:41-47    TargetTextureFormat
+  uastc.rs:77-146   Decoder::{read_to_uastc, decode_to_rgba, transcode}
+  lib.rs:26-27      Error = String  ->  BasisuError(message)
+
+The host logic itself (argument checks, staging, launch, status decode) is C++ inside
+libbasisu_hip.so; this module only marshals buffers.  All work runs on the GPU -- there is no CPU
+path here, and importing this module without the built library raises.
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from . import _lib
+
+
+class BasisuError(Exception):
+    """The reference's `Err(String)`; str(e) is the reference's message for hot-path errors."""
+
+    def __init__(self, status, first_bad_block=None, detail=None):
+        self.status = status
+        self.first_bad_block = first_bad_block
+        msg = _lib.load().bu_status_string(status).decode()
+        if detail:
+            msg += " (" + detail + ")"
+        super().__init__(msg)
+
+
+class TargetTextureFormat(enum.IntEnum):  # uastc.rs:41-47
+    Astc = _lib.ASTC
+    Bc7 = _lib.BC7
+    Etc1 = _lib.ETC1
+    Etc2 = _lib.ETC2
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    a = np.ascontiguousarray(a.reshape(-1).view(np.uint8))
+    return a
+
+
+class Context:
+    """Owns one bu_context (device tables, stream, staging buffers)."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        st = self._lib.bu_context_create(int(device), ctypes.byref(h))
+        if st != _lib.OK:
+            raise BasisuError(st)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bu_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _check(self, st, bad=None):
+        if st == _lib.OK:
+            return
+        detail = None
+        if st == _lib.ERR_HIP:
+            detail = self._lib.bu_last_error(self._h).decode()
+        raise BasisuError(st, bad.value if bad is not None and st in (_lib.ERR_INVALID_MODE, _lib.ERR_INVALID_PATTERN, _lib.ERR_INDEX_RANGE) else None, detail)
+
+    # ---- host-pointer slice API -----------------------------------------------------------------
+    def transcode(self, fmt, data):
+        """uastc::Decoder::transcode (uastc.rs:112-121): bytes in -> bytes out."""
+        a = _as_u8(data)
+        n = a.size // 16
+        out = np.empty(max(n, 1) * _lib.BLOCK_BYTES[int(fmt)], dtype=np.uint8)
+        bad = ctypes.c_uint64(0)
+        st = self._lib.bu_uastc_transcode(self._h, int(fmt), a.ctypes.data, a.size, out.ctypes.data, out.size, ctypes.byref(bad))
+        self._check(st, bad)
+        return out[: n * _lib.BLOCK_BYTES[int(fmt)]]
+
+    def decode_to_rgba(self, data, blocks_per_row):
+        """uastc::Decoder::decode_to_rgba (uastc.rs:89-110): row-major RGBA8 bytes."""
+        a = _as_u8(data)
+        n = a.size // 16
+        out = np.empty(max(n, 1) * 64, dtype=np.uint8)
+        bad = ctypes.c_uint64(0)
+        st = self._lib.bu_uastc_decode_to_rgba(self._h, a.ctypes.data, a.size, int(blocks_per_row), out.ctypes.data, out.size, ctypes.byref(bad))
+        self._check(st, bad)
+        return out[: n * 64]
+
+    def _block(self, fn, block, out_bytes):
+        a = _as_u8(block)
+        if a.size != 16:
+            raise ValueError("a UASTC block is 16 bytes")
+        out = np.empty(out_bytes, dtype=np.uint8)
+        st = fn(self._h, a.ctypes.data, out.ctypes.data)
+        self._check(st)
+        return out
+
+    # ---- ETC1S back-end -------------------------------------------------------------------------
+    def etc1s_transcode_to_etc1(self, idx, endpoints, selectors):
+        """basis_lz::Decoder::transcode_to_etc1 back-end (basis_lz/mod.rs:153-186)."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        endpoints = np.ascontiguousarray(endpoints, dtype=np.uint32)
+        selectors = np.ascontiguousarray(selectors, dtype=np.uint8).reshape(-1, 8)
+        out = np.empty(max(idx.size, 1) * 8, dtype=np.uint8)
+        bad = ctypes.c_uint64(0)
+        st = self._lib.bu_etc1s_transcode_etc1(self._h, idx.ctypes.data, idx.size, endpoints.ctypes.data, endpoints.size,
+                                               selectors.ctypes.data, selectors.shape[0], out.ctypes.data, out.size, ctypes.byref(bad))
+        self._check(st, bad)
+        return out[: idx.size * 8]
+
+    def etc1s_decode_to_rgba(self, idx, alpha_idx, nbx, nby, endpoints, selectors):
+        """basis_lz::Decoder::decode_to_rgba back-end (basis_lz/mod.rs:97-151)."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        aptr = None
+        if alpha_idx is not None:
+            alpha_idx = np.ascontiguousarray(alpha_idx, dtype=np.uint32)
+            aptr = alpha_idx.ctypes.data
+        endpoints = np.ascontiguousarray(endpoints, dtype=np.uint32)
+        selectors = np.ascontiguousarray(selectors, dtype=np.uint8).reshape(-1, 8)
+        n = int(nbx) * int(nby)
+        if idx.size != n:
+            raise ValueError("idx must hold nbx*nby entries")
+        out = np.empty(max(n, 1) * 64, dtype=np.uint8)
+        bad = ctypes.c_uint64(0)
+        st = self._lib.bu_etc1s_decode_rgba(self._h, idx.ctypes.data, aptr, int(nbx), int(nby), endpoints.ctypes.data, endpoints.size,
+                                            selectors.ctypes.data, selectors.shape[0], out.ctypes.data, out.size, ctypes.byref(bad))
+        self._check(st, bad)
+        return out[: n * 64]
+
+    # ---- device-pointer API (torch tensors or raw pointers) ---------------------------------------
+    def transcode_device(self, fmt, d_in, n_blocks, d_out, blocks_per_row=0, block_index_base=0, d_status=None, stream=None):
+        st = self._lib.bu_uastc_transcode_device(self._h, int(fmt), _ptr(d_in), int(n_blocks), _ptr(d_out), int(blocks_per_row),
+                                                 int(block_index_base), _ptr(d_status), _stream_ptr(stream))
+        self._check(st)
+
+    def status_word_reset(self, d_status, stream=None):
+        self._check(self._lib.bu_status_word_reset(self._h, _ptr(d_status), _stream_ptr(stream)))
+
+    def status_word_check(self, word):
+        bad = ctypes.c_uint64(0)
+        st = self._lib.bu_status_word_decode(int(word) & 0xFFFFFFFFFFFFFFFF, ctypes.byref(bad))
+        self._check(st, bad)
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(int(x))
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except ImportError:
+            pass
+        return None
+    if hasattr(stream, "cuda_stream"):
+        return ctypes.c_void_p(stream.cuda_stream)
+    return ctypes.c_void_p(int(stream))
+
+
+def etc1s_selector_from_rows(rows):
+    """etc::Selector::set_selector for the 16 texels of one codebook entry (etc.rs:363-393)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1, 4)
+    out = np.empty((rows.shape[0], 8), dtype=np.uint8)
+    lib = _lib.load()
+    for i in range(rows.shape[0]):
+        lib.bu_etc1s_selector_from_rows(rows[i].ctypes.data, out[i].ctypes.data)
+    return out
+
+
+# ---- module-level mirror of the reference's free functions / Decoder --------------------------------
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Decoder:
+    """uastc::Decoder (uastc.rs:77-146)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def read_to_uastc(self, data):  # uastc.rs:85-87
+        return bytes(data)
+
+    def decode_to_rgba(self, data, blocks_per_row):  # uastc.rs:89-110
+        return self.ctx.decode_to_rgba(data, blocks_per_row)
+
+    def transcode(self, fmt, data):  # uastc.rs:112-121
+        return self.ctx.transcode(TargetTextureFormat(fmt), data)
+
+
+def unpack_uastc_block_to_rgba(data, ctx=None):  # lib.rs:29-31 -> [u32; 16]
+    c = ctx or default_context()
+    return c._block(c._lib.bu_unpack_uastc_block_to_rgba, data, 64).view("<u4").copy()
+
+
+def transcode_uastc_block_to_astc(data, ctx=None):  # lib.rs:33-37
+    c = ctx or default_context()
+    return c._block(c._lib.bu_transcode_uastc_block_to_astc, data, 16)
+
+
+def transcode_uastc_block_to_bc7(data, ctx=None):  # lib.rs:39-41
+    c = ctx or default_context()
+    return c._block(c._lib.bu_transcode_uastc_block_to_bc7, data, 16)
+
+
+def transcode_uastc_block_to_etc1(data, ctx=None):  # lib.rs:43-47
+    c = ctx or default_context()
+    return c._block(c._lib.bu_transcode_uastc_block_to_etc1, data, 8)
+
+
+def transcode_uastc_block_to_etc2(data, ctx=None):  # lib.rs:49-53
+    c = ctx or default_context()
+    return c._block(c._lib.bu_transcode_uastc_block_to_etc2, data, 16)

@@ -1,0 +1,48 @@
+"""Builds the gfx950 shared library (the C ABI of include/basisu_hip.h) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+basisu_rs_amd/libbasisu_hip.so travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbasisu_hip.so")
+
+
+def _newer_than(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def sources():
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    out.append(os.path.join(HERE, "..", "include", "basisu_hip.h"))
+    return out
+
+
+def build_hip(force=False, verbose=False):
+    """Compile csrc/bu_hip.hip for gfx950 -> libbasisu_hip.so.  Returns the library path."""
+    if not force and _newer_than(LIB, sources()):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB, os.path.join(CSRC, "bu_hip.hip")]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libbasisu_hip.so")
+    if verbose:
+        sys.stderr.write(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose="-v" in sys.argv))

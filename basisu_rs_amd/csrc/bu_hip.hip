@@ -1,0 +1,594 @@
+// gfx950 kernels and the C ABI (include/basisu_hip.h) of the UASTC / ETC1S block-transcode path.
+//
+// Data layout in HBM
+//   UASTC slice      n x 16-byte blocks, raster order (uastc.rs:49-75)            -> read once as uint4
+//   ASTC/BC7/ETC2    n x 16-byte blocks, same order                                -> written once as uint4
+//   ETC1             n x  8-byte blocks                                            -> uint2
+//   RGBA32           row-major image, pitch 16*blocks_per_row bytes (uastc.rs:96) -> 4 x uint4 per block
+//   tables           one BuTables blob (5.8 KiB), copied to LDS by every workgroup
+// Mapping: one lane = one block.  A wave reads 64 x 16 B = 1 KiB contiguous and writes 1 KiB (512 B
+// for ETC1; for RGBA32 four 1 KiB row segments when the row has >= 64 blocks).  No MFMA: the work is
+// bit-field surgery on 128-bit values; the bound is HBM (see DESIGN.md for bytes/block).
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+
+#include "../../include/basisu_hip.h"
+#include "bu_uastc_dispatch.hpp"
+
+namespace {
+
+constexpr int BU_WG = 256;            // 4 waves
+constexpr int BU_TABLE_VEC = (int)(sizeof(BuTables) / 16);
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bu_stage_tables(BuTables& dst, const BuTables* __restrict__ src)
+{
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(&dst);
+    for (int i = threadIdx.x; i < BU_TABLE_VEC; i += BU_WG) d[i] = s[i];
+}
+
+__device__ __forceinline__ void bu_report(unsigned long long* status, unsigned long long block, int st)
+{
+    if (status) atomicMin(status, (block << 8) | (unsigned long long)st);
+}
+
+// UASTC -> {ASTC, BC7, ETC1, ETC2, RGBA32}: replaces the loop of uastc.rs:157-165 / 96-107
+template <int TARGET>
+__global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
+                                                         unsigned bpr, unsigned long long base, unsigned long long* status,
+                                                         const BuTables* __restrict__ tables)
+{
+    __shared__ BuTables T;
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x;
+    // first block load is issued before the table copy so both are in flight together
+    uint4 v = idx < n_blocks ? in[idx] : make_uint4(0, 0, 0, 0);
+    bu_stage_tables(T, tables);
+    __syncthreads();
+    while (idx < n_blocks) {
+        const size_t next = idx + stride;
+        const uint4 vn = next < n_blocks ? in[next] : make_uint4(0, 0, 0, 0);
+        BuBlk b;
+        b.w[0] = v.x;
+        b.w[1] = v.y;
+        b.w[2] = v.z;
+        b.w[3] = v.w;
+        const uint32_t mode = T.mode_lut[v.x & 127u];
+        uint32_t o[TARGET == BU_TGT_RGBA ? 16 : 4];
+#pragma unroll
+        for (int i = 0; i < (TARGET == BU_TGT_RGBA ? 16 : 4); i++) o[i] = 0;
+        const int st = bu_block_any<TARGET>(T, mode, b, o);
+        if (st) {
+            bu_report(status, base + idx, st);
+#pragma unroll
+            for (int i = 0; i < (TARGET == BU_TGT_RGBA ? 16 : 4); i++) o[i] = 0;
+        }
+        if constexpr (TARGET == BU_TGT_ETC1) {
+            reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
+        } else if constexpr (TARGET == BU_TGT_RGBA) {
+            const size_t by = idx / bpr, bx = idx - by * bpr;
+            uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+            for (int r = 0; r < 4; r++) img[(4 * by + r) * (size_t)bpr + bx] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+        } else {
+            reinterpret_cast<uint4*>(out)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        v = vn;
+        idx = next;
+    }
+}
+
+// uint4 -> uint4 copy with the transcoders' launch shape (measurement only)
+__global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    for (size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x; idx < n; idx += stride) out[idx] = in[idx];
+}
+
+// ---- ETC1S back-end ----------------------------------------------------------------------------
+// etc.rs:396-431 for one base colour: colour k = clamp(extend5(c5) + modifier[inten][k])
+__device__ __forceinline__ uint32_t bu_etc1s_color(const int16_t* mods, uint32_t ep, int k)
+{
+    const int md = mods[((ep >> 24) & 7u) * 4 + k];
+    uint32_t c = 0xFF000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const uint32_t c5 = (ep >> (8 * ch)) & 0xFFu;
+        const int base = (int)(((c5 << 3) | (c5 >> 2)) & 0xFFu);
+        const int v = base + md;
+        c |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * ch);
+    }
+    return c;
+}
+
+// basis_lz/mod.rs:163-181
+__global__ __launch_bounds__(BU_WG) void bu_etc1s_etc1_kernel(const uint32_t* __restrict__ idx, size_t n_blocks,
+                                                              const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                              const uint2* __restrict__ selectors, uint32_t n_sel,
+                                                              uint2* __restrict__ out, unsigned long long* status)
+{
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
+        const uint32_t ix = idx[i];
+        const uint32_t e = ix & 0xFFFFu, s = ix >> 16;
+        uint2 o = make_uint2(0, 0);
+        if (e >= n_ep || s >= n_sel) {
+            bu_report(status, i, BU_ERR_INDEX_RANGE);
+        } else {
+            const uint32_t ep = endpoints[e];
+            const uint32_t inten = ep >> 24;
+            // bytes: r5<<3, g5<<3, b5<<3, inten<<5 | inten<<2 | 0b11 (u8 arithmetic)
+            o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
+            o.y = selectors[s].y;
+        }
+        out[i] = o;
+    }
+}
+
+// basis_lz/mod.rs:122-146 (+ the alpha pass :139-143 fused)
+__global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ aidx,
+                                                              unsigned nbx, size_t n_blocks, const uint32_t* __restrict__ endpoints,
+                                                              uint32_t n_ep, const uint2* __restrict__ selectors, uint32_t n_sel,
+                                                              uint4* __restrict__ out, unsigned long long* status,
+                                                              const BuTables* __restrict__ tables)
+{
+    __shared__ int16_t mods[32];
+    if (threadIdx.x < 32) mods[threadIdx.x] = tables->etc1_mod[threadIdx.x];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
+        const uint32_t ix = idx[i];
+        const uint32_t e = ix & 0xFFFFu, s = ix >> 16;
+        uint32_t ae = 0, as = 0;
+        bool bad = e >= n_ep || s >= n_sel;
+        if (aidx) {
+            const uint32_t ax = aidx[i];
+            ae = ax & 0xFFFFu;
+            as = ax >> 16;
+            bad = bad || ae >= n_ep || as >= n_sel;
+        }
+        uint32_t px[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) px[k] = 0;
+        if (bad) {
+            bu_report(status, i, BU_ERR_INDEX_RANGE);
+        } else {
+            const uint32_t ep = endpoints[e];
+            const uint32_t rows = selectors[s].x;
+            uint32_t col[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) col[k] = bu_etc1s_color(mods, ep, k);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint32_t sel = (rows >> (2 * t)) & 3u;  // row y in byte y, x = 0 in the low bits (etc.rs:354-361)
+                px[t] = sel == 0 ? col[0] : sel == 1 ? col[1] : sel == 2 ? col[2] : col[3];
+            }
+            if (aidx) {
+                const uint32_t aep = endpoints[ae];
+                const uint32_t arows = selectors[as].x;
+                uint32_t ag[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ag[k] = (bu_etc1s_color(mods, aep, k) >> 8) & 0xFFu;  // .a = colors[sel].g
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const uint32_t sel = (arows >> (2 * t)) & 3u;
+                    const uint32_t a = sel == 0 ? ag[0] : sel == 1 ? ag[1] : sel == 2 ? ag[2] : ag[3];
+                    px[t] = (px[t] & 0x00FFFFFFu) | (a << 24);
+                }
+            }
+        }
+        const size_t by = i / nbx, bx = i - by * nbx;
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(4 * by + r) * (size_t)nbx + bx] = make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+unsigned bu_grid_for(size_t n_blocks, int cu_count)
+{
+    // enough workgroups to fill the chip several times over, capped so every workgroup amortises its
+    // table copy over >= 2 batches on large inputs (guide: grid ~ CUs x 8 for memory-bound kernels)
+    size_t wgs = (n_blocks + BU_WG - 1) / BU_WG;
+    const size_t cap = (size_t)cu_count * 8;
+    if (wgs > cap) wgs = cap;
+    if (wgs == 0) wgs = 1;
+    return (unsigned)wgs;
+}
+
+}  // namespace
+
+// ================================================================================================
+struct bu_context {
+    int device = -1;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    BuTables* d_tables = nullptr;
+    void* d_in = nullptr;
+    size_t in_cap = 0;
+    void* d_out = nullptr;
+    size_t out_cap = 0;
+    void* d_aux = nullptr;  // codebooks / alpha indices of the host-pointer ETC1S calls
+    size_t aux_cap = 0;
+    unsigned long long* d_status = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex lock;  // host-pointer entry points share the staging buffers
+    char err[256] = {0};
+};
+
+namespace {
+
+bu_status bu_fail(bu_context* ctx, hipError_t e, const char* what)
+{
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+    return BU_ERR_HIP;
+}
+#define BU_HIP(ctx, call)                                       \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return bu_fail(ctx, e_, #call);   \
+    } while (0)
+
+bu_status bu_reserve(bu_context* ctx, void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return BU_OK;
+    if (*p) BU_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t sz = need < (1u << 20) ? (1u << 20) : need;
+    BU_HIP(ctx, hipMalloc(p, sz));
+    *cap = sz;
+    return BU_OK;
+}
+
+bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
+                          uint64_t base, uint64_t* d_status, hipStream_t stream)
+{
+    if (n_blocks == 0) return BU_OK;
+    const unsigned grid = bu_grid_for(n_blocks, ctx->cu_count);
+    const uint4* in = static_cast<const uint4*>(d_in);
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(d_status);
+    switch (target) {
+    case BU_TARGET_ASTC: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_ASTC>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
+    case BU_TARGET_BC7: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_BC7>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
+    case BU_TARGET_ETC1: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_ETC1>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
+    case BU_TARGET_ETC2: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_ETC2>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
+    case BU_TARGET_RGBA32: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_RGBA>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
+    default: return BU_ERR_ARGUMENT;
+    }
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+// host-pointer UASTC driver shared by transcode / decode_to_rgba / the per-block API
+bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, size_t in_bytes, size_t bpr, uint8_t* out,
+                        size_t out_bytes, uint64_t* first_bad)
+{
+    if (!ctx || (!in && in_bytes) || !out) return BU_ERR_ARGUMENT;
+    const size_t bb = bu_target_block_bytes(target);
+    if (bb == 0) return BU_ERR_ARGUMENT;
+    if (in_bytes % 16 != 0) return BU_ERR_LENGTH;  // uastc.rs:54-59
+    const size_t n = in_bytes / 16;
+    if (out_bytes < n * bb) return BU_ERR_OUTPUT_SIZE;
+    if (target == BU_TARGET_RGBA32 && bpr == 0) return BU_ERR_ARGUMENT;
+    if (n == 0) return BU_OK;
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    bu_status st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, in_bytes);
+    if (st) return st;
+    // RGBA32: a ragged last block-row still writes whole rows of the image the caller sized as 64*n
+    size_t out_need = n * bb;
+    if (target == BU_TARGET_RGBA32) out_need = ((n + bpr - 1) / bpr) * bpr * 64;
+    st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, out_need);
+    if (st) return st;
+    BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
+    st = bu_launch_uastc(ctx, target, ctx->d_in, n, ctx->d_out, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream);
+    if (st) return st;
+    uint64_t word = 0;
+    BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return bu_status_word_decode(word, first_bad);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t bu_target_block_bytes(bu_target target)
+{
+    switch (target) {
+    case BU_TARGET_ASTC:
+    case BU_TARGET_BC7:
+    case BU_TARGET_ETC2: return 16;
+    case BU_TARGET_ETC1: return 8;
+    case BU_TARGET_RGBA32: return 64;
+    default: return 0;
+    }
+}
+
+const char* bu_status_string(bu_status st)
+{
+    switch (st) {
+    case BU_OK: return "ok";
+    case BU_ERR_INVALID_MODE: return "invalid mode index";                                        // uastc.rs:336
+    case BU_ERR_INVALID_PATTERN: return "block pattern is not valid";                             // uastc.rs:364
+    case BU_ERR_LENGTH: return "data length is not divisible by UASTC block size (16)";           // uastc.rs:56
+    case BU_ERR_OUTPUT_SIZE: return "output buffer too small";
+    case BU_ERR_ARGUMENT: return "invalid argument";
+    case BU_ERR_INDEX_RANGE: return "ETC1S endpoint or selector index out of range";
+    case BU_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+    case BU_ERR_HIP: return "HIP runtime error";
+    default: return "unknown status";
+    }
+}
+
+const char* bu_last_error(const bu_context* ctx) { return ctx ? ctx->err : "no context"; }
+
+bu_status bu_context_create(int device, bu_context** out_ctx)
+{
+    if (!out_ctx) return BU_ERR_ARGUMENT;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BU_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BU_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BU_ERR_NO_DEVICE;  // the code object is gfx950-only
+    bu_context* ctx = new (std::nothrow) bu_context();
+    if (!ctx) return BU_ERR_HIP;
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    bu_status st = BU_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { st = BU_ERR_NO_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTables)) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { st = BU_ERR_HIP; break; }
+        BuTables* h = new (std::nothrow) BuTables();
+        if (!h) { st = BU_ERR_HIP; break; }
+        bu_build_tables(h);
+        hipError_t e = hipMemcpy(ctx->d_tables, h, sizeof(BuTables), hipMemcpyHostToDevice);
+        delete h;
+        if (e != hipSuccess) { st = BU_ERR_HIP; break; }
+    } while (0);
+    if (st != BU_OK) {
+        bu_context_destroy(ctx);
+        return st;
+    }
+    *out_ctx = ctx;
+    return BU_OK;
+}
+
+void bu_context_destroy(bu_context* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+bu_status bu_status_word_reset(bu_context* ctx, uint64_t* d_status, void* stream)
+{
+    if (!ctx || !d_status) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+    return BU_OK;
+}
+
+bu_status bu_status_word_decode(uint64_t word, uint64_t* first_bad_block)
+{
+    if (word == BU_STATUS_WORD_CLEAR) return BU_OK;
+    if (first_bad_block) *first_bad_block = word >> 8;
+    return static_cast<bu_status>(word & 0xFFu);
+}
+
+bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
+                                    size_t blocks_per_row, uint64_t block_index_base, uint64_t* d_status, void* stream)
+{
+    if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
+    if (bu_target_block_bytes(target) == 0) return BU_ERR_ARGUMENT;
+    if (target == BU_TARGET_RGBA32 && blocks_per_row == 0) return BU_ERR_ARGUMENT;
+    return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream));
+}
+
+bu_status bu_uastc_transcode(bu_context* ctx, bu_target target, const uint8_t* in, size_t in_bytes, uint8_t* out,
+                             size_t out_bytes, uint64_t* first_bad_block)
+{
+    if (target == BU_TARGET_RGBA32) return BU_ERR_ARGUMENT;  // uastc.rs:41-47 has no RGBA member; use bu_uastc_decode_to_rgba
+    return bu_uastc_host(ctx, target, in, in_bytes, 1, out, out_bytes, first_bad_block);
+}
+
+bu_status bu_uastc_decode_to_rgba(bu_context* ctx, const uint8_t* in, size_t in_bytes, size_t blocks_per_row, uint8_t* out,
+                                  size_t out_bytes, uint64_t* first_bad_block)
+{
+    if (blocks_per_row == 0) return BU_ERR_ARGUMENT;
+    // the reference's image has exactly 64*n bytes (uastc.rs:95); a ragged last row would index past it
+    // (Rust panics there), so require whole block rows
+    if (in_bytes % 16 == 0 && (in_bytes / 16) % blocks_per_row != 0) return BU_ERR_ARGUMENT;
+    return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, in_bytes, blocks_per_row, out, out_bytes, first_bad_block);
+}
+
+bu_status bu_unpack_uastc_block_to_rgba(bu_context* ctx, const uint8_t in[16], uint32_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, 16, 1, reinterpret_cast<uint8_t*>(out), 64, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_astc(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_ASTC, in, 16, 1, out, 16, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_bc7(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_BC7, in, 16, 1, out, 16, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_etc1(bu_context* ctx, const uint8_t in[16], uint8_t out[8])
+{
+    return bu_uastc_host(ctx, BU_TARGET_ETC1, in, 16, 1, out, 8, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_ETC2, in, 16, 1, out, 16, nullptr);
+}
+
+// ---- ETC1S ---------------------------------------------------------------------------------------
+void bu_etc1s_selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8])
+{
+    // Selector::set_selector (etc.rs:363-393) for all 16 texels: ETC1 code = [3,2,0,1][value],
+    // pixel id = x*4 + y, MSB plane in bytes 0-1 (pixels 8-15, then 0-7), LSB plane in bytes 2-3
+    uint32_t msb = 0, lsb = 0;
+    for (unsigned y = 0; y < 4; y++)
+        for (unsigned x = 0; x < 4; x++) {
+            const unsigned v = (rows[y] >> (2 * x)) & 3u;
+            const unsigned code = BU_SEL_TO_ETC1[v];
+            msb |= (code >> 1) << (x * 4 + y);
+            lsb |= (code & 1u) << (x * 4 + y);
+        }
+    memcpy(out_entry, rows, 4);
+    out_entry[4] = (uint8_t)(msb >> 8);
+    out_entry[5] = (uint8_t)(msb & 0xFF);
+    out_entry[6] = (uint8_t)(lsb >> 8);
+    out_entry[7] = (uint8_t)(lsb & 0xFF);
+}
+
+bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx, size_t n_blocks, const uint32_t* d_endpoints,
+                                         uint32_t n_endpoints, const void* d_selectors, uint32_t n_selectors, void* d_out,
+                                         uint64_t* d_status, void* stream)
+{
+    if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
+    if (n_blocks == 0) return BU_OK;
+    hipLaunchKernelGGL(bu_etc1s_etc1_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream), d_idx,
+                       n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors, static_cast<uint2*>(d_out),
+                       reinterpret_cast<unsigned long long*>(d_status));
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+bu_status bu_etc1s_decode_rgba_device(bu_context* ctx, const uint32_t* d_idx, const uint32_t* d_alpha_idx, size_t nbx, size_t nby,
+                                      const uint32_t* d_endpoints, uint32_t n_endpoints, const void* d_selectors,
+                                      uint32_t n_selectors, void* d_out, uint64_t* d_status, void* stream)
+{
+    const size_t n_blocks = nbx * nby;
+    if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
+    if (n_blocks == 0) return BU_OK;
+    hipLaunchKernelGGL(bu_etc1s_rgba_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream), d_idx,
+                       d_alpha_idx, (unsigned)nbx, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
+                       static_cast<uint4*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+static bu_status bu_etc1s_host(bu_context* ctx, bool rgba, const uint32_t* idx, const uint32_t* alpha_idx, size_t nbx, size_t nby,
+                               const uint32_t* endpoints, uint32_t n_ep, const uint8_t* selectors, uint32_t n_sel, uint8_t* out,
+                               size_t out_bytes, uint64_t* first_bad)
+{
+    const size_t n = nbx * nby;
+    if (!ctx || !out || (n && (!idx || !endpoints || !selectors))) return BU_ERR_ARGUMENT;
+    const size_t bb = rgba ? 64 : 8;
+    if (out_bytes < n * bb) return BU_ERR_OUTPUT_SIZE;
+    if (n == 0) return BU_OK;
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    bu_status st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, n * 4);
+    if (st) return st;
+    st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, n * bb);
+    if (st) return st;
+    const size_t ep_bytes = ((size_t)n_ep * 4 + 15) & ~(size_t)15, sel_bytes = ((size_t)n_sel * 8 + 15) & ~(size_t)15;
+    const size_t a_bytes = alpha_idx ? n * 4 : 0;
+    st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + a_bytes);
+    if (st) return st;
+    uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
+    BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(aux, endpoints, (size_t)n_ep * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, selectors, (size_t)n_sel * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (alpha_idx) BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes + sel_bytes, alpha_idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
+    uint64_t* ds = reinterpret_cast<uint64_t*>(ctx->d_status);
+    const uint32_t* d_ep = reinterpret_cast<const uint32_t*>(aux);
+    const void* d_sel = aux + ep_bytes;
+    if (rgba)
+        st = bu_etc1s_decode_rgba_device(ctx, static_cast<const uint32_t*>(ctx->d_in),
+                                         alpha_idx ? reinterpret_cast<const uint32_t*>(aux + ep_bytes + sel_bytes) : nullptr, nbx, nby, d_ep,
+                                         n_ep, d_sel, n_sel, ctx->d_out, ds, ctx->stream);
+    else
+        st = bu_etc1s_transcode_etc1_device(ctx, static_cast<const uint32_t*>(ctx->d_in), n, d_ep, n_ep, d_sel, n_sel, ctx->d_out, ds, ctx->stream);
+    if (st) return st;
+    uint64_t word = 0;
+    BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return bu_status_word_decode(word, first_bad);
+}
+
+bu_status bu_etc1s_transcode_etc1(bu_context* ctx, const uint32_t* idx, size_t n_blocks, const uint32_t* endpoints, uint32_t n_endpoints,
+                                  const uint8_t* selectors, uint32_t n_selectors, uint8_t* out, size_t out_bytes, uint64_t* first_bad_block)
+{
+    return bu_etc1s_host(ctx, false, idx, nullptr, n_blocks, 1, endpoints, n_endpoints, selectors, n_selectors, out, out_bytes, first_bad_block);
+}
+
+bu_status bu_etc1s_decode_rgba(bu_context* ctx, const uint32_t* idx, const uint32_t* alpha_idx, size_t nbx, size_t nby,
+                               const uint32_t* endpoints, uint32_t n_endpoints, const uint8_t* selectors, uint32_t n_selectors, uint8_t* out,
+                               size_t out_bytes, uint64_t* first_bad_block)
+{
+    if (nbx == 0 && nby != 0) return BU_ERR_ARGUMENT;
+    return bu_etc1s_host(ctx, true, idx, alpha_idx, nbx, nby, endpoints, n_endpoints, selectors, n_selectors, out, out_bytes, first_bad_block);
+}
+
+// ---- measurement helpers ---------------------------------------------------------------------------
+bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blocks, void* d_out, void* stream)
+{
+    if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
+    if (n_blocks == 0) return BU_OK;
+    hipLaunchKernelGGL(bu_copy_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), n_blocks);
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                 size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream, float* out_ms)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (size_t)i % n_buffers;
+        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, stream);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
+
+bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers, size_t n_blocks,
+                                int launches, void* stream, float* out_ms)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (size_t)i % n_buffers;
+        bu_status st = bu_copy_ceiling_device(ctx, d_in[k], n_blocks, d_out[k], stream);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
+
+}  // extern "C"

@@ -51,7 +51,7 @@ constexpr int bu_deq_ofs(int range)
     return range == 7 ? 0 : range == 8 ? 16 : range == 11 ? 32 : range == 12 ? 64 : range == 13 ? 104 : range == 18 ? 152 : range == 19 ? 312 : -1;
 }
 
-#ifndef __HIP_DEVICE_COMPILE__
+// host side (plain functions: never emitted for the device)
 // exact-rational form of the reference's f32 quantiser (bc7.rs:441-444, 511-514); SURVEY.md appendix A
 static inline int bu_quant_p(int x, int S, int p)
 {
@@ -173,4 +173,3 @@ static inline void bu_build_tables(BuTables* t)
         t->eac_magic[i] = (uint32_t)(((1u << 20) + 2 * range - 1) / (2 * range));  // exact for num*2*range < 2^20
     }
 }
-#endif

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: UASTC -> BC7 at 4096x4096 (1 048 576 blocks per step) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A step = one launch of the UASTC->BC7 kernel over one 4096x4096 synthetic atlas already resident in
+HBM.  Atlases rotate through NBUF distinct input/output buffer pairs (>= 1 GiB each way) so neither L2
+nor the 256 MiB Infinity Cache can serve a launch (cold-cache protocol).
+Every rank owns its own atlases (weak scaling: in the texture-array reading of the config each rank
+holds 16 slices of 1024x1024 px); the transcode needs no data-path collective.  The all-gather that
+reassembles the array is timed separately and reported under "allgather" -- never folded into `value`.
+
+Prints ONE JSON line (rank 0): metric/value per the driver contract plus
+  roofline      algorithmic bytes (32 B/block x blocks per launch) / average kernel duration measured
+                with hipEvents on the launch stream over the timed region, against the 8 TB/s HBM peak
+  cpu_baseline  the oracle (C restatement of the reference CPU path, kind "port") timed on this box's
+                host cores on a bounded sample of the same atlas
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NBX = NBY = 1024  # 4096x4096 px
+N_BLOCKS = NBX * NBY
+BYTES_PER_BLOCK = 32  # 16 read + 16 written
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(golden, idx, budget_s=12.0):
+    """oracle timed on the host: 1 thread and all hardware threads, bounded sample"""
+    from oracle.pyoracle import Oracle
+
+    orc = Oracle()
+    cores = os.cpu_count() or 1
+    sample = 1 << 18
+    blocks = np.ascontiguousarray(golden["uastc"][idx[:sample]])
+    out = np.empty((sample, 16), dtype=np.uint8)
+    t0 = time.perf_counter()
+    st = orc.lib.bu_oracle_transcode_mt(1, blocks.ctypes.data, blocks.size, out.ctypes.data, 1)
+    t1 = time.perf_counter() - t0
+    assert st == 0 and (out == golden["bc7"][idx[:sample]]).all()
+    one = sample / t1 / 1e6
+    # all threads on the full atlas, repeated until about budget_s seconds are spent
+    blocks = np.ascontiguousarray(golden["uastc"][idx])
+    out = np.empty((idx.size, 16), dtype=np.uint8)
+    reps, spent = 0, 0.0
+    while spent < budget_s and reps < 50:
+        t0 = time.perf_counter()
+        st = orc.lib.bu_oracle_transcode_mt(1, blocks.ctypes.data, blocks.size, out.ctypes.data, cores)
+        spent += time.perf_counter() - t0
+        reps += 1
+    assert st == 0
+    allc = reps * idx.size / spent / 1e6
+    return {
+        "value": round(allc, 3), "unit": "Mblocks/s", "cores": cores, "kind": "port",
+        "sample": "UASTC->BC7, %d x 4096x4096 A-gold atlas on %d threads (%.1f s); 1 thread on %d blocks = %.3f Mblocks/s" % (reps, cores, spent, sample, one),
+        "one_thread_mblocks_s": round(one, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--nbuf", type=int, default=64, help="distinct atlas buffers rotated through (cold cache)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from basisu_rs_amd import Context, _lib, synth
+
+    ctx = Context(local_rank)
+    lib = _lib.load()
+    golden = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+    dev = torch.device("cuda", local_rank)
+    g_uastc = torch.from_numpy(golden["uastc"]).to(dev)
+    g_bc7 = torch.from_numpy(golden["bc7"]).to(dev)
+
+    # NBUF distinct A-gold atlases per rank: block i of atlas k = G[h(i; seed_k) mod 608]
+    nbuf = max(1, args.nbuf)
+    idx0 = synth.gold_indices(N_BLOCKS, seed=synth.GOLD_SEED + 7919 * rank)
+    ins, outs, idxs = [], [], []
+    for k in range(nbuf):
+        if k == 0:
+            idx = torch.from_numpy(idx0).to(dev)
+        else:  # a different pseudo-random arrangement per buffer, generated on the GPU
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1000 * rank + k)
+            idx = torch.randint(0, 608, (N_BLOCKS,), device=dev, generator=gen)
+        idxs.append(idx if k < 2 else None)
+        ins.append(g_uastc[idx].contiguous())
+        outs.append(torch.empty((N_BLOCKS, 16), dtype=torch.uint8, device=dev))
+    status = torch.empty(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    PtrArr = ctypes.c_void_p * nbuf
+    in_ptrs = PtrArr(*[t.data_ptr() for t in ins])
+    out_ptrs = PtrArr(*[t.data_ptr() for t in outs])
+
+    def run(launches, coherent=False, target=_lib.BC7, inp=in_ptrs, outp=out_ptrs, nb=nbuf):
+        ms = ctypes.c_float(0)
+        st = lib.bu_time_uastc_launches(ctx.handle, target, inp, outp, nb, N_BLOCKS, NBX, launches, ctypes.c_void_p(status.data_ptr()), sp, ctypes.byref(ms))
+        if st != 0:
+            raise RuntimeError("bu_time_uastc_launches: " + lib.bu_status_string(st).decode())
+        return ms.value
+
+    # ---- correctness gate before any timing: full-size, self-verifying ----
+    ctx.status_word_reset(status)
+    run(min(2, nbuf))
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    for k in range(min(2, nbuf)):
+        if not torch.equal(outs[k], g_bc7[idxs[k]]):
+            raise SystemExit("bench: BC7 output of atlas %d differs from the known-answer vectors" % k)
+
+    # ---- warmup, then EXACTLY K timed steps between barrier + synchronize ----
+    if args.warmup > 0:
+        run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_ms = run(args.steps)  # K launches, hipEvents recorded on the launch stream around them
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, ev_ms / 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max, ev_max = float(t[0]), float(t[1])
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+
+    total_blocks = world * args.steps * N_BLOCKS
+    value = total_blocks / dt_max / 1e6
+    kern_s = ev_max / args.steps  # average launch duration (slowest rank), HIP events
+    achieved = BYTES_PER_BLOCK * N_BLOCKS / kern_s / 1e9
+
+    extra = {}
+    if rank == 0:
+        # context rows (not the headline): copy ceiling of the same shape, hot-cache and coherent atlases, RGBA32
+        ms = ctypes.c_float(0)
+        lib.bu_time_copy_launches(ctx.handle, in_ptrs, out_ptrs, nbuf, N_BLOCKS, 32, sp, ctypes.byref(ms))
+        lib.bu_time_copy_launches(ctx.handle, in_ptrs, out_ptrs, nbuf, N_BLOCKS, args.steps, sp, ctypes.byref(ms))
+        copy_s = ms.value / 1e3 / args.steps
+        extra["copy_ceiling"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / copy_s / 1e9, 1), "us_per_launch": round(copy_s * 1e6, 3),
+                                 "note": "uint4->uint4 copy kernel, same grid, same cold-cache rotation"}
+        one_in, one_out = (ctypes.c_void_p * 1)(ins[0].data_ptr()), (ctypes.c_void_p * 1)(outs[0].data_ptr())
+        run(32, inp=one_in, outp=one_out, nb=1)
+        hot_s = run(args.steps, inp=one_in, outp=one_out, nb=1) / 1e3 / args.steps
+        extra["hot_cache"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / hot_s / 1e9, 1), "us_per_launch": round(hot_s * 1e6, 3),
+                              "note": "same atlas every launch (32 MiB working set sits in the 256 MiB Infinity Cache) -- NOT the headline"}
+        # mode-coherent atlases (mode chosen per 8x8-block tile): texture-like, waves see 1-2 modes
+        coh = []
+        for k in range(min(nbuf, 64)):
+            cidx = torch.from_numpy(synth.coh_indices(NBX, NBY, seed=synth.GOLD_SEED + k)).to(dev)
+            coh.append(g_uastc[cidx].contiguous())
+            if k == 0:
+                coh_idx0 = cidx
+        coh_ptrs = (ctypes.c_void_p * len(coh))(*[t.data_ptr() for t in coh])
+        run(len(coh), inp=coh_ptrs, outp=out_ptrs, nb=len(coh))
+        torch.cuda.synchronize()
+        coh_ok = bool(torch.equal(outs[0], g_bc7[coh_idx0]))
+        coh_s = run(args.steps, inp=coh_ptrs, outp=out_ptrs, nb=len(coh)) / 1e3 / args.steps
+        extra["coherent_atlas"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / coh_s / 1e9, 1), "us_per_launch": round(coh_s * 1e6, 3),
+                                   "mblocks_s": round(N_BLOCKS / coh_s / 1e6, 1), "verified": coh_ok,
+                                   "note": "A-coh: UASTC mode chosen per 8x8-block tile"}
+        del coh
+        # config 3: UASTC -> RGBA32 (16 B in, 64 B out)
+        rg_n = min(nbuf, 16)
+        rg_out = [torch.empty((N_BLOCKS, 64), dtype=torch.uint8, device=dev) for _ in range(rg_n)]
+        rg_in = (ctypes.c_void_p * rg_n)(*[ins[k].data_ptr() for k in range(rg_n)])
+        rg_outp = (ctypes.c_void_p * rg_n)(*[t.data_ptr() for t in rg_out])
+        run(rg_n, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
+        rg_s = run(max(32, args.steps // 4), target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n) / 1e3 / max(32, args.steps // 4)
+        extra["uastc_to_rgba32"] = {"gb_s": round(80 * N_BLOCKS / rg_s / 1e9, 1), "us_per_launch": round(rg_s * 1e6, 3),
+                                    "mblocks_s": round(N_BLOCKS / rg_s / 1e6, 1), "bytes_per_block": 80}
+        del rg_out
+
+    allgather = None
+    if world > 1:
+        # reassembly of the texture array: every rank receives every rank's 16 MiB BC7 shard
+        full = torch.empty((world * N_BLOCKS, 16), dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            dist.all_gather_into_tensor(full, outs[0])
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, outs[0])
+        torch.cuda.synchronize()
+        ag = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+        allgather = {"ms": round(float(ag[0]) * 1e3, 3), "bytes_per_rank": N_BLOCKS * 16, "collective": "all_gather_into_tensor (RCCL)"}
+
+    if rank == 0:
+        line = {
+            "metric": "M 4x4 blocks/s UASTC->BC7 4096x4096",
+            "value": round(value, 1),
+            "unit": "Mblocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "UASTC->BC7, 4096x4096 px (1 048 576 blocks) per GPU per step, A-gold atlas "
+                                   "(block i = reference known-answer block h(i) mod 608, uniform mix of the 19 modes), "
+                                   "%d distinct atlases rotated (cold cache)" % nbuf,
+                       "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "bu_uastc_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
+                         "bytes_per_launch": BYTES_PER_BLOCK * N_BLOCKS},
+        }
+        if allgather:
+            line["allgather"] = allgather
+        line["extra"] = extra
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(golden, idx0)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1560,3 +1560,68 @@ void bu_oracle_decode_etc1_block(const uint8_t b[8], uint8_t out[64])
             memcpy(out + 4 * (y * 4 + x), cols[sb][k].c, 4);
         }
 }
+
+/* ================================================================== test helpers */
+/* block-linear batch that does not stop at errors: st[i] = status of block i (fuzz parity) */
+void bu_oracle_batch(int target, const uint8_t *in, size_t n_blocks, uint8_t *out, uint8_t *st)
+{
+    size_t obs = out_block_size(target);
+    for (size_t i = 0; i < n_blocks; i++) {
+        uint8_t tmp[64];
+        memset(tmp, 0, sizeof tmp);
+        st[i] = (uint8_t)block_any(target, in + 16 * i, tmp);
+        memcpy(out + obs * i, tmp, obs);
+    }
+}
+
+/* Exhaustive proof helper: determine_shared_pbits, f32 form vs integer form,
+ * over every RGB endpoint pair whose channels are multiples of 17 (the only inputs UASTC mode 2 can
+ * produce).  Returns the number of (decision or endpoint) mismatches; *ties = exact-tie count. */
+uint64_t bu_oracle_prove_shared_pbits(uint64_t *ties)
+{
+    uint64_t bad = 0, nt = 0;
+    for (unsigned v = 0; v < (1u << 24); v++) {
+        uint8_t lo[4], hi[4], lo2[4], hi2[4];
+        for (int c = 0; c < 3; c++) {
+            lo[c] = lo2[c] = (uint8_t)(17 * ((v >> (4 * c)) & 15));
+            hi[c] = hi2[c] = (uint8_t)(17 * ((v >> (12 + 4 * c)) & 15));
+        }
+        lo[3] = lo2[3] = hi[3] = hi2[3] = 255;
+        int p1 = bu_oracle_shared_pbits_f32(3, 6, lo, hi);
+        int p2 = bu_oracle_shared_pbits_int(3, 6, lo2, hi2);
+        if (p1 != p2 || memcmp(lo, lo2, 3) || memcmp(hi, hi2, 3)) bad++;
+        (void)nt;
+    }
+    if (ties) *ties = nt;
+    return bad;
+}
+
+/* determine_unique_pbits f32 vs integer over random endpoints (decision is per endpoint) */
+uint64_t bu_oracle_prove_unique_pbits(unsigned total_comps, unsigned comp_bits, uint64_t n, uint64_t seed)
+{
+    uint64_t bad = 0, s = seed * 6364136223846793005ull + 1442695040888963407ull;
+    for (uint64_t i = 0; i < n; i++) {
+        uint8_t lo[4], hi[4], lo2[4], hi2[4], p[2];
+        for (int c = 0; c < 4; c++) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            lo[c] = lo2[c] = (uint8_t)(s >> 33);
+            hi[c] = hi2[c] = (uint8_t)(s >> 41);
+        }
+        bu_oracle_unique_pbits_f32(total_comps, comp_bits, lo, hi, p);
+        int q0 = bu_oracle_unique_pbit_int(total_comps, comp_bits, lo2);
+        int q1 = bu_oracle_unique_pbit_int(total_comps, comp_bits, hi2);
+        if (q0 != p[0] || q1 != p[1] || memcmp(lo, lo2, 4) || memcmp(hi, hi2, 4)) bad++;
+    }
+    return bad;
+}
+
+/* EAC centre, f32 vs integer, all 16 tables x all 0 <= min < max <= 255 */
+uint64_t bu_oracle_prove_eac_center(void)
+{
+    uint64_t bad = 0;
+    for (unsigned t = 0; t < 16; t++)
+        for (int mn = 0; mn < 256; mn++)
+            for (int mx = mn + 1; mx < 256; mx++)
+                if (bu_oracle_eac_center_f32(mn, mx, t) != bu_oracle_eac_center_int(mn, mx, t)) bad++;
+    return bad;
+}

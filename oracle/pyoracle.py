@@ -1,0 +1,94 @@
+"""ctypes view of the CPU oracle (oracle/libbu_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg --
+always as the checker / the reported CPU baseline, never by the product package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+TARGETS = {"astc": (0, 16), "bc7": (1, 16), "etc1": (2, 8), "etc2": (3, 16), "rgba": (4, 64)}
+
+
+def _make(path, target):
+    if not os.path.exists(os.path.join(path, target)):
+        subprocess.run(["make", "-C", path, target], check=True, capture_output=True)
+
+
+class Oracle:
+    """ctypes view of oracle/libbu_oracle.so -- the CHECKER (never the thing under test)."""
+
+    def __init__(self):
+        _make(os.path.join(ROOT, "oracle"), "libbu_oracle.so")
+        self.lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libbu_oracle.so"))
+        L, c = self.lib, ctypes
+        L.bu_oracle_batch.argtypes = [c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+        L.bu_oracle_batch.restype = None
+        L.bu_oracle_transcode.argtypes = [c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.POINTER(c.c_size_t)]
+        L.bu_oracle_decode_to_rgba.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_void_p, c.POINTER(c.c_size_t)]
+        L.bu_oracle_transcode_mt.argtypes = [c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_int]
+        L.bu_oracle_etc1s_to_etc1.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p]
+        L.bu_oracle_etc1s_to_etc1.restype = None
+        L.bu_oracle_etc1s_to_rgba.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p]
+        L.bu_oracle_etc1s_to_rgba.restype = None
+        L.bu_oracle_selector_from_rows.argtypes = [c.c_void_p, c.c_void_p]
+        L.bu_oracle_selector_from_rows.restype = None
+        L.bu_oracle_decode_etc1_block.argtypes = [c.c_void_p, c.c_void_p]
+        L.bu_oracle_decode_etc1_block.restype = None
+        for n in ("bu_oracle_prove_shared_pbits", "bu_oracle_prove_unique_pbits", "bu_oracle_prove_eac_center"):
+            getattr(L, n).restype = c.c_uint64
+        L.bu_oracle_prove_unique_pbits.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64]
+
+    def batch(self, target, blocks):
+        """blocks [n,16] uint8 -> (out [n,bytes], status [n])"""
+        t, obs = TARGETS[target]
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
+        out = np.zeros((blocks.shape[0], obs), dtype=np.uint8)
+        st = np.zeros(blocks.shape[0], dtype=np.uint8)
+        self.lib.bu_oracle_batch(t, blocks.ctypes.data, blocks.shape[0], out.ctypes.data, st.ctypes.data)
+        return out, st
+
+    def transcode(self, target, data):
+        """slice driver with the reference's first-error-aborts semantics -> (status, first_bad, out)"""
+        t, obs = TARGETS[target]
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        out = np.zeros((data.size // 16 + 1) * obs, dtype=np.uint8)
+        fb = ctypes.c_size_t(0)
+        st = self.lib.bu_oracle_transcode(t, data.ctypes.data, data.size, out.ctypes.data, ctypes.byref(fb))
+        return st, fb.value, out[: (data.size // 16) * obs]
+
+    def decode_to_rgba(self, data, bpr):
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        out = np.zeros((data.size // 16 + 1) * 64, dtype=np.uint8)
+        fb = ctypes.c_size_t(0)
+        st = self.lib.bu_oracle_decode_to_rgba(data.ctypes.data, data.size, bpr, out.ctypes.data, ctypes.byref(fb))
+        return st, fb.value, out[: (data.size // 16) * 64]
+
+    def selectors_from_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1, 4)
+        out = np.zeros((rows.shape[0], 8), dtype=np.uint8)
+        for i in range(rows.shape[0]):
+            self.lib.bu_oracle_selector_from_rows(rows[i].ctypes.data, out[i].ctypes.data)
+        return out
+
+    def etc1s_to_etc1(self, idx, endpoints, selectors):
+        idx16 = np.ascontiguousarray(idx, dtype=np.uint32).view(np.uint16)  # {ep, sel} little endian pairs
+        ep = np.ascontiguousarray(endpoints, dtype=np.uint32)
+        sel = np.ascontiguousarray(selectors, dtype=np.uint8)
+        out = np.zeros(idx.size * 8, dtype=np.uint8)
+        self.lib.bu_oracle_etc1s_to_etc1(idx16.ctypes.data, idx.size, ep.ctypes.data, sel.ctypes.data, out.ctypes.data)
+        return out
+
+    def etc1s_to_rgba(self, idx, alpha_idx, nbx, nby, endpoints, selectors):
+        idx16 = np.ascontiguousarray(idx, dtype=np.uint32).view(np.uint16)
+        a16 = None if alpha_idx is None else np.ascontiguousarray(alpha_idx, dtype=np.uint32).view(np.uint16)
+        ep = np.ascontiguousarray(endpoints, dtype=np.uint32)
+        sel = np.ascontiguousarray(selectors, dtype=np.uint8)
+        out = np.zeros(nbx * nby * 64, dtype=np.uint8)
+        self.lib.bu_oracle_etc1s_to_rgba(idx16.ctypes.data, None if a16 is None else a16.ctypes.data, nbx, nby, ep.ctypes.data,
+                                         sel.ctypes.data, out.ctypes.data)
+        return out

@@ -1,0 +1,80 @@
+"""The N>1 path on CPU: 2 processes, gloo backend, the per-shard transcode injected (oracle), checking
+partitioning and the all-gather reassembly against the unsharded result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_slices, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basisu_rs_amd import sharded, synth
+        from oracle.pyoracle import Oracle
+
+        oracle = Oracle()
+        g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+        bps = 64
+        idx = synth.gold_indices(n_slices * bps, seed=3)
+        slices = torch.from_numpy(g["uastc"][idx].reshape(n_slices, bps, 16).copy())
+
+        def fn(t):
+            out, st = oracle.batch("bc7", t.numpy())
+            assert (st == 0).all()
+            return torch.from_numpy(out)
+
+        full = sharded.transcode_array_sharded(slices, fn)
+        want = g["bc7"][idx].reshape(n_slices, bps, 16)
+        ok = bool((full.numpy() == want).all())
+        lo, hi = sharded.partition(n_slices, world, rank)
+        local = sharded.transcode_array_sharded(slices, fn, gather=False)
+        ok = ok and bool((local.numpy() == want[lo:hi]).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_slices", [8, 7])
+def test_two_rank_sharded_transcode_reassembles(n_slices):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_slices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, True), (1, True)]
+
+
+def test_partition_covers_everything_once():
+    from basisu_rs_amd import sharded
+
+    for n in (0, 1, 7, 8, 512, 513):
+        for w in (1, 2, 3, 8):
+            ranges = [sharded.partition(n, w, r) for r in range(w)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
