@@ -77,7 +77,7 @@ def test_error_strings_and_first_error_semantics(ctx, golden):
     with pytest.raises(BasisuError, match="block pattern is not valid") as ex:
         dec.transcode(TargetTextureFormat.Astc, e)
     assert ex.value.first_bad_block == 77
-    e = synth.atlas_err(golden["uastc"], 4096, [100, 77])
+    e = synth.atlas_err(golden["uastc"], 4096, [77, 100])
     with pytest.raises(BasisuError, match="invalid mode index") as ex:
         dec.decode_to_rgba(e, 64)
     assert ex.value.first_bad_block == 77  # lowest index wins, like the sequential loop
