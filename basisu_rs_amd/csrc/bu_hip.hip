@@ -24,6 +24,7 @@ namespace {
 
 constexpr int BU_WG = 256;            // 4 waves
 constexpr int BU_TABLE_VEC = (int)(sizeof(BuTables) / 16);
+constexpr int BU_SORT_MIN_BLOCKS = 2048;  // below this the plain one-lane-per-block kernel is used
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bu_stage_tables(BuTables& dst, const BuTables* __restrict__ src)
@@ -81,6 +82,142 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
         }
         v = vn;
         idx = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mode-sorted variant for the block-linear targets (ASTC, BC7, ETC1, ETC2).
+//
+// The per-mode code paths are straight-line and short (~130 VALU each for BC7) but there are 19 of
+// them: a wave whose 64 lanes hold a random mix of modes executes all 19 serially (measured: 69 us
+// per 4096x4096 atlas vs a 7 us copy).  So each workgroup first sorts its tile of BU_TILE blocks by
+// mode through LDS (counting sort: one LDS atomic per block), cuts every mode's run into chunks of
+// <= 64 blocks, and each wave then transcodes whole chunks with a wave-uniform mode (scalar branch,
+// no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
+// so global loads and stores stay fully coalesced (1 KiB per wave instruction).
+//   LDS per workgroup: tile 16 KiB + tables 5.8 KiB + 1 KiB status + counters.
+constexpr int BU_BPT = 4;                  // blocks per thread
+constexpr int BU_TILE = BU_WG * BU_BPT;    // 1024 blocks = 16 KiB
+constexpr int BU_MAX_CHUNKS = BU_TILE / 64 + 20;
+
+template <int TARGET>
+__global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
+                                                                unsigned long long base, unsigned long long* status,
+                                                                const BuTables* __restrict__ tables)
+{
+    static_assert(TARGET != BU_TGT_RGBA, "RGBA32 uses bu_uastc_kernel");
+    __shared__ BuTables T;
+    __shared__ uint4 sblk[BU_TILE];
+    __shared__ uint8_t sst[BU_TILE];
+    __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const size_t n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
+    size_t tile = blockIdx.x;
+    uint4 v[BU_BPT];
+#pragma unroll
+    for (int j = 0; j < BU_BPT; j++) {
+        const size_t idx = tile * BU_TILE + (size_t)j * BU_WG + tid;
+        v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+    }
+    bu_stage_tables(T, tables);
+    if (tid < 32) cnt[tid] = 0;
+    __syncthreads();
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const size_t tbase = tile * BU_TILE;
+        // ---- A: mode + rank within the mode (counting sort, pass 1) ----
+        uint32_t mode[BU_BPT], pos[BU_BPT];
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            const bool valid = tbase + (size_t)j * BU_WG + tid < n_blocks;
+            mode[j] = valid ? T.mode_lut[v[j].x & 127u] : 31u;
+            pos[j] = valid ? atomicAdd(&cnt[mode[j]], 1u) : 0u;
+        }
+        __syncthreads();
+        // ---- B: run starts and the chunk list (one wave) ----
+        if (wave == 0) {
+            const uint32_t c = lane < 20 ? cnt[lane] : 0u;
+            uint32_t incl = c, nch = (c + 63u) >> 6, cincl = nch;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t a = __shfl_up(incl, d), b2 = __shfl_up(cincl, d);
+                if (lane >= (unsigned)d) {
+                    incl += a;
+                    cincl += b2;
+                }
+            }
+            const uint32_t st = incl - c, cst = cincl - nch;
+            if (lane < 20) {
+                start[lane] = st;
+                cnt[lane] = 0;
+            }
+            for (uint32_t k = 0; k < nch; k++) {
+                const uint32_t left = c - 64u * k;
+                chunk[cst + k] = lane | ((st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
+            }
+            if (lane == 19) n_chunks = cincl;
+        }
+        __syncthreads();
+        // ---- scatter into sorted order (counting sort, pass 2) ----
+        uint32_t dest[BU_BPT];
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            dest[j] = mode[j] < 20u ? start[mode[j]] + pos[j] : 0u;
+            if (mode[j] < 20u) sblk[dest[j]] = v[j];
+        }
+        // prefetch the next tile while this one is transcoded
+        const size_t ntile = tile + gridDim.x;
+        uint4 vn[BU_BPT];
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            const size_t idx = ntile * BU_TILE + (size_t)j * BU_WG + tid;
+            vn[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        // ---- C: whole chunks, wave-uniform mode ----
+        const uint32_t nc = n_chunks;
+        for (uint32_t c = wave; c < nc; c += BU_WG / 64) {
+            const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk[c]);
+            const uint32_t m = desc & 31u, s0 = (desc >> 8) & 0xFFFFu, count = desc >> 24;
+            const bool active = lane < count;
+            const uint32_t slot = s0 + (active ? lane : 0u);
+            const uint4 bv = sblk[slot];
+            BuBlk b;
+            b.w[0] = bv.x;
+            b.w[1] = bv.y;
+            b.w[2] = bv.z;
+            b.w[3] = bv.w;
+            uint32_t o[4] = {0, 0, 0, 0};
+            int st = BU_ST_BAD_MODE;
+            if (active) {
+                switch (m) {
+#define BU_CASE(k) \
+    case k: st = bu_block_mode<TARGET, k>(T, b, o); break;
+                    BU_CASE(0) BU_CASE(1) BU_CASE(2) BU_CASE(3) BU_CASE(4) BU_CASE(5) BU_CASE(6) BU_CASE(7) BU_CASE(8) BU_CASE(9)
+                    BU_CASE(10) BU_CASE(11) BU_CASE(12) BU_CASE(13) BU_CASE(14) BU_CASE(15) BU_CASE(16) BU_CASE(17) BU_CASE(18)
+#undef BU_CASE
+                default: break;
+                }
+                if (st) o[0] = o[1] = o[2] = o[3] = 0;
+                sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
+                sst[slot] = (uint8_t)st;
+            }
+        }
+        __syncthreads();
+        // ---- D: results leave in original order ----
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            if (mode[j] < 20u) {
+                const size_t idx = tbase + (size_t)j * BU_WG + tid;
+                const uint4 r = sblk[dest[j]];
+                const uint32_t st = sst[dest[j]];
+                if (st) bu_report(status, base + idx, (int)st);
+                if constexpr (TARGET == BU_TGT_ETC1) reinterpret_cast<uint2*>(out)[idx] = make_uint2(r.x, r.y);
+                else reinterpret_cast<uint4*>(out)[idx] = r;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
+        __syncthreads();
     }
 }
 
@@ -253,6 +390,20 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     const unsigned grid = bu_grid_for(n_blocks, ctx->cu_count);
     const uint4* in = static_cast<const uint4*>(d_in);
     unsigned long long* st = reinterpret_cast<unsigned long long*>(d_status);
+    if (target != BU_TARGET_RGBA32 && n_blocks >= (size_t)BU_SORT_MIN_BLOCKS) {
+        // mode-sorted kernel: one 1024-block tile per workgroup, grid-stride beyond 7 workgroups per CU
+        size_t tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
+        const size_t cap = (size_t)ctx->cu_count * 7;
+        const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
+        switch (target) {
+        case BU_TARGET_ASTC: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_ASTC>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
+        case BU_TARGET_BC7: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_BC7>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
+        case BU_TARGET_ETC1: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_ETC1>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
+        default: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_ETC2>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
+        }
+        BU_HIP(ctx, hipGetLastError());
+        return BU_OK;
+    }
     switch (target) {
     case BU_TARGET_ASTC: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_ASTC>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
     case BU_TARGET_BC7: hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_BC7>, dim3(grid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables); break;
