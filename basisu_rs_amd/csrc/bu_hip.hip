@@ -96,16 +96,30 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
 // so global loads and stores stay fully coalesced (1 KiB per wave instruction).
 //   LDS per workgroup: tile 16 KiB + tables 5.8 KiB + 1 KiB status + counters.
-constexpr int BU_BPT = 4;                  // blocks per thread
-constexpr int BU_TILE = BU_WG * BU_BPT;    // 1024 blocks = 16 KiB
-constexpr int BU_MAX_CHUNKS = BU_TILE / 64 + 20;
+// WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
+constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 
-template <int TARGET>
-__global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
-                                                                unsigned long long base, unsigned long long* status,
-                                                                const BuTables* __restrict__ tables)
+template <int WGS>
+__device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
 {
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(&dst);
+    for (int i = threadIdx.x; i < BU_TABLE_VEC; i += WGS) d[i] = s[i];
+}
+
+#ifndef BU_STAMP
+#define BU_STAMP(k)
+#define BU_STAMP_ARG
+#define BU_STAMP_PASS
+#endif
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true>
+__global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
+                                                                unsigned long long base, unsigned long long* status,
+                                                                const BuTables* __restrict__ tables BU_STAMP_ARG)
+{
+    BU_STAMP(0)
     static_assert(TARGET != BU_TGT_RGBA, "RGBA32 uses bu_uastc_kernel");
+    constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
     __shared__ BuTables T;
     __shared__ uint4 sblk[BU_TILE];
     __shared__ uint8_t sst[BU_TILE];
@@ -119,9 +133,10 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __r
         const size_t idx = tile * BU_TILE + (size_t)j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
     }
-    bu_stage_tables(T, tables);
+    bu_stage_tables_n<WGS>(T, tables);
     if (tid < 32) cnt[tid] = 0;
     __syncthreads();
+    BU_STAMP(1)
     for (; tile < n_tiles; tile += gridDim.x) {
         const size_t tbase = tile * BU_TILE;
         // ---- A: mode + rank within the mode (counting sort, pass 1) ----
@@ -132,7 +147,9 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __r
             mode[j] = valid ? T.mode_lut[v[j].x & 127u] : 31u;
             pos[j] = valid ? atomicAdd(&cnt[mode[j]], 1u) : 0u;
         }
+        BU_STAMP(2)
         __syncthreads();
+        BU_STAMP(3)
         // ---- B: run starts and the chunk list (one wave) ----
         if (wave == 0) {
             const uint32_t c = lane < 20 ? cnt[lane] : 0u;
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __r
             if (lane == 19) n_chunks = cincl;
         }
         __syncthreads();
+        BU_STAMP(4)
         // ---- scatter into sorted order (counting sort, pass 2) ----
         uint32_t dest[BU_BPT];
 #pragma unroll
@@ -167,12 +185,15 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __r
         // prefetch the next tile while this one is transcoded
         const size_t ntile = tile + gridDim.x;
         uint4 vn[BU_BPT];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int j = 0; j < BU_BPT; j++) {
-            const size_t idx = ntile * BU_TILE + (size_t)j * BU_WG + tid;
-            vn[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < BU_BPT; j++) {
+                const size_t idx = ntile * BU_TILE + (size_t)j * BU_WG + tid;
+                vn[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+            }
         }
         __syncthreads();
+        BU_STAMP(5)
         // ---- C: whole chunks, wave-uniform mode ----
         const uint32_t nc = n_chunks;
         for (uint32_t c = wave; c < nc; c += BU_WG / 64) {
@@ -202,7 +223,9 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __r
                 sst[slot] = (uint8_t)st;
             }
         }
+        BU_STAMP(6)
         __syncthreads();
+        BU_STAMP(7)
         // ---- D: results leave in original order ----
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
@@ -215,10 +238,19 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_sorted_kernel(const uint4* __r
                 else reinterpret_cast<uint4*>(out)[idx] = r;
             }
         }
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
+            for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) {
+                const size_t idx = ntile * BU_TILE + (size_t)j * BU_WG + tid;
+                v[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+            }
+        }
         __syncthreads();
     }
+    BU_STAMP(8)
 }
 
 // uint4 -> uint4 copy with the transcoders' launch shape (measurement only)
@@ -392,14 +424,15 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     unsigned long long* st = reinterpret_cast<unsigned long long*>(d_status);
     if (target != BU_TARGET_RGBA32 && n_blocks >= (size_t)BU_SORT_MIN_BLOCKS) {
         // mode-sorted kernel: one 1024-block tile per workgroup, grid-stride beyond 7 workgroups per CU
+        constexpr int BU_TILE = BU_SORT_WGS * BU_SORT_BPT;
         size_t tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
         const size_t cap = (size_t)ctx->cu_count * 7;
         const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
         switch (target) {
-        case BU_TARGET_ASTC: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_ASTC>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
-        case BU_TARGET_BC7: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_BC7>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
-        case BU_TARGET_ETC1: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_ETC1>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
-        default: hipLaunchKernelGGL(bu_uastc_sorted_kernel<BU_TGT_ETC2>, dim3(sgrid), dim3(BU_WG), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables); break;
+        case BU_TARGET_ASTC: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ASTC, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        case BU_TARGET_BC7: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        case BU_TARGET_ETC1: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC1, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        default: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC2, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
         }
         BU_HIP(ctx, hipGetLastError());
         return BU_OK;

@@ -1,0 +1,139 @@
+// EXPERIMENTS ONLY (never shipped): time-attribution variants of the mode-sorted kernel.
+#include <hip/hip_runtime.h>
+// in-kernel stamps (diagnostic build only): s_memrealtime (100 MHz) is too coarse; s_memtime = shader clock
+#define BU_STAMP_ARG , unsigned long long* __restrict__ stamps
+#define BU_STAMP_PASS , (unsigned long long*)nullptr
+#define BU_STAMP(k)                                                                                   \
+    if (stamps && (threadIdx.x & 63u) == 0) {                                                         \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = t_;        \
+    }
+#include "../../basisu_rs_amd/csrc/bu_hip.hip"
+
+namespace {
+constexpr int BU_BPT = 4, BU_TILE = 1024, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
+// V=1 no transcode (identity through the sort); V=2 additionally no atomics/sort; V=3 load->LDS->store
+template <int V>
+__global__ __launch_bounds__(BU_WG) void bu_exp_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
+                                                       const BuTables* __restrict__ tables)
+{
+    __shared__ BuTables T;
+    __shared__ uint4 sblk[BU_TILE];
+    __shared__ uint8_t sst[BU_TILE];
+    __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const size_t n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
+    size_t tile = blockIdx.x;
+    uint4 v[BU_BPT];
+#pragma unroll
+    for (int j = 0; j < BU_BPT; j++) {
+        const size_t idx = tile * BU_TILE + (size_t)j * BU_WG + tid;
+        v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+    }
+    if (V != 3) bu_stage_tables(T, tables);
+    if (tid < 32) cnt[tid] = 0;
+    __syncthreads();
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const size_t tbase = tile * BU_TILE;
+        uint32_t mode[BU_BPT], pos[BU_BPT], dest[BU_BPT];
+        if constexpr (V == 3) {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) sblk[j * BU_WG + tid] = v[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) reinterpret_cast<uint4*>(out)[tbase + (size_t)j * BU_WG + tid] = sblk[j * BU_WG + tid];
+            __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            mode[j] = T.mode_lut[v[j].x & 127u];
+            if constexpr (V == 1) pos[j] = atomicAdd(&cnt[mode[j]], 1u);
+            else pos[j] = 0;
+        }
+        __syncthreads();
+        if (wave == 0 && V == 1) {
+            const uint32_t c = lane < 20 ? cnt[lane] : 0u;
+            uint32_t incl = c, nch = (c + 63u) >> 6, cincl = nch;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t a = __shfl_up(incl, d), b2 = __shfl_up(cincl, d);
+                if (lane >= (unsigned)d) { incl += a; cincl += b2; }
+            }
+            const uint32_t st = incl - c, cst = cincl - nch;
+            if (lane < 20) { start[lane] = st; cnt[lane] = 0; }
+            for (uint32_t k = 0; k < nch; k++) {
+                const uint32_t left = c - 64u * k;
+                chunk[cst + k] = lane | ((st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
+            }
+            if (lane == 19) n_chunks = cincl;
+        }
+        if (V == 2 && tid < 16) { chunk[tid] = 0 | ((64u * tid) << 8) | (64u << 24); n_chunks = 16; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            dest[j] = V == 1 ? start[mode[j]] + pos[j] : j * BU_WG + tid;
+            sblk[dest[j]] = v[j];
+        }
+        __syncthreads();
+        const uint32_t nc = n_chunks;
+        for (uint32_t c = wave; c < nc; c += BU_WG / 64) {
+            const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk[c]);
+            const uint32_t s0 = (desc >> 8) & 0xFFFFu, count = desc >> 24;
+            const bool active = lane < count;
+            const uint32_t slot = s0 + (active ? lane : 0u);
+            uint4 bv = sblk[slot];
+            bv.x ^= 1u;
+            if (active) { sblk[slot] = bv; sst[slot] = 0; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            const size_t idx = tbase + (size_t)j * BU_WG + tid;
+            uint4 r = sblk[dest[j]];
+            r.y += sst[dest[j]];
+            reinterpret_cast<uint4*>(out)[idx] = r;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+static unsigned long long* g_stamps = nullptr;
+extern "C" void bu_exp_set_stamps(unsigned long long* p) { g_stamps = p; }
+extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                 size_t n_blocks, int launches, void* stream, float* out_ms)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    const size_t tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (size_t)i % n_buffers;
+        const uint4* in = static_cast<const uint4*>(d_in[k]);
+        switch (variant) {
+        case 1: hipLaunchKernelGGL(bu_exp_kernel<1>, dim3((unsigned)tiles), dim3(BU_WG), 0, s, in, d_out[k], n_blocks, ctx->d_tables); break;
+        case 2: hipLaunchKernelGGL(bu_exp_kernel<2>, dim3((unsigned)tiles), dim3(BU_WG), 0, s, in, d_out[k], n_blocks, ctx->d_tables); break;
+        case 3: hipLaunchKernelGGL(bu_exp_kernel<3>, dim3((unsigned)tiles), dim3(BU_WG), 0, s, in, d_out[k], n_blocks, ctx->d_tables); break;
+        case 100:  // plain one-lane-per-block kernel
+            hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_BC7>, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, s, in, d_out[k], n_blocks, 1u, 0ull,
+                               (unsigned long long*)nullptr, ctx->d_tables);
+            break;
+#define SV(code, W, B, DIV, MINW, PF)                                                                                        \
+    case code: {                                                                                                            \
+        const size_t t_ = (n_blocks + (size_t)(W) * (B)-1) / ((size_t)(W) * (B));                                           \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, W, B, MINW, PF>), dim3((unsigned)((t_ + (DIV)-1) / (DIV))), dim3(W), 0, s, in, d_out[k], \
+                           n_blocks, 0ull, (unsigned long long*)nullptr, ctx->d_tables, g_stamps);                          \
+    } break;
+            SV(0, 256, 4, 1, 1, true) SV(10, 256, 4, 1, 1, false) SV(11, 512, 2, 1, 1, false) SV(12, 512, 2, 1, 8, false) SV(13, 256, 4, 1, 6, false)
+            SV(14, 1024, 1, 1, 8, false) SV(15, 512, 4, 1, 1, false) SV(16, 512, 4, 1, 8, false) SV(17, 1024, 2, 1, 8, false) SV(18, 1024, 4, 1, 4, false)
+            SV(19, 1024, 4, 1, 1, false) SV(20, 256, 4, 1, 8, false)
+#undef SV
+        default: return BU_ERR_ARGUMENT;
+        }
+    }
+    BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
