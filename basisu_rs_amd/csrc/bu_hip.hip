@@ -112,17 +112,21 @@ __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables*
 #define BU_STAMP_ARG
 #define BU_STAMP_PASS
 #endif
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true>
+// DIRECT: results are stored to global memory straight from the chunk loop at the block's original
+// index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
+// RGBA32 (64 B per block do not fit a second LDS tile; `bpr` = blocks per image row).
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA)>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
-                                                                unsigned long long base, unsigned long long* status,
+                                                                unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTables* __restrict__ tables BU_STAMP_ARG)
 {
     BU_STAMP(0)
-    static_assert(TARGET != BU_TGT_RGBA, "RGBA32 uses bu_uastc_kernel");
+    static_assert(TARGET != BU_TGT_RGBA || DIRECT, "RGBA32 needs DIRECT stores");
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
     __shared__ BuTables T;
     __shared__ uint4 sblk[BU_TILE];
-    __shared__ uint8_t sst[BU_TILE];
+    __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
+    __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
     __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const size_t n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
@@ -180,7 +184,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             dest[j] = mode[j] < 20u ? start[mode[j]] + pos[j] : 0u;
-            if (mode[j] < 20u) sblk[dest[j]] = v[j];
+            if (mode[j] < 20u) {
+                sblk[dest[j]] = v[j];
+                if constexpr (DIRECT) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
+            }
         }
         // prefetch the next tile while this one is transcoded
         const size_t ntile = tile + gridDim.x;
@@ -207,7 +214,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             b.w[1] = bv.y;
             b.w[2] = bv.z;
             b.w[3] = bv.w;
-            uint32_t o[4] = {0, 0, 0, 0};
+            constexpr int NO = TARGET == BU_TGT_RGBA ? 16 : 4;
+            uint32_t o[NO];
+#pragma unroll
+            for (int i = 0; i < NO; i++) o[i] = 0;
             int st = BU_ST_BAD_MODE;
             if (active) {
                 switch (m) {
@@ -218,24 +228,44 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #undef BU_CASE
                 default: break;
                 }
-                if (st) o[0] = o[1] = o[2] = o[3] = 0;
-                sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
-                sst[slot] = (uint8_t)st;
+                if (st) {
+#pragma unroll
+                    for (int i = 0; i < NO; i++) o[i] = 0;
+                }
+                if constexpr (DIRECT) {
+                    const size_t idx = tbase + sorig[slot];
+                    if (st) bu_report(status, base + idx, st);
+                    if constexpr (TARGET == BU_TGT_RGBA) {
+                        const size_t by = idx / bpr, bx = idx - by * bpr;
+                        uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) img[(4 * by + r) * (size_t)bpr + bx] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+                    } else if constexpr (TARGET == BU_TGT_ETC1) {
+                        reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
+                    } else {
+                        reinterpret_cast<uint4*>(out)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                } else {
+                    sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
+                    sst[slot] = (uint8_t)st;
+                }
             }
         }
         BU_STAMP(6)
         __syncthreads();
         BU_STAMP(7)
         // ---- D: results leave in original order ----
+        if constexpr (!DIRECT) {
 #pragma unroll
-        for (int j = 0; j < BU_BPT; j++) {
-            if (mode[j] < 20u) {
-                const size_t idx = tbase + (size_t)j * BU_WG + tid;
-                const uint4 r = sblk[dest[j]];
-                const uint32_t st = sst[dest[j]];
-                if (st) bu_report(status, base + idx, (int)st);
-                if constexpr (TARGET == BU_TGT_ETC1) reinterpret_cast<uint2*>(out)[idx] = make_uint2(r.x, r.y);
-                else reinterpret_cast<uint4*>(out)[idx] = r;
+            for (int j = 0; j < BU_BPT; j++) {
+                if (mode[j] < 20u) {
+                    const size_t idx = tbase + (size_t)j * BU_WG + tid;
+                    const uint4 r = sblk[dest[j]];
+                    const uint32_t st = sst[dest[j]];
+                    if (st) bu_report(status, base + idx, (int)st);
+                    if constexpr (TARGET == BU_TGT_ETC1) reinterpret_cast<uint2*>(out)[idx] = make_uint2(r.x, r.y);
+                    else reinterpret_cast<uint4*>(out)[idx] = r;
+                }
             }
         }
         if constexpr (PREFETCH) {
@@ -422,17 +452,18 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     const unsigned grid = bu_grid_for(n_blocks, ctx->cu_count);
     const uint4* in = static_cast<const uint4*>(d_in);
     unsigned long long* st = reinterpret_cast<unsigned long long*>(d_status);
-    if (target != BU_TARGET_RGBA32 && n_blocks >= (size_t)BU_SORT_MIN_BLOCKS) {
+    if (n_blocks >= (size_t)BU_SORT_MIN_BLOCKS) {
         // mode-sorted kernel: one 1024-block tile per workgroup, grid-stride beyond 7 workgroups per CU
         constexpr int BU_TILE = BU_SORT_WGS * BU_SORT_BPT;
         size_t tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
         const size_t cap = (size_t)ctx->cu_count * 7;
         const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
         switch (target) {
-        case BU_TARGET_ASTC: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ASTC, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        case BU_TARGET_BC7: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        case BU_TARGET_ETC1: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC1, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        default: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC2, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        case BU_TARGET_ASTC: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ASTC, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        case BU_TARGET_BC7: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        case BU_TARGET_ETC1: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC1, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        case BU_TARGET_RGBA32: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        default: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC2, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
         }
         BU_HIP(ctx, hipGetLastError());
         return BU_OK;

@@ -254,8 +254,34 @@ BU_DEV uint32_t bu_wdeq(uint32_t r)
     else return r * 2u + ((r >> 4) << 1);
 }
 
-// uastc.rs:218-235 with l64 = 64*l, d = h-l:  ((l*257)*(64-w) + (h*257)*w + 32) >> 14
-BU_DEV uint32_t bu_lerp(int l64, int d, uint32_t w) { return (uint32_t)((l64 + (int)w * d) * 257 + 32) >> 14; }
+// uastc.rs:218-235 as one dot product.  With lo16 = l*257, hi16 = h*257 packed in a word and the
+// weights scaled by 4, ((lo16*(64-w) + hi16*w + 32) >> 6) >> 8 is byte 2 of
+//   lo16*(256-4w) + hi16*4w + 128      (v_dot2_u32_u16, max 65535*256+128 < 2^32)
+BU_DEV uint32_t bu_udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIPCC__)
+    typedef unsigned short bu_us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(bu_us2, a), __builtin_bit_cast(bu_us2, b), c, false);
+#else
+    return (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16) + c;
+#endif
+}
+// bytes of a:b selected into one word (v_perm_b32): sel byte k picks byte (sel>>8k)&7 of {b (0-3), a (4-7)}, 0x0C = zero
+BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
+{
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_perm(a, b, sel);
+#else
+    const uint64_t v = ((uint64_t)a << 32) | b;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t sk = (sel >> (8 * k)) & 0xFFu;
+        const uint32_t byte = sk < 8 ? (uint32_t)((v >> (8 * sk)) & 0xFFu) : 0u;
+        r |= byte << (8 * k);
+    }
+    return r;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // Full unpack to 16 RGBA8 texels, row-major inside the block, little-endian R,G,B,A
@@ -285,49 +311,73 @@ BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
         uint32_t W[3];
         bu_decode_weights<M>(b, uanch, W);
 
-        // per subset, per output channel: 64*lo and hi-lo (uastc.rs:176-216 gives the channel order)
+        // per subset, per interpolated channel: lo*257 | (hi*257) << 16 (uastc.rs:176-216 gives the channel order)
         constexpr int NC = fmt == BU_FMT_RGB ? 3 : (fmt == BU_FMT_RGBA ? 4 : 2);  // distinct interpolations
-        int l64[3][4], dd[3][4];
+        uint32_t A[3][4];
         BU_UNROLL
         for (int s = 0; s < subsets; s++) {
             BU_UNROLL
             for (int c = 0; c < NC; c++) {
-                const int lo = (int)e[(2 * L::channels) * s + 2 * c], hi = (int)e[(2 * L::channels) * s + 2 * c + 1];
-                l64[s][c] = lo * 64;
-                dd[s][c] = hi - lo;
+                const uint32_t lo = e[(2 * L::channels) * s + 2 * c], hi = e[(2 * L::channels) * s + 2 * c + 1];
+                A[s][c] = (lo * 257u) | ((hi * 257u) << 16);
             }
+        }
+        uint32_t X1[4], X2[4];  // xor deltas for the branch-free subset blend
+        if constexpr (subsets == 3) {
+            BU_UNROLL
+            for (int c = 0; c < NC; c++) {
+                X1[c] = A[0][c] ^ A[1][c];
+                X2[c] = A[0][c] ^ A[2][c];
+            }
+        }
+        if constexpr (planes == 2 && fmt != BU_FMT_LA) {
+            // Dual plane, runtime component selector (uastc.rs:293-296).  Rotate the compsel channel into
+            // slot 3 once per block, interpolate slot 3 with the plane-1 weight, and undo the rotation with
+            // one byte permute per texel -- instead of one select per channel per texel.
+            const uint32_t a3 = NC == 4 ? A[0][3] : 0xFFFFFFFFu;  // RGB: alpha is the constant 255
+            uint32_t As[4];
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) As[c] = compsel == (uint32_t)c ? a3 : A[0][c];
+            As[3] = compsel == 0 ? A[0][0] : compsel == 1 ? A[0][1] : compsel == 2 ? A[0][2] : a3;
+            const uint32_t unrot = compsel == 0 ? 0x00020103u : compsel == 1 ? 0x01020300u : compsel == 2 ? 0x02030100u : 0x03020100u;
+            BU_UNROLL
+            for (int i = 0; i < 16; i++) {
+                const uint32_t b0 = bu_wdeq<wb>(bu_wfield<wb>(W, 2 * i)) * 0x3FFFCu + 256u;
+                const uint32_t b1 = bu_wdeq<wb>(bu_wfield<wb>(W, 2 * i + 1)) * 0x3FFFCu + 256u;
+                const uint32_t v0 = bu_udot2(As[0], b0, 128u), v1 = bu_udot2(As[1], b0, 128u);
+                const uint32_t v2 = bu_udot2(As[2], b0, 128u), v3 = bu_udot2(As[3], b1, 128u);
+                const uint32_t q = bu_perm(v1, v0, 0x0C0C0602u) | bu_perm(v3, v2, 0x06020C0Cu);
+                px[i] = bu_perm(q, q, unrot);
+            }
+            return BU_ST_OK;
         }
         BU_UNROLL
         for (int i = 0; i < 16; i++) {
             uint32_t sid = 0;
             if constexpr (subsets > 1) sid = (upat >> (2 * i)) & 3u;
-            const uint32_t w0 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes));
-            uint32_t w1 = w0;
-            if constexpr (planes == 2) w1 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes + 1));
+            // weights x4, packed (256-4w) | 4w << 16
+            const uint32_t b0 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes)) * 0x3FFFCu + 256u;
+            uint32_t b1 = b0;
+            if constexpr (planes == 2) b1 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes + 1)) * 0x3FFFCu + 256u;
             uint32_t v[4];
             BU_UNROLL
             for (int c = 0; c < NC; c++) {
-                int L0 = l64[0][c], D0 = dd[0][c];
-                if constexpr (subsets >= 2) {
-                    L0 = sid == 1 ? l64[1][c] : L0;
-                    D0 = sid == 1 ? dd[1][c] : D0;
-                }
+                uint32_t a = A[0][c];
+                if constexpr (subsets == 2) a = sid == 1 ? A[1][c] : a;
                 if constexpr (subsets == 3) {
-                    L0 = sid == 2 ? l64[2][c] : L0;
-                    D0 = sid == 2 ? dd[2][c] : D0;
+                    // mask blend, not a select chain: hipcc turns `sid==2 ? a[2] : sid==1 ? a[1] : a[0]` back
+                    // into a dynamically indexed array and parks it in LDS (48 KiB per workgroup)
+                    const uint32_t k1 = 0u - (sid & 1u), k2 = 0u - (sid >> 1);
+                    a ^= (X1[c] & k1) ^ (X2[c] & k2);
                 }
-                // plane-1 weight drives the compsel channel (uastc.rs:293-296); for LA the second
-                // interpolation is alpha and compsel is fixed to A
-                uint32_t w = w0;
-                if constexpr (planes == 2) {
-                    if constexpr (fmt == BU_FMT_LA) w = (c == 1) ? w1 : w0;
-                    else w = (compsel == (uint32_t)c) ? w1 : w0;
-                }
-                v[c] = bu_lerp(L0, D0, w);
+                // LA dual plane (mode 17): the second interpolation is alpha, compsel fixed to A
+                const uint32_t bw = (planes == 2 && c == 1) ? b1 : b0;
+                v[c] = bu_udot2(a, bw, 128u);  // result = byte 2
             }
-            if constexpr (fmt == BU_FMT_RGB) px[i] = v[0] | (v[1] << 8) | (v[2] << 16) | 0xFF000000u;
-            else if constexpr (fmt == BU_FMT_RGBA) px[i] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-            else px[i] = v[0] * 0x010101u | (v[1] << 24);
+            // gather byte 2 of each channel word
+            if constexpr (fmt == BU_FMT_RGB) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | ((v[2] & 0x00FF0000u) | 0xFF000000u);
+            else if constexpr (fmt == BU_FMT_RGBA) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | (bu_perm(v[3], v[2], 0x06020C0Cu));
+            else px[i] = bu_perm(v[1], v[0], 0x06020202u);
         }
         return BU_ST_OK;
     }

@@ -119,15 +119,14 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
             hipLaunchKernelGGL(bu_uastc_kernel<BU_TGT_BC7>, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, s, in, d_out[k], n_blocks, 1u, 0ull,
                                (unsigned long long*)nullptr, ctx->d_tables);
             break;
-#define SV(code, W, B, DIV, MINW, PF)                                                                                        \
+#define SV(code, W, B, DIV, MINW, PF, DIR)                                                                                   \
     case code: {                                                                                                            \
         const size_t t_ = (n_blocks + (size_t)(W) * (B)-1) / ((size_t)(W) * (B));                                           \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, W, B, MINW, PF>), dim3((unsigned)((t_ + (DIV)-1) / (DIV))), dim3(W), 0, s, in, d_out[k], \
-                           n_blocks, 0ull, (unsigned long long*)nullptr, ctx->d_tables, g_stamps);                          \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, W, B, MINW, PF, DIR>), dim3((unsigned)((t_ + (DIV)-1) / (DIV))), dim3(W), 0, s, in, d_out[k], \
+                           n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, g_stamps);                   \
     } break;
-            SV(0, 256, 4, 1, 1, true) SV(10, 256, 4, 1, 1, false) SV(11, 512, 2, 1, 1, false) SV(12, 512, 2, 1, 8, false) SV(13, 256, 4, 1, 6, false)
-            SV(14, 1024, 1, 1, 8, false) SV(15, 512, 4, 1, 1, false) SV(16, 512, 4, 1, 8, false) SV(17, 1024, 2, 1, 8, false) SV(18, 1024, 4, 1, 4, false)
-            SV(19, 1024, 4, 1, 1, false) SV(20, 256, 4, 1, 8, false)
+            SV(0, 256, 4, 1, 1, true, false) SV(10, 256, 4, 1, 1, false, true) SV(11, 512, 4, 1, 1, false, false) SV(12, 512, 4, 1, 1, false, true)
+            SV(13, 1024, 4, 1, 1, false, false) SV(14, 1024, 4, 1, 1, false, true) SV(15, 256, 8, 1, 1, false, true) SV(16, 512, 2, 1, 1, false, true)
 #undef SV
         default: return BU_ERR_ARGUMENT;
         }

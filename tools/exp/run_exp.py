@@ -36,25 +36,7 @@ def t(variant, ins, launches=256):
         best = min(best, ms.value / launches * 1e3)
     return best
 gold = mk("gold")
-import numpy as np
-def stamps(variant, nwaves_per_wg, n_wg):
-    buf = torch.zeros((n_wg * nwaves_per_wg, 16), dtype=torch.int64, device=dev)
-    lib.bu_exp_set_stamps(vp(buf.data_ptr()))
-    A = vp * NBUF
-    ip, op = A(*[x.data_ptr() for x in gold]), A(*[x.data_ptr() for x in outs])
-    ms = ctypes.c_float(0)
-    # several launches so the measured one starts from a busy pipeline; stamps of the last launch survive
-    lib.bu_exp_time(h, variant, ip, op, NBUF, N, 5, sp, ctypes.byref(ms))
-    torch.cuda.synchronize()
-    lib.bu_exp_set_stamps(None)
-    s = buf.cpu().numpy()[:, :9].astype(np.float64)
-    t0 = s[:, 0].min()
-    rel = s - t0
-    names_ = ["start", "tables+loads", "A done", "bar1", "B done(bar2)", "scatter(bar3)", "C done", "bar4", "end"]
-    print("variant", variant, "stamp = shader clocks since first wave start; mean / p50 / max over waves")
-    for k in range(9):
-        print("  %-14s mean %8.0f  p50 %8.0f  max %8.0f   delta-mean %8.0f" % (names_[k], rel[:, k].mean(), np.median(rel[:, k]), rel[:, k].max(), (rel[:, k] - rel[:, k - 1]).mean() if k else 0))
-lib.bu_exp_set_stamps.argtypes = [vp]
-print("baseline", t(0, gold))
-stamps(0, 4, 1024)
-stamps(19, 16, 256)
+names = {0: "WG256 BPT4 lds-out", 10: "WG256 BPT4 direct", 11: "WG512 BPT4 lds-out", 12: "WG512 BPT4 direct", 13: "WG1024 BPT4 lds-out",
+         14: "WG1024 BPT4 direct", 15: "WG256 BPT8 direct", 16: "WG512 BPT2 direct"}
+for v in sorted(names):
+    print("%-28s %8.2f us" % (names[v], t(v, gold)), flush=True)
