@@ -116,7 +116,7 @@ __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables*
 // index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
 // RGBA32 (64 B per block do not fit a second LDS tile; `bpr` = blocks per image row).
 template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA)>
-__global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
+__global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTables* __restrict__ tables BU_STAMP_ARG)
 {
@@ -129,12 +129,12 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
     __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const size_t n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
-    size_t tile = blockIdx.x;
+    const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
+    unsigned tile = blockIdx.x;
     uint4 v[BU_BPT];
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++) {
-        const size_t idx = tile * BU_TILE + (size_t)j * BU_WG + tid;
+        const unsigned idx = tile * BU_TILE + j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
     }
     bu_stage_tables_n<WGS>(T, tables);
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     __syncthreads();
     BU_STAMP(1)
     for (; tile < n_tiles; tile += gridDim.x) {
-        const size_t tbase = tile * BU_TILE;
+        const unsigned tbase = tile * BU_TILE;
         // ---- A: mode + rank within the mode (counting sort, pass 1) ----
         uint32_t mode[BU_BPT], pos[BU_BPT];
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
-            const bool valid = tbase + (size_t)j * BU_WG + tid < n_blocks;
+            const bool valid = tbase + j * BU_WG + tid < n_blocks;
             mode[j] = valid ? T.mode_lut[v[j].x & 127u] : 31u;
             pos[j] = valid ? atomicAdd(&cnt[mode[j]], 1u) : 0u;
         }
@@ -190,12 +190,12 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             }
         }
         // prefetch the next tile while this one is transcoded
-        const size_t ntile = tile + gridDim.x;
+        const unsigned ntile = tile + gridDim.x;
         uint4 vn[BU_BPT];
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const size_t idx = ntile * BU_TILE + (size_t)j * BU_WG + tid;
+                const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
                 vn[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
             }
         }
@@ -233,13 +233,13 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                     for (int i = 0; i < NO; i++) o[i] = 0;
                 }
                 if constexpr (DIRECT) {
-                    const size_t idx = tbase + sorig[slot];
+                    const unsigned idx = tbase + sorig[slot];
                     if (st) bu_report(status, base + idx, st);
                     if constexpr (TARGET == BU_TGT_RGBA) {
-                        const size_t by = idx / bpr, bx = idx - by * bpr;
+                        const unsigned by = idx / bpr, bx = idx - by * bpr;
                         uint4* img = reinterpret_cast<uint4*>(out);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) img[(4 * by + r) * (size_t)bpr + bx] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+                        for (int r = 0; r < 4; r++) img[(size_t)((4 * by + r) * bpr + bx)] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
                     } else if constexpr (TARGET == BU_TGT_ETC1) {
                         reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
                     } else {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 if (mode[j] < 20u) {
-                    const size_t idx = tbase + (size_t)j * BU_WG + tid;
+                    const unsigned idx = tbase + j * BU_WG + tid;
                     const uint4 r = sblk[dest[j]];
                     const uint32_t st = sst[dest[j]];
                     if (st) bu_report(status, base + idx, (int)st);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         } else {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const size_t idx = ntile * BU_TILE + (size_t)j * BU_WG + tid;
+                const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
                 v[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
             }
         }
@@ -453,19 +453,43 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     const uint4* in = static_cast<const uint4*>(d_in);
     unsigned long long* st = reinterpret_cast<unsigned long long*>(d_status);
     if (n_blocks >= (size_t)BU_SORT_MIN_BLOCKS) {
-        // mode-sorted kernel: one 1024-block tile per workgroup, grid-stride beyond 7 workgroups per CU
+        // mode-sorted kernel: one tile per workgroup, grid-stride beyond 7 workgroups per CU.  The kernel
+        // indexes with 32 bits, so very large slices are cut into launches of <= 2^26 blocks (1 GiB in);
+        // RGBA32 pieces end on whole block rows so the image addressing stays launch-relative.
         constexpr int BU_TILE = BU_SORT_WGS * BU_SORT_BPT;
-        size_t tiles = (n_blocks + BU_TILE - 1) / BU_TILE;
-        const size_t cap = (size_t)ctx->cu_count * 7;
-        const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
-        switch (target) {
-        case BU_TARGET_ASTC: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ASTC, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        case BU_TARGET_BC7: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        case BU_TARGET_ETC1: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC1, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        case BU_TARGET_RGBA32: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
-        default: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC2, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, in, d_out, n_blocks, (unsigned)bpr, base, st, ctx->d_tables BU_STAMP_PASS); break;
+        size_t piece = (size_t)1 << 26;
+        if (target == BU_TARGET_RGBA32) piece = bpr <= piece ? (piece / bpr) * bpr : bpr;
+        const size_t obytes = bu_target_block_bytes(target);
+        for (size_t done = 0; done < n_blocks; done += piece) {
+            const size_t nb = n_blocks - done < piece ? n_blocks - done : piece;
+            const uint4* pin = in + done;
+            void* pout = static_cast<uint8_t*>(d_out) + done * obytes;  // RGBA32: done is a multiple of bpr -> whole rows
+            const size_t tiles = (nb + BU_TILE - 1) / BU_TILE;
+            const size_t cap = (size_t)ctx->cu_count * 7;
+            const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
+            const unsigned long long pbase = base + done;
+            // large inputs: 4096-block tiles (1024 threads x 4) -- longer per-mode runs, so the <= 64-block chunks
+            // are fuller (96 % vs 84 %) and the table blob is staged 4x less often; measured 14.1 vs 15.3 us at 2^20 blocks
+#define BU_LAUNCH_SORTED(T)                                                                                                             \
+    if (big)                                                                                                                            \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 4, 1, false>), dim3(bgrid), dim3(1024), 0, stream, pin, pout, (unsigned)nb, \
+                           (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                                      \
+    else                                                                                                                                \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
+            const bool big = target != BU_TARGET_RGBA32 && nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
+            const size_t btiles = (nb + 4095) / 4096;
+            const unsigned bgrid = (unsigned)(btiles < (size_t)ctx->cu_count * 2 ? btiles : (size_t)ctx->cu_count * 2);
+            switch (target) {
+            case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
+            case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
+            case BU_TARGET_ETC1: BU_LAUNCH_SORTED(BU_TGT_ETC1) break;
+            case BU_TARGET_RGBA32: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS); break;
+            default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
+            }
+#undef BU_LAUNCH_SORTED
+            BU_HIP(ctx, hipGetLastError());
         }
-        BU_HIP(ctx, hipGetLastError());
         return BU_OK;
     }
     switch (target) {

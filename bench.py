@@ -35,6 +35,21 @@ BYTES_PER_BLOCK = 32  # 16 read + 16 written
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the BC7 kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE; tools/gpu_pmc.sh), or None when no summary is committed"""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bc7.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(golden, idx, budget_s=12.0):
     """oracle timed on the host: 1 thread and all hardware threads, bounded sample"""
     from oracle.pyoracle import Oracle
@@ -85,8 +100,13 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 exercises the N>1 code path (RCCL init, barriers, all_reduce, all-gather) with one rank
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from basisu_rs_amd import Context, _lib, synth
@@ -139,18 +159,18 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev_ms = run(args.steps)  # K launches, hipEvents recorded on the launch stream around them
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, ev_ms / 1e3], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, ev_max = float(t[0]), float(t[1])
     ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
@@ -202,7 +222,7 @@ def main():
         del rg_out
 
     allgather = None
-    if world > 1:
+    if use_dist:
         # reassembly of the texture array: every rank receives every rank's 16 MiB BC7 shard
         full = torch.empty((world * N_BLOCKS, 16), dtype=torch.uint8, device=dev)
         for _ in range(3):
@@ -237,8 +257,8 @@ def main():
                                    "%d distinct atlases rotated (cold cache)" % nbuf,
                        "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "bu_uastc_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
+                         "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
                          "bytes_per_launch": BYTES_PER_BLOCK * N_BLOCKS},
         }
         if allgather:
@@ -247,7 +267,7 @@ def main():
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(golden, idx0)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
