@@ -9,7 +9,19 @@ from .api import (  # noqa: F401
     Decoder,
     TargetTextureFormat,
     default_context,
+    Image,
+    basislz_decode,
+    crc16,
     etc1s_selector_from_rows,
+    read_header,
+    read_slice_descs,
+    read_to_astc,
+    read_to_bc7,
+    read_to_etc1,
+    read_to_etc2,
+    read_to_rgba,
+    read_to_uastc,
+    write_uastc_file,
     transcode_uastc_block_to_astc,
     transcode_uastc_block_to_bc7,
     transcode_uastc_block_to_etc1,

@@ -22,8 +22,39 @@ SYMBOLS = [
     "bu_uastc_transcode_device", "bu_status_word_reset", "bu_status_word_decode",
     "bu_etc1s_selector_from_rows", "bu_etc1s_transcode_etc1_device", "bu_etc1s_decode_rgba_device",
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
+    "bu_basis_read_header", "bu_basis_read_slice_descs", "bu_basis_crc16", "bu_read_query", "bu_read_to", "bu_basislz_decode",
+    "bu_basis_write_uastc",
     "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_copy_launches",
 ]
+
+# bu_read_target
+READ_RGBA, READ_ETC1, READ_ETC2, READ_UASTC, READ_ASTC, READ_BC7 = range(6)
+
+
+class BasisHeader(ctypes.Structure):  # bu_basis_header == basis::Header (basis.rs:417-454)
+    _fields_ = [("sig", ctypes.c_uint16), ("ver", ctypes.c_uint16), ("header_size", ctypes.c_uint16), ("header_crc16", ctypes.c_uint16),
+                ("data_size", ctypes.c_uint32), ("data_crc16", ctypes.c_uint16), ("total_slices", ctypes.c_uint32), ("total_images", ctypes.c_uint32),
+                ("tex_format", ctypes.c_uint8), ("flags", ctypes.c_uint16), ("tex_type", ctypes.c_uint8), ("us_per_frame", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("userdata0", ctypes.c_uint32), ("userdata1", ctypes.c_uint32), ("total_endpoints", ctypes.c_uint16),
+                ("endpoint_cb_file_ofs", ctypes.c_uint32), ("endpoint_cb_file_size", ctypes.c_uint32), ("total_selectors", ctypes.c_uint16),
+                ("selector_cb_file_ofs", ctypes.c_uint32), ("selector_cb_file_size", ctypes.c_uint32), ("tables_file_ofs", ctypes.c_uint32),
+                ("tables_file_size", ctypes.c_uint32), ("slice_desc_file_ofs", ctypes.c_uint32), ("extended_file_ofs", ctypes.c_uint32),
+                ("extended_file_size", ctypes.c_uint32)]
+
+    def as_list(self):
+        return [getattr(self, f) for f, _ in self._fields_]
+
+
+class SliceDesc(ctypes.Structure):  # bu_slice_desc == basis::SliceDesc (basis.rs:519-535)
+    _fields_ = [("image_index", ctypes.c_uint32), ("level_index", ctypes.c_uint8), ("flags", ctypes.c_uint8), ("orig_width", ctypes.c_uint16),
+                ("orig_height", ctypes.c_uint16), ("num_blocks_x", ctypes.c_uint16), ("num_blocks_y", ctypes.c_uint16), ("file_ofs", ctypes.c_uint32),
+                ("file_size", ctypes.c_uint32), ("slice_data_crc16", ctypes.c_uint16)]
+
+
+class ImageDesc(ctypes.Structure):  # bu_image
+    _fields_ = [("w", ctypes.c_uint32), ("h", ctypes.c_uint32), ("stride", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("offset", ctypes.c_uint64), ("size", ctypes.c_uint64)]
+
 
 _lib = None
 
@@ -74,6 +105,21 @@ def load():
     lib.bu_etc1s_transcode_etc1.restype = c.c_int
     lib.bu_etc1s_decode_rgba.argtypes = [vp, vp, vp, sz, sz, vp, u32, vp, u32, vp, sz, u64p]
     lib.bu_etc1s_decode_rgba.restype = c.c_int
+    szp = c.POINTER(sz)
+    lib.bu_basis_read_header.argtypes = [vp, sz, c.POINTER(BasisHeader)]
+    lib.bu_basis_read_header.restype = c.c_int
+    lib.bu_basis_read_slice_descs.argtypes = [vp, sz, c.POINTER(BasisHeader), c.POINTER(SliceDesc), sz, szp]
+    lib.bu_basis_read_slice_descs.restype = c.c_int
+    lib.bu_basis_crc16.argtypes = [vp, sz, c.c_uint16]
+    lib.bu_basis_crc16.restype = c.c_uint16
+    lib.bu_read_query.argtypes = [c.c_int, vp, sz, szp, szp]
+    lib.bu_read_query.restype = c.c_int
+    lib.bu_read_to.argtypes = [vp, c.c_int, vp, sz, c.POINTER(BasisHeader), c.POINTER(ImageDesc), sz, szp, vp, sz]
+    lib.bu_read_to.restype = c.c_int
+    lib.bu_basislz_decode.argtypes = [vp, sz, u32, vp, vp, vp]
+    lib.bu_basislz_decode.restype = c.c_int
+    lib.bu_basis_write_uastc.argtypes = [c.POINTER(SliceDesc), c.POINTER(vp), szp, sz, c.c_uint16, c.c_uint8, vp, sz, szp]
+    lib.bu_basis_write_uastc.restype = c.c_int
     lib.bu_copy_ceiling_device.argtypes = [vp, vp, sz, vp, vp]
     lib.bu_copy_ceiling_device.restype = c.c_int
     lib.bu_time_uastc_launches.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]

@@ -189,6 +189,125 @@ def etc1s_selector_from_rows(rows):
     return out
 
 
+# ---- whole-file API: basis.rs / lib.rs:20-22 -----------------------------------------------------------
+class Image:
+    """lib.rs:63-68 Image<u8>: w, h = original pixel size, stride in bytes, data = bytes"""
+
+    def __init__(self, w, h, stride, data):
+        self.w, self.h, self.stride, self.data = w, h, stride, data
+
+    def __repr__(self):
+        return "Image(w=%d, h=%d, stride=%d, %d bytes)" % (self.w, self.h, self.stride, len(self.data))
+
+
+def _check_host(st):
+    if st != _lib.OK:
+        raise BasisuError(st)
+
+
+def read_header(buf):
+    """basis::read_header (basis.rs:307-336) -> _lib.BasisHeader"""
+    lib = _lib.load()
+    a = _as_u8(buf)
+    h = _lib.BasisHeader()
+    _check_host(lib.bu_basis_read_header(a.ctypes.data, a.size, ctypes.byref(h)))
+    return h
+
+
+def read_slice_descs(buf, header=None):
+    """basis::read_slice_descs (basis.rs:343-362)"""
+    lib = _lib.load()
+    a = _as_u8(buf)
+    h = header or read_header(buf)
+    n = ctypes.c_size_t(0)
+    _check_host(lib.bu_basis_read_slice_descs(a.ctypes.data, a.size, ctypes.byref(h), None, 0, ctypes.byref(n)))
+    arr = (_lib.SliceDesc * max(n.value, 1))()
+    _check_host(lib.bu_basis_read_slice_descs(a.ctypes.data, a.size, ctypes.byref(h), arr, n.value, ctypes.byref(n)))
+    return list(arr[: n.value])
+
+
+def crc16(data, crc=0):
+    a = _as_u8(data)
+    return _lib.load().bu_basis_crc16(a.ctypes.data, a.size, crc)
+
+
+def _read_to(target, buf, ctx=None):
+    lib = _lib.load()
+    a = _as_u8(buf)
+    n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _check_host(lib.bu_read_query(target, a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb)))
+    c = ctx or default_context()
+    imgs = (_lib.ImageDesc * max(n.value, 1))()
+    out = np.empty(max(nb.value, 1), dtype=np.uint8)
+    h = _lib.BasisHeader()
+    st = lib.bu_read_to(c.handle, target, a.ctypes.data, a.size, ctypes.byref(h), imgs, n.value, ctypes.byref(n), out.ctypes.data, out.size)
+    c._check(st)
+    return h, [Image(im.w, im.h, im.stride, out[im.offset:im.offset + im.size]) for im in imgs[: n.value]]
+
+
+def read_to_rgba(buf, ctx=None):  # basis.rs:8-90 -> (Header, Vec<Image<u8>>)
+    return _read_to(_lib.READ_RGBA, buf, ctx)
+
+
+def read_to_etc1(buf, ctx=None):  # basis.rs:92-143
+    return _read_to(_lib.READ_ETC1, buf, ctx)[1]
+
+
+def read_to_etc2(buf, ctx=None):  # basis.rs:145-173
+    return _read_to(_lib.READ_ETC2, buf, ctx)[1]
+
+
+def read_to_uastc(buf, ctx=None):  # basis.rs:175-202
+    return _read_to(_lib.READ_UASTC, buf, ctx)[1]
+
+
+def read_to_astc(buf, ctx=None):  # basis.rs:204-231
+    return _read_to(_lib.READ_ASTC, buf, ctx)[1]
+
+
+def read_to_bc7(buf, ctx=None):  # basis.rs:233-260
+    return _read_to(_lib.READ_BC7, buf, ctx)[1]
+
+
+def basislz_decode(buf, slice_index=None):
+    """host-only BasisLZ decode of an ETC1S file -> (endpoints u32[n], selectors u8[n,8], idx u32[blocks] or None)"""
+    lib = _lib.load()
+    a = _as_u8(buf)
+    h = read_header(buf)
+    n = h.total_selectors  # reference quirk: both codebooks are sized by total_selectors (basis.rs:289-291)
+    ep = np.zeros(max(n, 1), dtype=np.uint32)
+    sel = np.zeros((max(n, 1), 8), dtype=np.uint8)
+    idx = None
+    iptr = None
+    if slice_index is not None:
+        sd = read_slice_descs(buf, h)[slice_index]
+        idx = np.zeros(max(sd.num_blocks_x * sd.num_blocks_y, 1), dtype=np.uint32)
+        iptr = idx.ctypes.data
+    _check_host(lib.bu_basislz_decode(a.ctypes.data, a.size, slice_index or 0, ep.ctypes.data, sel.ctypes.data, iptr))
+    if idx is not None:
+        idx = idx[: sd.num_blocks_x * sd.num_blocks_y]
+    return ep[:n], sel[:n], idx
+
+
+def write_uastc_file(slices, header_flags=0, tex_type=0):
+    """slices: list of dict(data=bytes-like, orig_w, orig_h, nbx, nby, image_index=0, level=0, flags=0) -> bytes of a .basis file"""
+    lib = _lib.load()
+    n = len(slices)
+    descs = (_lib.SliceDesc * max(n, 1))()
+    keep = [_as_u8(s["data"]) for s in slices]
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[k.ctypes.data for k in keep])
+    sizes = (ctypes.c_size_t * max(n, 1))(*[k.size for k in keep])
+    for i, s in enumerate(slices):
+        d = descs[i]
+        d.image_index, d.level_index, d.flags = s.get("image_index", 0), s.get("level", 0), s.get("flags", 0)
+        d.orig_width, d.orig_height, d.num_blocks_x, d.num_blocks_y = s["orig_w"], s["orig_h"], s["nbx"], s["nby"]
+    ln = ctypes.c_size_t(0)
+    _check_host(lib.bu_basis_write_uastc(descs, ptrs, sizes, n, header_flags, tex_type, None, 0, ctypes.byref(ln)))
+    out = np.empty(ln.value, dtype=np.uint8)
+    _check_host(lib.bu_basis_write_uastc(descs, ptrs, sizes, n, header_flags, tex_type, out.ctypes.data, out.size, ctypes.byref(ln)))
+    return out.tobytes()
+
+
 # ---- module-level mirror of the reference's free functions / Decoder --------------------------------
 _default_ctx = None
 

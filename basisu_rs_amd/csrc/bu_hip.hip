@@ -18,6 +18,7 @@
 #include <new>
 
 #include "../../include/basisu_hip.h"
+#include "bu_basis.hpp"
 #include "bu_uastc_dispatch.hpp"
 
 namespace {
@@ -564,6 +565,17 @@ const char* bu_status_string(bu_status st)
     case BU_ERR_INDEX_RANGE: return "ETC1S endpoint or selector index out of range";
     case BU_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
     case BU_ERR_HIP: return "HIP runtime error";
+    case BU_ERR_SIG: return "Sig mismatch, not a Basis Universal file";                                  // basis.rs:309
+    case BU_ERR_HEADER_TRUNCATED: return "Expected at least 77 byte header";                              // basis.rs:313
+    case BU_ERR_HEADER_SIZE: return "File specified unexpected header size, expected 77";                 // basis.rs:323
+    case BU_ERR_HEADER_CRC: return "Header CRC16 failed";                                                 // basis.rs:332
+    case BU_ERR_DATA_CRC: return "Data CRC16 failed";                                                     // basis.rs:12
+    case BU_ERR_TEX_FORMAT: return "Unknown texture format";                                              // basis.rs:404
+    case BU_ERR_SLICE_DESC: return "Expected 23 byte slice desc";                                         // basis.rs:350
+    case BU_ERR_ALPHA_SLICES: return "alpha slice layout is invalid (odd slice count, missing alpha flag or size mismatch)";  // basis.rs:19,29,34
+    case BU_ERR_UNSUPPORTED: return "not implemented for this texture format";                            // unimplemented!()
+    case BU_ERR_BASISLZ: return "BasisLZ stream is invalid";
+    case BU_ERR_BOUNDS: return "offset outside the file or invalid stream state";
     default: return "unknown status";
     }
 }
@@ -783,6 +795,249 @@ bu_status bu_etc1s_decode_rgba(bu_context* ctx, const uint32_t* idx, const uint3
 {
     if (nbx == 0 && nby != 0) return BU_ERR_ARGUMENT;
     return bu_etc1s_host(ctx, true, idx, alpha_idx, nbx, nby, endpoints, n_endpoints, selectors, n_selectors, out, out_bytes, first_bad_block);
+}
+
+// ---- whole-file level (basis.rs) --------------------------------------------------------------------
+bu_status bu_basis_read_header(const uint8_t* file, size_t len, bu_basis_header* out)
+{
+    if (!file || !out) return BU_ERR_ARGUMENT;
+    return bu_host::read_header(file, len, out);
+}
+
+bu_status bu_basis_read_slice_descs(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out, size_t max_descs,
+                                    size_t* n_descs)
+{
+    if (!file || !header) return BU_ERR_ARGUMENT;
+    std::vector<bu_slice_desc> v;
+    bu_status st = bu_host::read_slice_descs(file, len, header, v);
+    if (st) return st;
+    if (n_descs) *n_descs = v.size();
+    if (out) {
+        if (v.size() > max_descs) return BU_ERR_OUTPUT_SIZE;
+        for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+    }
+    return BU_OK;
+}
+
+uint16_t bu_basis_crc16(const uint8_t* data, size_t len, uint16_t crc) { return bu_host::crc16(data, len, crc); }
+
+namespace {
+
+struct BuFilePlan {
+    bu_basis_header h;
+    std::vector<bu_slice_desc> slices;
+    std::vector<bu_image> images;       // one per output image
+    std::vector<size_t> first_slice;    // slice feeding image i (its colour slice for RGBA+alpha)
+    size_t out_bytes = 0;
+    bool etc1s = false, alpha_pairs = false;
+};
+
+// everything of read_to_* that needs no block work: checks in the reference's order, image geometry
+bu_status bu_plan_file(bu_read_target target, const uint8_t* file, size_t len, BuFilePlan& p)
+{
+    if (!file) return BU_ERR_ARGUMENT;
+    if ((int)target < 0 || (int)target > 5) return BU_ERR_ARGUMENT;
+    bu_status st = bu_host::read_header(file, len, &p.h);
+    if (st) return st;
+    if (bu_host::crc16(file + 77, len - 77, 0) != p.h.data_crc16) return BU_ERR_DATA_CRC;  // to EOF, basis.rs:338-341
+    st = bu_host::read_slice_descs(file, len, &p.h, p.slices);
+    if (st) return st;
+    if (p.h.tex_format > 1) return BU_ERR_TEX_FORMAT;
+    p.etc1s = p.h.tex_format == 0;
+    const bool has_alpha = (p.h.flags & 4) != 0;
+    if (p.etc1s && !(target == BU_READ_RGBA || target == BU_READ_ETC1)) return BU_ERR_UNSUPPORTED;
+    if (p.etc1s && has_alpha && (p.slices.size() % 2) != 0) return BU_ERR_ALPHA_SLICES;
+    p.alpha_pairs = p.etc1s && has_alpha && target == BU_READ_RGBA;
+    for (size_t i = 0; i < p.slices.size(); i++) {
+        const bu_slice_desc& s = p.slices[i];
+        if (!bu_host::in_file(len, s.file_ofs, s.file_size)) return BU_ERR_BOUNDS;
+        if (p.alpha_pairs) {
+            if (i & 1) continue;
+            const bu_slice_desc& a = p.slices[i + 1];
+            if (!(a.flags & 1)) return BU_ERR_ALPHA_SLICES;
+            if (a.num_blocks_x != s.num_blocks_x || a.num_blocks_y != s.num_blocks_y) return BU_ERR_ALPHA_SLICES;
+        }
+        const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y, nb16 = s.file_size / 16;
+        bu_image im = {s.orig_width, s.orig_height, 0, 0, p.out_bytes, 0};
+        if (p.etc1s) {
+            if (target == BU_READ_RGBA) {
+                im.size = nblk * 64;
+                im.stride = 16u * s.orig_width;  // basis.rs:46,64 x4 (lib.rs:75): reference quirk, rows are 16*nbx apart
+            } else {
+                im.size = nblk * 8;
+                im.stride = 8u * s.num_blocks_x;
+            }
+        } else {
+            if (target != BU_READ_UASTC && s.file_size % 16) return BU_ERR_LENGTH;  // uastc.rs:54-59
+            switch (target) {
+            case BU_READ_RGBA:
+                if (s.num_blocks_x == 0 && nb16) return BU_ERR_BOUNDS;
+                if (s.num_blocks_x && nb16 % s.num_blocks_x) return BU_ERR_BOUNDS;  // the reference indexes past its image
+                im.size = nb16 * 64;
+                im.stride = 16u * s.num_blocks_x;
+                break;
+            case BU_READ_UASTC: im.size = s.file_size; im.stride = 16u * s.num_blocks_x; break;
+            case BU_READ_ETC1: im.size = nb16 * 8; im.stride = 8u * s.num_blocks_x; break;
+            default: im.size = nb16 * 16; im.stride = 16u * s.num_blocks_x; break;
+            }
+        }
+        p.images.push_back(im);
+        p.first_slice.push_back(i);
+        p.out_bytes += im.size;
+    }
+    return BU_OK;
+}
+
+bu_status bu_make_lz(const uint8_t* file, size_t len, const bu_basis_header& h, bu_host::BasisLz& lz)
+{
+    if (!bu_host::in_file(len, h.endpoint_cb_file_ofs, h.endpoint_cb_file_size) || !bu_host::in_file(len, h.selector_cb_file_ofs, h.selector_cb_file_size) ||
+        !bu_host::in_file(len, h.tables_file_ofs, h.tables_file_size) || !bu_host::in_file(len, h.extended_file_ofs, h.extended_file_size))
+        return BU_ERR_BOUNDS;
+    // total_selectors for both codebooks: basis.rs:289-291
+    return lz.init(h.total_selectors, h.total_selectors, file + h.endpoint_cb_file_ofs, h.endpoint_cb_file_size, file + h.selector_cb_file_ofs,
+                   h.selector_cb_file_size, file + h.tables_file_ofs, h.tables_file_size, h.tex_type == 3);
+}
+
+}  // namespace
+
+bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes)
+{
+    BuFilePlan p;
+    bu_status st = bu_plan_file(target, file, len, p);
+    if (st) return st;
+    if (n_images) *n_images = p.images.size();
+    if (out_bytes) *out_bytes = p.out_bytes;
+    return BU_OK;
+}
+
+bu_status bu_basislz_decode(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out, uint8_t* selectors_out,
+                            uint32_t* idx_out)
+{
+    if (!file) return BU_ERR_ARGUMENT;
+    bu_basis_header h;
+    bu_status st = bu_host::read_header(file, len, &h);
+    if (st) return st;
+    if (h.tex_format != 0) return BU_ERR_UNSUPPORTED;
+    std::vector<bu_slice_desc> slices;
+    st = bu_host::read_slice_descs(file, len, &h, slices);
+    if (st) return st;
+    bu_host::BasisLz lz;
+    st = bu_make_lz(file, len, h, lz);
+    if (st) return st;
+    if (endpoints_out) memcpy(endpoints_out, lz.endpoints.data(), lz.endpoints.size() * 4);
+    if (selectors_out) memcpy(selectors_out, lz.selectors.data(), lz.selectors.size());
+    if (idx_out) {
+        if (slice_index >= slices.size()) return BU_ERR_ARGUMENT;
+        const bu_slice_desc& s = slices[slice_index];
+        if (!bu_host::in_file(len, s.file_ofs, s.file_size)) return BU_ERR_BOUNDS;
+        st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, file + s.file_ofs, s.file_size, idx_out);
+    }
+    return st;
+}
+
+bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
+                     size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
+{
+    if (!ctx || !out) return BU_ERR_ARGUMENT;
+    BuFilePlan p;
+    bu_status st = bu_plan_file(target, file, len, p);
+    if (st) return st;
+    if (header_out) *header_out = p.h;
+    if (n_images) *n_images = p.images.size();
+    if (out_bytes < p.out_bytes) return BU_ERR_OUTPUT_SIZE;
+    if (images) {
+        if (p.images.size() > max_images) return BU_ERR_OUTPUT_SIZE;
+        for (size_t i = 0; i < p.images.size(); i++) images[i] = p.images[i];
+    }
+    bu_host::BasisLz lz;
+    if (p.etc1s) {
+        st = bu_make_lz(file, len, p.h, lz);
+        if (st) return st;
+    }
+    std::vector<uint32_t> idx, aidx;
+    for (size_t k = 0; k < p.images.size(); k++) {
+        const bu_slice_desc& s = p.slices[p.first_slice[k]];
+        const bu_image& im = p.images[k];
+        const uint8_t* data = file + s.file_ofs;
+        uint8_t* dst = out + im.offset;
+        uint64_t bad = 0;
+        if (p.etc1s) {
+            const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y;
+            idx.assign(nblk ? nblk : 1, 0);
+            st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, data, s.file_size, idx.data());
+            if (st) return st;
+            const uint32_t n_cb = (uint32_t)lz.endpoints.size();
+            if (target == BU_READ_RGBA) {
+                const uint32_t* ap = nullptr;
+                if (p.alpha_pairs) {
+                    const bu_slice_desc& a = p.slices[p.first_slice[k] + 1];
+                    aidx.assign(nblk ? nblk : 1, 0);
+                    st = lz.decode_slice(a.num_blocks_x, a.num_blocks_y, file + a.file_ofs, a.file_size, aidx.data());
+                    if (st) return st;
+                    ap = aidx.data();
+                }
+                st = bu_etc1s_decode_rgba(ctx, idx.data(), ap, s.num_blocks_x, s.num_blocks_y, lz.endpoints.data(), n_cb, lz.selectors.data(), n_cb,
+                                          dst, im.size, &bad);
+            } else {
+                st = bu_etc1s_transcode_etc1(ctx, idx.data(), nblk, lz.endpoints.data(), n_cb, lz.selectors.data(), n_cb, dst, im.size, &bad);
+            }
+        } else {
+            switch (target) {
+            case BU_READ_UASTC: memcpy(dst, data, s.file_size); st = BU_OK; break;  // uastc.rs:85-87
+            case BU_READ_RGBA: st = s.file_size ? bu_uastc_decode_to_rgba(ctx, data, s.file_size, s.num_blocks_x, dst, im.size, &bad) : BU_OK; break;
+            case BU_READ_ASTC: st = bu_uastc_transcode(ctx, BU_TARGET_ASTC, data, s.file_size, dst, im.size, &bad); break;
+            case BU_READ_BC7: st = bu_uastc_transcode(ctx, BU_TARGET_BC7, data, s.file_size, dst, im.size, &bad); break;
+            case BU_READ_ETC1: st = bu_uastc_transcode(ctx, BU_TARGET_ETC1, data, s.file_size, dst, im.size, &bad); break;
+            default: st = bu_uastc_transcode(ctx, BU_TARGET_ETC2, data, s.file_size, dst, im.size, &bad); break;
+            }
+        }
+        if (st) return st;  // first Err aborts the whole call, like the `?` in the reference drivers
+    }
+    return BU_OK;
+}
+
+bu_status bu_basis_write_uastc(const bu_slice_desc* descs, const uint8_t* const* slice_data, const size_t* slice_bytes, size_t n_slices,
+                               uint16_t header_flags, uint8_t tex_type, uint8_t* out, size_t out_cap, size_t* out_len)
+{
+    if ((n_slices && (!descs || !slice_data || !slice_bytes)) || n_slices >= (1u << 24)) return BU_ERR_ARGUMENT;
+    size_t total = 77 + 23 * n_slices;
+    for (size_t i = 0; i < n_slices; i++) total += slice_bytes[i];
+    if (out_len) *out_len = total;
+    if (!out) return BU_OK;
+    if (out_cap < total || total > 0xFFFFFFFFull) return BU_ERR_OUTPUT_SIZE;
+    auto put = [&](size_t pos, uint32_t v, int n) { for (int k = 0; k < n; k++) out[pos + k] = (uint8_t)(v >> (8 * k)); };
+    memset(out, 0, 77 + 23 * n_slices);
+    size_t ofs = 77 + 23 * n_slices;
+    uint32_t n_images = 0;
+    for (size_t i = 0; i < n_slices; i++) {
+        const size_t d = 77 + 23 * i;
+        put(d, descs[i].image_index, 3);
+        out[d + 3] = descs[i].level_index;
+        out[d + 4] = descs[i].flags;
+        put(d + 5, descs[i].orig_width, 2);
+        put(d + 7, descs[i].orig_height, 2);
+        put(d + 9, descs[i].num_blocks_x, 2);
+        put(d + 11, descs[i].num_blocks_y, 2);
+        put(d + 13, (uint32_t)ofs, 4);
+        put(d + 17, (uint32_t)slice_bytes[i], 4);
+        put(d + 21, bu_host::crc16(slice_data[i], slice_bytes[i], 0), 2);
+        if (slice_bytes[i]) memcpy(out + ofs, slice_data[i], slice_bytes[i]);
+        ofs += slice_bytes[i];
+        if (descs[i].image_index + 1 > n_images) n_images = descs[i].image_index + 1;
+    }
+    put(0, 0x4273, 2);   // sig
+    put(2, 0x13, 2);     // ver
+    put(4, 77, 2);       // header_size
+    put(8, (uint32_t)(total - 77), 4);
+    put(12, bu_host::crc16(out + 77, total - 77, 0), 2);
+    put(14, (uint32_t)n_slices, 3);
+    put(17, n_images, 3);
+    out[20] = 1;         // UASTC4x4
+    put(21, header_flags, 2);
+    out[23] = tex_type;
+    put(65, 77, 4);      // slice_desc_file_ofs
+    put(6, bu_host::crc16(out + 8, 77 - 8, 0), 2);
+    return BU_OK;
 }
 
 // ---- measurement helpers ---------------------------------------------------------------------------

@@ -210,6 +210,17 @@ def main():
                                    "mblocks_s": round(N_BLOCKS / coh_s / 1e6, 1), "verified": coh_ok,
                                    "note": "A-coh: UASTC mode chosen per 8x8-block tile"}
         del coh
+        # end-to-end row: host buffer -> host buffer through bu_uastc_transcode (H2D + kernel + D2H, PCIe-bound)
+        host_in = golden["uastc"][idx0]
+        ctx.transcode(_lib.BC7, host_in)
+        t0 = time.perf_counter()
+        e2e_reps = 5
+        for _ in range(e2e_reps):
+            host_out = ctx.transcode(_lib.BC7, host_in)
+        e2e_s = (time.perf_counter() - t0) / e2e_reps
+        extra["end_to_end_host_pointers"] = {"mblocks_s": round(N_BLOCKS / e2e_s / 1e6, 1), "ms_per_atlas": round(e2e_s * 1e3, 3),
+                                             "verified": bool((host_out.reshape(-1, 16) == golden["bc7"][idx0]).all()),
+                                             "note": "pageable host memory, includes PCIe both ways -- never the headline value"}
         # config 3: UASTC -> RGBA32 (16 B in, 64 B out)
         rg_n = min(nbuf, 16)
         rg_out = [torch.empty((N_BLOCKS, 64), dtype=torch.uint8, device=dev) for _ in range(rg_n)]

@@ -47,7 +47,19 @@ typedef enum bu_status {
     BU_ERR_ARGUMENT = 5,        /* null pointer / unknown target / blocks_per_row == 0 */
     BU_ERR_INDEX_RANGE = 6,     /* ETC1S endpoint/selector index outside the codebook (reference: assert!, basis_lz/mod.rs:443-445) */
     BU_ERR_NO_DEVICE = 7,       /* no HIP device / not gfx950 */
-    BU_ERR_HIP = 8              /* a HIP runtime call failed; see bu_last_error() */
+    BU_ERR_HIP = 8,             /* a HIP runtime call failed; see bu_last_error() */
+    /* container / BasisLZ (host side) */
+    BU_ERR_SIG = 9,               /* "Sig mismatch, not a Basis Universal file"            basis.rs:309 */
+    BU_ERR_HEADER_TRUNCATED = 10, /* "Expected at least 77 byte header, got N bytes"       basis.rs:313 */
+    BU_ERR_HEADER_SIZE = 11,      /* "File specified unexpected header size, ..."          basis.rs:323 */
+    BU_ERR_HEADER_CRC = 12,       /* "Header CRC16 failed"                                 basis.rs:332 */
+    BU_ERR_DATA_CRC = 13,         /* "Data CRC16 failed"                                   basis.rs:12  */
+    BU_ERR_TEX_FORMAT = 14,       /* "Unknown texture format"                              basis.rs:404 */
+    BU_ERR_SLICE_DESC = 15,       /* "Expected 23 byte slice desc at pos ..."              basis.rs:350 */
+    BU_ERR_ALPHA_SLICES = 16,     /* odd slice count / "Expected slice with alpha" / size mismatch  basis.rs:19,29,34 */
+    BU_ERR_UNSUPPORTED = 17,      /* format/target pair the reference answers with unimplemented!() basis.rs:88,141,171,200,229,258 */
+    BU_ERR_BASISLZ = 18,          /* any Err of basis_lz (bad Huffman table / code, global or hybrid selector codebook) */
+    BU_ERR_BOUNDS = 19            /* offsets outside the file, or a condition the reference asserts/panics on */
 } bu_status;
 
 typedef struct bu_context bu_context;
@@ -134,6 +146,77 @@ bu_status bu_etc1s_transcode_etc1(bu_context* ctx, const uint32_t* idx, size_t n
 bu_status bu_etc1s_decode_rgba(bu_context* ctx, const uint32_t* idx, const uint32_t* alpha_idx, size_t nbx, size_t nby,
                                const uint32_t* endpoints, uint32_t n_endpoints, const uint8_t* selectors,
                                uint32_t n_selectors, uint8_t* out, size_t out_bytes, uint64_t* first_bad_block);
+
+/* ---- whole-file level: the crate's public read_to_* API (src/lib.rs:20-22, src/basis.rs) -------------
+ * Host side in C++ (container parse, CRC-16, BasisLZ entropy decode -- byte/symbol serial, stays on the CPU),
+ * block work on the GPU through the entry points above. */
+
+/* basis::Header (basis.rs:417-454), same 26 public fields */
+typedef struct bu_basis_header {
+    uint16_t sig, ver, header_size, header_crc16;
+    uint32_t data_size;
+    uint16_t data_crc16;
+    uint32_t total_slices, total_images; /* u24 in the file */
+    uint8_t tex_format;                  /* 0 ETC1S, 1 UASTC4x4 (basis.rs:389-407) */
+    uint16_t flags;                      /* 1 ETC1S, 2 YFlipped, 4 HasAlphaSlices (basis.rs:409-415) */
+    uint8_t tex_type;                    /* 3 = video frames (basis.rs:374-381) */
+    uint32_t us_per_frame, reserved, userdata0, userdata1;
+    uint16_t total_endpoints;
+    uint32_t endpoint_cb_file_ofs, endpoint_cb_file_size;
+    uint16_t total_selectors;
+    uint32_t selector_cb_file_ofs, selector_cb_file_size;
+    uint32_t tables_file_ofs, tables_file_size, slice_desc_file_ofs, extended_file_ofs, extended_file_size;
+} bu_basis_header;
+
+/* basis::SliceDesc (basis.rs:519-535) */
+typedef struct bu_slice_desc {
+    uint32_t image_index; /* u24 */
+    uint8_t level_index, flags; /* flags: 1 HasAlpha, 2 FrameIsIFrame */
+    uint16_t orig_width, orig_height, num_blocks_x, num_blocks_y;
+    uint32_t file_ofs, file_size;
+    uint16_t slice_data_crc16;
+} bu_slice_desc;
+
+/* Image<u8> (lib.rs:63-68): data = out + offset, `size` bytes; stride as the reference reports it */
+typedef struct bu_image {
+    uint32_t w, h, stride, reserved;
+    uint64_t offset, size;
+} bu_image;
+
+typedef enum bu_read_target {
+    BU_READ_RGBA = 0, /* read_to_rgba  basis.rs:8   */
+    BU_READ_ETC1 = 1, /* read_to_etc1  basis.rs:92  */
+    BU_READ_ETC2 = 2, /* read_to_etc2  basis.rs:145 */
+    BU_READ_UASTC = 3, /* read_to_uastc basis.rs:175 */
+    BU_READ_ASTC = 4, /* read_to_astc  basis.rs:204 */
+    BU_READ_BC7 = 5   /* read_to_bc7   basis.rs:233 */
+} bu_read_target;
+
+/* read_header (basis.rs:307-336): signature, size, header_size == 77, header CRC */
+bu_status bu_basis_read_header(const uint8_t* file, size_t len, bu_basis_header* out);
+/* read_slice_descs (basis.rs:343-362) */
+bu_status bu_basis_read_slice_descs(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out,
+                                    size_t max_descs, size_t* n_descs);
+/* crc16 (basis.rs:364-372): CRC-16/GENIBUS continued from `crc` */
+uint16_t bu_basis_crc16(const uint8_t* data, size_t len, uint16_t crc);
+/* number of images and output bytes bu_read_to() will produce for this file (no GPU work) */
+bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes);
+/* read_to_{rgba,etc1,etc2,uastc,astc,bc7}: every slice of the file (every colour/alpha pair for RGBA from an
+ * ETC1S file with alpha) becomes one bu_image whose bytes are written to `out`.  header_out may be NULL.
+ * Reference quirks are reproduced: the data CRC covers bytes[77..EOF]; total_selectors sizes BOTH ETC1S
+ * codebooks (basis.rs:289-291); ETC1S RGBA images report stride 16*orig_width (basis.rs:46,64). */
+bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out,
+                     bu_image* images, size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes);
+/* Host-only BasisLZ decode of an ETC1S file (basis_lz/mod.rs:64-95, 188-458): the two codebooks in the layouts
+ * the bu_etc1s_* entry points take, and the per-block indices of slice `slice_index`.  Any pointer may be NULL. */
+bu_status bu_basislz_decode(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out,
+                            uint8_t* selectors_out, uint32_t* idx_out);
+/* Writer: assemble a UASTC `.basis` file (header + slice descs + slice data, CRCs filled).  descs[i] supplies
+ * image_index, level_index, flags, orig_*, num_blocks_*; file_ofs/file_size/crc are computed.  With out == NULL
+ * only *out_len is set. */
+bu_status bu_basis_write_uastc(const bu_slice_desc* descs, const uint8_t* const* slice_data, const size_t* slice_bytes,
+                               size_t n_slices, uint16_t header_flags, uint8_t tex_type, uint8_t* out, size_t out_cap,
+                               size_t* out_len);
 
 /* ---- measurement helpers (bench.py) ------------------------------------------------------------
  * uint4 -> uint4 copy kernel of the same launch shape as the 16 B -> 16 B transcoders: the practical

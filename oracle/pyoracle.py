@@ -43,6 +43,51 @@ class Oracle:
             getattr(L, n).restype = c.c_uint64
         L.bu_oracle_prove_unique_pbits.argtypes = [c.c_uint, c.c_uint, c.c_uint64, c.c_uint64]
 
+    # ---- container / BasisLZ half (bu_oracle_basis.c) ----
+    READ = {"rgba": 0, "etc1": 1, "etc2": 2, "uastc": 3, "astc": 4, "bc7": 5}
+
+    def crc16(self, data, crc=0):
+        self.lib.bu_oracle_crc16.restype = ctypes.c_uint16
+        self.lib.bu_oracle_crc16.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint16]
+        return self.lib.bu_oracle_crc16(bytes(data), len(data), crc)
+
+    def header_from_bytes(self, data):
+        out = (ctypes.c_uint32 * 26)()
+        self.lib.bu_oracle_header_from_bytes(bytes(data), out)
+        return list(out)
+
+    def read_to(self, which, data):
+        """-> (status, header[26], [(w, h, stride, bytes)...])"""
+        class Img(ctypes.Structure):
+            _fields_ = [("w", ctypes.c_uint32), ("h", ctypes.c_uint32), ("stride", ctypes.c_uint32), ("offset", ctypes.c_uint64), ("size", ctypes.c_uint64)]
+
+        data = bytes(data)
+        L = self.lib
+        L.bu_oracle_read_to.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        hdr = (ctypes.c_uint32 * 26)()
+        n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        st = L.bu_oracle_read_to(self.READ[which], data, len(data), hdr, None, 0, ctypes.byref(n), None, 0, ctypes.byref(nb))
+        if st:
+            return st, list(hdr), []
+        imgs = (Img * max(n.value, 1))()
+        out = np.zeros(max(nb.value, 1), dtype=np.uint8)
+        st = L.bu_oracle_read_to(self.READ[which], data, len(data), hdr, imgs, n.value, ctypes.byref(n), out.ctypes.data, out.size, ctypes.byref(nb))
+        res = [(im.w, im.h, im.stride, out[im.offset:im.offset + im.size].copy()) for im in imgs[: n.value]]
+        return st, list(hdr), res
+
+    def lz_decode(self, ecb, scb, tables, n_ep, n_sel, is_video, slice_bytes, nbx, nby):
+        L = self.lib
+        L.bu_oracle_lz_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                          ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t,
+                                          ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        ep = np.zeros(n_ep * 4, dtype=np.uint8)
+        sel = np.zeros(n_sel * 8, dtype=np.uint8)
+        idx = np.zeros(nbx * nby * 2, dtype=np.uint16)
+        st = L.bu_oracle_lz_decode(ecb, len(ecb), scb, len(scb), tables, len(tables), n_ep, n_sel, int(is_video), slice_bytes, len(slice_bytes),
+                                   nbx, nby, ep.ctypes.data, sel.ctypes.data, idx.ctypes.data)
+        return st, ep.view("<u4"), sel.reshape(-1, 8), idx.reshape(-1, 2)
+
     def batch(self, target, blocks):
         """blocks [n,16] uint8 -> (out [n,bytes], status [n])"""
         t, obs = TARGETS[target]

@@ -1,0 +1,427 @@
+"""TEST-ONLY builder of `.basis` files (UASTC and ETC1S/BasisLZ) for the container / BasisLZ tests and the
+config-4 path.  It writes the bitstream the reference *reads* (src/basis.rs:417-572,
+src/basis_lz/huffman.rs:43-184, src/basis_lz/mod.rs:188-608).  It makes random but always-valid symbol
+choices; what the symbols decode to is established by the oracle, and the product must agree with it.
+"""
+import heapq
+import struct
+
+import numpy as np
+
+
+class BitWriter:
+    """LSB-first bit writer (the reader is src/bitreader.rs)"""
+
+    def __init__(self):
+        self.acc = 0
+        self.n = 0
+        self.out = bytearray()
+
+    def put(self, value, bits):
+        assert 0 <= value < (1 << bits) or bits == 0
+        self.acc |= value << self.n
+        self.n += bits
+        while self.n >= 8:
+            self.out.append(self.acc & 0xFF)
+            self.acc >>= 8
+            self.n -= 8
+
+    def bytes(self):
+        out = bytearray(self.out)
+        if self.n:
+            out.append(self.acc & 0xFF)
+        return bytes(out)
+
+
+def crc16(data, crc=0):
+    """CRC-16/GENIBUS (basis.rs:364-372), table-free like the reference"""
+    crc = (~crc) & 0xFFFF
+    for b in data:
+        q = (b ^ (crc >> 8)) & 0xFFFF
+        k = ((q >> 4) ^ q) & 0xFFFF
+        crc = (((crc << 8) ^ k) ^ (k << 5) ^ (k << 12)) & 0xFFFF
+    return (~crc) & 0xFFFF
+
+
+def huffman_lengths(freqs, max_len=16):
+    """code length per symbol (0 = unused); falls back to fixed-length codes if Huffman exceeds max_len"""
+    used = [i for i, f in enumerate(freqs) if f > 0]
+    lengths = [0] * len(freqs)
+    if len(used) == 1:
+        lengths[used[0]] = 1
+        return lengths
+    heap = [(freqs[i], i, (i,)) for i in used]
+    heapq.heapify(heap)
+    depth = {i: 0 for i in used}
+    uid = len(freqs)
+    while len(heap) > 1:
+        fa, _, a = heapq.heappop(heap)
+        fb, _, b = heapq.heappop(heap)
+        for s in a + b:
+            depth[s] += 1
+        heapq.heappush(heap, (fa + fb, uid, a + b))
+        uid += 1
+    if max(depth.values()) > max_len:
+        fixed = max(1, (len(used) - 1).bit_length())
+        for i in used:
+            lengths[i] = fixed
+    else:
+        for i in used:
+            lengths[i] = depth[i]
+    return lengths
+
+
+def canonical_codes(lengths):
+    """symbol -> code as written LSB-first (bit-reversed canonical code, huffman.rs:133-184)"""
+    count = [0] * 18
+    for ln in lengths:
+        count[ln] += 1
+    count[0] = 0
+    next_code = [0] * 18
+    total = 0
+    for bits in range(1, 17):
+        total = (total + count[bits - 1]) << 1
+        next_code[bits] = total
+    codes = {}
+    for sym, ln in enumerate(lengths):
+        if ln:
+            c = next_code[ln]
+            next_code[ln] += 1
+            codes[sym] = int(format(c, "0%db" % ln)[::-1], 2)
+    return codes
+
+
+class Coder:
+    def __init__(self, lengths):
+        self.lengths = lengths
+        self.codes = canonical_codes(lengths)
+
+    def put(self, bw, sym):
+        assert self.lengths[sym] > 0, "symbol %d has no code" % sym
+        bw.put(self.codes[sym], self.lengths[sym])
+
+
+CL_ORDER = [17, 18, 19, 20, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 16]
+
+
+def write_huffman_table(bw, lengths, use_runs=True):
+    """Huffman table record (huffman.rs:43-118): symbol code sizes, themselves coded with the 21-symbol alphabet"""
+    n = len(lengths)
+    while n > 1 and lengths[n - 1] == 0:
+        n -= 1
+    lengths = lengths[:n]
+    # tokenise with zero runs (17: 3-10, 18: 11-138) and repeats (19: 3-6, 20: 7-134)
+    toks = []
+    i = 0
+    while i < n:
+        v = lengths[i]
+        j = i
+        while j < n and lengths[j] == v:
+            j += 1
+        run = j - i
+        if use_runs and v == 0 and run >= 3:
+            take = min(run, 138)
+            toks.append((18, take - 11, 7) if take >= 11 else (17, take - 3, 3))
+            i += take
+        elif use_runs and v != 0 and run >= 4:
+            toks.append((v, None, 0))
+            take = min(run - 1, 134)
+            toks.append((20, take - 7, 7) if take >= 7 else (19, take - 3, 2))
+            i += 1 + take
+        else:
+            toks.append((v, None, 0))
+            i += 1
+    freq = [0] * 21
+    for t, _, _ in toks:
+        freq[t] += 1
+    cl_len = huffman_lengths(freq, max_len=7)
+    cl = Coder(cl_len)
+    bw.put(n, 14)
+    ncl = 21
+    while ncl > 1 and cl_len[CL_ORDER[ncl - 1]] == 0:
+        ncl -= 1
+    bw.put(ncl, 5)
+    for k in range(ncl):
+        bw.put(cl_len[CL_ORDER[k]], 3)
+    for t, extra, ebits in toks:
+        cl.put(bw, t)
+        if extra is not None:
+            bw.put(extra, ebits)
+
+
+def vlc(bw, v, chunk_bits):
+    """mod.rs:585-608"""
+    while True:
+        chunk = v & ((1 << chunk_bits) - 1)
+        v >>= chunk_bits
+        bw.put(chunk | ((1 << chunk_bits) if v else 0), chunk_bits + 1)
+        if not v:
+            break
+
+
+def model_for(prev):
+    return 0 if prev <= 9 else (1 if prev <= 21 else 2)
+
+
+def encode_endpoints(endpoints_u32, grayscale=False):
+    """endpoint codebook section (mod.rs:461-516); endpoints r5|g5<<8|b5<<16|inten<<24"""
+    ep = np.asarray(endpoints_u32, dtype=np.uint32)
+    syms = [[], [], [], []]  # colour delta models 0..2, intensity
+    prev = [16, 16, 16]
+    prev_i = 0
+    plan = []
+    for e in ep:
+        inten = int(e >> 24) & 7
+        plan.append((3, (inten - prev_i) & 7))
+        prev_i = inten
+        for c in range(1 if grayscale else 3):
+            v = int(e >> (8 * c)) & 31
+            m = model_for(prev[c])
+            plan.append((m, (v - prev[c]) & 31))
+            prev[c] = v
+    freqs = [[0] * 32, [0] * 32, [0] * 32, [0] * 8]
+    for m, s in plan:
+        freqs[m][s] += 1
+    bw = BitWriter()
+    coders = []
+    for m in range(4):
+        if sum(freqs[m]) == 0:
+            freqs[m][0] = 1
+        ln = huffman_lengths(freqs[m])
+        coders.append(Coder(ln))
+        write_huffman_table(bw, ln)
+    bw.put(1 if grayscale else 0, 1)
+    for m, s in plan:
+        coders[m].put(bw, s)
+    return bw.bytes()
+
+
+def encode_selectors(rows, raw=True):
+    """selector codebook section (mod.rs:524-583); rows [n,4] bytes"""
+    rows = np.asarray(rows, dtype=np.uint8).reshape(-1, 4)
+    bw = BitWriter()
+    bw.put(0, 1)
+    bw.put(0, 1)
+    bw.put(1 if raw else 0, 1)
+    if raw:
+        for r in rows:
+            for y in range(4):
+                bw.put(int(r[y]), 8)
+    else:
+        deltas = []
+        prev = [0, 0, 0, 0]
+        for i, r in enumerate(rows):
+            for y in range(4):
+                if i:
+                    deltas.append(int(r[y]) ^ prev[y])
+                prev[y] = int(r[y])
+        freq = [0] * 256
+        for d in deltas:
+            freq[d] += 1
+        if not deltas:
+            freq[0] = 1
+        ln = huffman_lengths(freq)
+        coder = Coder(ln)
+        write_huffman_table(bw, ln)
+        for y in range(4):
+            bw.put(int(rows[0][y]), 8)
+        for d in deltas:
+            coder.put(bw, d)
+    return bw.bytes()
+
+
+class SliceSymbols:
+    """random valid symbol stream of one slice (mod.rs:188-458), recorded first so code lengths can be fitted"""
+
+    def __init__(self, rng, nbx, nby, n_endpoints, n_selectors, history_size, is_video=False, p_repeat=0.15, p_history=0.25, p_rle=0.05):
+        self.ops = []  # (table, symbol) or ("vlc", value, bits)
+        T_PRED, T_DELTA, T_SEL, T_RLE = 0, 1, 2, 3
+        prev_sym = 0
+        repeat = 0
+        sel_rle = 0
+        row_bits = [0] * nbx  # pred bits saved for the odd row below
+
+        def valid_pred(p, x, y):
+            if p == 0:
+                return x > 0
+            if p == 1:
+                return y > 0
+            if p == 2:
+                return True if is_video else (x > 0 and y > 0)
+            return True
+
+        def group_ok(sym, x, y):
+            for k, (dx, dy) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+                if x + dx < nbx and y + dy < nby and not valid_pred((sym >> (2 * k)) & 3, x + dx, y + dy):
+                    return False
+            return True
+
+        cur_bits = 0
+        for y in range(nby):
+            for x in range(nbx):
+                if x % 2 == 0:
+                    if y % 2 == 0:
+                        if repeat:
+                            repeat -= 1
+                            cur_bits = prev_sym
+                        else:
+                            # how many upcoming groups (raster order over even rows) accept prev_sym?
+                            run = 0
+                            gx, gy = x, y
+                            while run < 40 and gy < nby and group_ok(prev_sym, gx, gy):
+                                run += 1
+                                gx += 2
+                                if gx >= nbx:
+                                    gx, gy = 0, gy + 2
+                            if run >= 3 and rng.random() < p_repeat:
+                                count = int(rng.integers(3, run + 1))
+                                self.ops.append((T_PRED, 256))
+                                self.ops.append(("vlc", count - 3, 4))
+                                repeat = count - 1
+                                cur_bits = prev_sym
+                            else:
+                                while True:
+                                    sym = int(rng.integers(0, 256)) if rng.random() < 0.7 else 255
+                                    if group_ok(sym, x, y):
+                                        break
+                                self.ops.append((T_PRED, sym))
+                                cur_bits = sym
+                                prev_sym = sym
+                        row_bits[x] = cur_bits >> 4
+                    else:
+                        cur_bits = row_bits[x]
+                pred = cur_bits & 3
+                cur_bits >>= 2
+                if pred == 3:
+                    self.ops.append((T_DELTA, int(rng.integers(0, n_endpoints))))
+                if (not is_video) or pred != 2:
+                    if sel_rle:
+                        sel_rle -= 1
+                    else:
+                        u = rng.random()
+                        if history_size > 0 and u < p_rle:
+                            self.ops.append((T_SEL, n_selectors + history_size))
+                            if rng.random() < 0.2:
+                                extra = int(rng.integers(0, 300))
+                                self.ops.append((T_RLE, 63))
+                                self.ops.append(("vlc", extra, 7))
+                                sel_rle = 3 + extra - 1
+                            else:
+                                run_sym = int(rng.integers(0, 63))
+                                self.ops.append((T_RLE, run_sym))
+                                sel_rle = 3 + run_sym - 1
+                        elif history_size > 0 and u < p_rle + p_history:
+                            self.ops.append((T_SEL, n_selectors + int(rng.integers(0, history_size))))
+                        else:
+                            self.ops.append((T_SEL, int(rng.integers(0, n_selectors))))
+
+
+def encode_etc1s_payload(rng, slices_dims, n_endpoints, n_selectors, history_size=32, is_video=False):
+    """-> (tables_bytes, [slice_bytes...]) for slices of the given (nbx, nby)"""
+    streams = [SliceSymbols(rng, nbx, nby, n_endpoints, n_selectors, history_size, is_video) for nbx, nby in slices_dims]
+    sizes = [257, n_endpoints, n_selectors + history_size + 1, 64]
+    freqs = [[0] * s for s in sizes]
+    for st in streams:
+        for op in st.ops:
+            if op[0] != "vlc":
+                freqs[op[0]][op[1]] += 1
+    coders = []
+    bw = BitWriter()
+    for f in freqs:
+        if sum(f) == 0:
+            f[0] = 1
+        ln = huffman_lengths(f)
+        coders.append(Coder(ln))
+        write_huffman_table(bw, ln)
+    bw.put(history_size, 13)
+    tables = bw.bytes()
+    out = []
+    for st in streams:
+        b = BitWriter()
+        for op in st.ops:
+            if op[0] == "vlc":
+                vlc(b, op[1], op[2])
+            else:
+                coders[op[0]].put(b, op[1])
+        out.append(b.bytes())
+    return tables, out
+
+
+def build_basis_file(tex_format, slices, flags=0, tex_type=0, total_endpoints=0, endpoint_cb=b"", total_selectors=0, selector_cb=b"",
+                     tables=b"", total_images=None, corrupt=None):
+    """slices: list of dict(data=bytes, orig_w, orig_h, nbx, nby, image_index=0, level=0, flags=0).
+    Layout: header (77) | slice descs (23 each) | endpoint cb | selector cb | tables | slice data"""
+    n = len(slices)
+    ofs = 77 + 23 * n
+    ep_ofs = ofs
+    ofs += len(endpoint_cb)
+    sel_ofs = ofs
+    ofs += len(selector_cb)
+    tab_ofs = ofs
+    ofs += len(tables)
+    descs = bytearray()
+    body = bytearray()
+    for s in slices:
+        d = s["data"]
+        descs += struct.pack("<I", s.get("image_index", 0))[:3] + struct.pack("<BBHHHHIIH", s.get("level", 0), s.get("flags", 0), s["orig_w"],
+                                                                               s["orig_h"], s["nbx"], s["nby"], ofs + len(body), len(d),
+                                                                               crc16(d))
+        body += d
+    payload = bytes(descs) + endpoint_cb + selector_cb + tables + bytes(body)
+    hdr = bytearray(77)
+    struct.pack_into("<HHH", hdr, 0, 0x4273, 0x13, 77)
+    struct.pack_into("<I", hdr, 8, len(payload))
+    struct.pack_into("<H", hdr, 12, crc16(payload))
+    hdr[14:17] = struct.pack("<I", n)[:3]
+    hdr[17:20] = struct.pack("<I", total_images if total_images is not None else n)[:3]
+    hdr[20] = tex_format
+    struct.pack_into("<H", hdr, 21, flags)
+    hdr[23] = tex_type
+    struct.pack_into("<H", hdr, 39, total_endpoints)
+    struct.pack_into("<I", hdr, 41, ep_ofs if endpoint_cb else 0)
+    hdr[45:48] = struct.pack("<I", len(endpoint_cb))[:3]
+    struct.pack_into("<H", hdr, 48, total_selectors)
+    struct.pack_into("<I", hdr, 50, sel_ofs if selector_cb else 0)
+    hdr[54:57] = struct.pack("<I", len(selector_cb))[:3]
+    struct.pack_into("<I", hdr, 57, tab_ofs if tables else 0)
+    struct.pack_into("<I", hdr, 61, len(tables))
+    struct.pack_into("<I", hdr, 65, 77)
+    if corrupt == "header_size":
+        struct.pack_into("<H", hdr, 4, 78)
+    struct.pack_into("<H", hdr, 6, crc16(bytes(hdr[8:77])))
+    out = bytearray(hdr) + payload
+    if corrupt == "sig":
+        out[0] ^= 1
+    elif corrupt == "header_crc":
+        out[30] ^= 0x40
+    elif corrupt == "data_crc":
+        out[-1] ^= 0x01
+    return bytes(out)
+
+
+def uastc_file(block_arrays, dims, **kw):
+    """block_arrays: list of [n,16] uint8; dims: list of (nbx, nby)"""
+    slices = [dict(data=np.ascontiguousarray(b, dtype=np.uint8).tobytes(), orig_w=4 * nbx - 1 if nbx else 0, orig_h=4 * nby - 2 if nby else 0, nbx=nbx,
+                   nby=nby, image_index=i) for i, (b, (nbx, nby)) in enumerate(zip(block_arrays, dims))]
+    return build_basis_file(1, slices, **kw)
+
+
+def etc1s_file(rng, dims, n_codebook=256, history_size=32, alpha=False, raw_selectors=True, is_video=False, grayscale=False):
+    """random ETC1S file; total_endpoints == total_selectors (the reference passes total_selectors for both,
+    basis.rs:289-291).  With alpha, slices alternate colour / alpha."""
+    from basisu_rs_amd import synth
+
+    ep, rows = synth.etc1s_codebooks(n_codebook, n_codebook, seed=int(rng.integers(0, 1 << 30)))
+    if grayscale:
+        ep = (ep & 0xFF0000FF) | ((ep & 0xFF) << 8) | ((ep & 0xFF) << 16)
+    ecb = encode_endpoints(ep, grayscale)
+    scb = encode_selectors(rows, raw=raw_selectors)
+    all_dims = [d for d in dims for _ in range(2 if alpha else 1)]
+    tables, datas = encode_etc1s_payload(rng, all_dims, n_codebook, n_codebook, history_size, is_video)
+    slices = []
+    for i, ((nbx, nby), d) in enumerate(zip(all_dims, datas)):
+        is_a = alpha and (i & 1)
+        slices.append(dict(data=d, orig_w=4 * nbx, orig_h=4 * nby, nbx=nbx, nby=nby, image_index=i // (2 if alpha else 1), flags=1 if is_a else 0))
+    flags = 1 | (4 if alpha else 0)
+    return build_basis_file(0, slices, flags=flags, tex_type=3 if is_video else 0, total_endpoints=n_codebook, endpoint_cb=ecb,
+                            total_selectors=n_codebook, selector_cb=scb, tables=tables, total_images=len(dims)), ep, rows

@@ -1,0 +1,165 @@
+"""Host side of the drop-in (container parse, CRC-16, BasisLZ decode, UASTC file writer) against the oracle.
+No GPU needed: these entry points are pure host code of the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import basis_builder as bb  # noqa: E402
+import basisu_rs_amd as bu  # noqa: E402
+from basisu_rs_amd import _lib, synth  # noqa: E402
+
+
+def _le(*b):
+    return sum(v << (8 * i) for i, v in enumerate(b))
+
+
+# the reference's own unit test (basis.rs:578-620): bytes 0..76 -> header fields
+HEADER_VECTOR = [_le(0, 1), _le(2, 3), _le(4, 5), _le(6, 7), _le(8, 9, 10, 11), _le(12, 13), _le(14, 15, 16), _le(17, 18, 19), 20, _le(21, 22), 23,
+                 _le(24, 25, 26), _le(27, 28, 29, 30), _le(31, 32, 33, 34), _le(35, 36, 37, 38), _le(39, 40), _le(41, 42, 43, 44), _le(45, 46, 47),
+                 _le(48, 49), _le(50, 51, 52, 53), _le(54, 55, 56), _le(57, 58, 59, 60), _le(61, 62, 63, 64), _le(65, 66, 67, 68), _le(69, 70, 71, 72),
+                 _le(73, 74, 75, 76)]
+
+
+def test_header_layout_matches_the_reference_unit_test(oracle):
+    raw = bytearray(range(77))
+    assert oracle.header_from_bytes(bytes(raw)) == HEADER_VECTOR
+    # product: make the vector pass read_header's checks without touching the fields under test
+    raw[0:2] = b"\x73\x42"
+    raw[4:6] = (77).to_bytes(2, "little")
+    raw[6:8] = bb.crc16(bytes(raw[8:77])).to_bytes(2, "little")
+    got = bu.read_header(bytes(raw)).as_list()
+    want = list(HEADER_VECTOR)
+    want[0], want[2], want[3] = 0x4273, 77, bb.crc16(bytes(raw[8:77]))
+    assert got == want
+
+
+def test_crc16_is_genibus(oracle):
+    assert oracle.crc16(b"123456789") == 0xD64E  # published check value of CRC-16/GENIBUS (basis.rs:422 names it)
+    assert bu.crc16(b"123456789") == 0xD64E
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 77, 1000, 65537):
+        d = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert bu.crc16(d) == oracle.crc16(d)
+    d = rng.integers(0, 256, size=999, dtype=np.uint8).tobytes()
+    # the `crc` argument continues a previous result (the ~ at entry undoes the ~ at exit), as in the reference
+    assert bu.crc16(d[500:], bu.crc16(d[:500])) == bu.crc16(d) == oracle.crc16(d[500:], oracle.crc16(d[:500]))
+
+
+def test_container_errors_match_oracle(oracle, golden):
+    blocks = [golden["uastc"][synth.gold_indices(12, seed=1)]]
+    lib = _lib.load()
+    import ctypes
+
+    def product_status(f, target=_lib.READ_BC7):
+        a = np.frombuffer(f, dtype=np.uint8)
+        n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        return lib.bu_read_query(target, a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb))
+
+    for corrupt, want in (("sig", _lib.OK + 9), ("header_crc", 12), ("data_crc", 13), ("header_size", 11), (None, 0)):
+        f = bb.uastc_file(blocks, [(4, 3)], corrupt=corrupt)
+        assert oracle.read_to("bc7", f)[0] == want
+        assert product_status(f) == want
+    f = bb.uastc_file(blocks, [(4, 3)])
+    assert product_status(f[:50]) == oracle.read_to("bc7", f[:50])[0] == 10  # truncated header
+    assert product_status(b"") == oracle.read_to("bc7", b"")[0] == 9
+    # unknown texture format / unsupported target for ETC1S
+    g = bytearray(f)
+    g[20] = 7
+    g[6:8] = bb.crc16(bytes(g[8:77])).to_bytes(2, "little")
+    assert product_status(bytes(g)) == oracle.read_to("bc7", bytes(g))[0] == 14
+    e, _, _ = bb.etc1s_file(np.random.default_rng(1), [(4, 4)], n_codebook=32)
+    assert product_status(e, _lib.READ_BC7) == oracle.read_to("bc7", e)[0] == 17
+    assert product_status(e, _lib.READ_ETC1) == 0
+    # slice length not a multiple of 16
+    bad = bb.build_basis_file(1, [dict(data=bytes(40), orig_w=8, orig_h=4, nbx=2, nby=1)])
+    assert product_status(bad) == oracle.read_to("bc7", bad)[0] == 3
+    assert product_status(bad, _lib.READ_UASTC) == oracle.read_to("uastc", bad)[0] == 0
+
+
+def test_read_query_geometry_matches_oracle(oracle, golden):
+    dims = [(8, 4), (3, 5), (16, 16), (1, 1)]
+    blocks = [golden["uastc"][synth.gold_indices(x * y, seed=i)] for i, (x, y) in enumerate(dims)]
+    f = bb.uastc_file(blocks, dims)
+    lib = _lib.load()
+    import ctypes
+
+    a = np.frombuffer(f, dtype=np.uint8)
+    for name, t in (("rgba", 0), ("etc1", 1), ("etc2", 2), ("uastc", 3), ("astc", 4), ("bc7", 5)):
+        st, _, imgs = oracle.read_to(name, f)
+        n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert lib.bu_read_query(t, a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb)) == st == 0
+        assert n.value == len(imgs) and nb.value == sum(len(d) for _, _, _, d in imgs)
+    sd = bu.read_slice_descs(f)
+    assert [(s.num_blocks_x, s.num_blocks_y, s.orig_width, s.orig_height) for s in sd] == [(x, y, 4 * x - 1, 4 * y - 2) for x, y in dims]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(alpha=True), dict(raw_selectors=False), dict(is_video=True), dict(grayscale=True),
+                                dict(history_size=0), dict(history_size=1), dict(history_size=64, n_codebook=3)])
+def test_basislz_host_decoder_matches_oracle(oracle, kw):
+    """the serial entropy decode (Huffman tables, codebooks, predictors, history, RLE) -- product C++ vs oracle C"""
+    rng = np.random.default_rng(hash(str(sorted(kw.items()))) & 0xFFFF)
+    for trial in range(25):
+        dims = [(int(rng.integers(1, 40)), int(rng.integers(1, 30))) for _ in range(3)]
+        kw2 = dict(n_codebook=int(rng.integers(2, 300)))
+        kw2.update(kw)
+        f, ep, rows = bb.etc1s_file(rng, dims, **kw2)
+        h = bu.read_header(f)
+        sd = bu.read_slice_descs(f, h)
+        for si, s in enumerate(sd):
+            st, oep, osel, oidx = oracle.lz_decode(f[h.endpoint_cb_file_ofs:h.endpoint_cb_file_ofs + h.endpoint_cb_file_size],
+                                                   f[h.selector_cb_file_ofs:h.selector_cb_file_ofs + h.selector_cb_file_size],
+                                                   f[h.tables_file_ofs:h.tables_file_ofs + h.tables_file_size], h.total_selectors, h.total_selectors,
+                                                   h.tex_type == 3, f[s.file_ofs:s.file_ofs + s.file_size], s.num_blocks_x, s.num_blocks_y)
+            assert st == 0
+            pep, psel, pidx = bu.basislz_decode(f, si)
+            assert (pep == oep).all() and (psel == osel).all()
+            assert (pidx == (oidx[:, 0].astype(np.uint32) | (oidx[:, 1].astype(np.uint32) << 16))).all()
+        # the codebooks survive the round trip through the test encoder
+        assert (pep == ep).all() and (psel[:, :4] == rows).all()
+
+
+def test_basislz_corrupt_streams_agree_with_oracle(oracle):
+    """bit flips anywhere in an ETC1S file: product and oracle must fail (or succeed) identically"""
+    import ctypes
+
+    rng = np.random.default_rng(3)
+    f, _, _ = bb.etc1s_file(rng, [(7, 5), (4, 4)], n_codebook=40, raw_selectors=False)
+    lib = _lib.load()
+    agree = 0
+    for trial in range(1500):
+        g = bytearray(f)
+        pos = int(rng.integers(77 + 46, len(g)))
+        g[pos] ^= 1 << int(rng.integers(0, 8))
+        g[12:14] = bb.crc16(bytes(g[77:])).to_bytes(2, "little")
+        g[6:8] = bb.crc16(bytes(g[8:77])).to_bytes(2, "little")
+        g = bytes(g)
+        for si in range(2):
+            h = bu.read_header(g)
+            sd = bu.read_slice_descs(g, h)[si]
+            st, oep, osel, oidx = oracle.lz_decode(g[h.endpoint_cb_file_ofs:h.endpoint_cb_file_ofs + h.endpoint_cb_file_size],
+                                                   g[h.selector_cb_file_ofs:h.selector_cb_file_ofs + h.selector_cb_file_size],
+                                                   g[h.tables_file_ofs:h.tables_file_ofs + h.tables_file_size], h.total_selectors, h.total_selectors, False,
+                                                   g[sd.file_ofs:sd.file_ofs + sd.file_size], sd.num_blocks_x, sd.num_blocks_y)
+            a = np.frombuffer(g, dtype=np.uint8)
+            idx = np.zeros(sd.num_blocks_x * sd.num_blocks_y, dtype=np.uint32)
+            pst = lib.bu_basislz_decode(a.ctypes.data, a.size, si, None, None, idx.ctypes.data)
+            assert (pst == 0) == (st == 0), (trial, pos, pst, st)
+            if st == 0:
+                assert (idx == (oidx[:, 0].astype(np.uint32) | (oidx[:, 1].astype(np.uint32) << 16))).all()
+                agree += 1
+    assert agree > 50
+
+
+def test_uastc_writer_round_trips_through_the_oracle(oracle, golden):
+    dims = [(5, 2), (16, 9)]
+    blocks = [golden["uastc"][synth.gold_indices(x * y, seed=9 + i)] for i, (x, y) in enumerate(dims)]
+    f = bu.write_uastc_file([dict(data=b, orig_w=4 * x - 3, orig_h=4 * y, nbx=x, nby=y, image_index=i) for i, (b, (x, y)) in enumerate(zip(blocks, dims))])
+    st, hdr, imgs = oracle.read_to("uastc", f)
+    assert st == 0 and len(imgs) == 2
+    for (w, h, stride, data), b, (x, y) in zip(imgs, blocks, dims):
+        assert (w, h, stride) == (4 * x - 3, 4 * y, 16 * x) and data.tobytes() == b.tobytes()
+    st, _, imgs = oracle.read_to("bc7", f)
+    assert st == 0 and (imgs[1][3].reshape(-1, 16) == golden["bc7"][synth.gold_indices(16 * 9, seed=10)]).all()

@@ -166,3 +166,92 @@ def test_etc1s_backend_matches_oracle(ctx, oracle):
     with pytest.raises(BasisuError) as e:
         ctx.etc1s_transcode_to_etc1(bad, ep, sel)
     assert e.value.status == _lib.ERR_INDEX_RANGE and e.value.first_bad_block == 1234
+
+
+def test_virtual_ranks_on_one_device_match_single_rank(ctx, golden):
+    """P virtual ranks (P streams, contiguous slice ranges, gather = D2D copies into one buffer)
+    must give byte-identical output to P = 1"""
+    import torch
+
+    from basisu_rs_amd import sharded
+
+    n_slices, bps = 32, 4096  # 32 slices of 64x64 blocks
+    idx = synth.gold_indices(n_slices * bps, seed=77)
+    slices = torch.from_numpy(golden["uastc"][idx].reshape(n_slices, bps, 16).copy()).cuda()
+    fn = sharded.gpu_transcode_fn(ctx, _lib.BC7)
+    whole = fn(slices.reshape(-1, 16)).reshape(n_slices, bps, 16)
+    assert (whole.cpu().numpy() == golden["bc7"][idx].reshape(n_slices, bps, 16)).all()
+    for P in (2, 3, 8):
+        full = torch.empty_like(whole)
+        streams = [torch.cuda.Stream() for _ in range(P)]
+        status = torch.empty(P, dtype=torch.int64, device="cuda")
+        for r in range(P):
+            lo, hi = sharded.partition(n_slices, P, r)
+            with torch.cuda.stream(streams[r]):
+                ctx.status_word_reset(status[r:r + 1], stream=streams[r])
+                ctx.transcode_device(_lib.BC7, slices[lo:hi], (hi - lo) * bps, full[lo:hi], block_index_base=lo * bps,
+                                     d_status=status[r:r + 1], stream=streams[r])
+        torch.cuda.synchronize()
+        for r in range(P):
+            ctx.status_word_check(int(status[r].item()) & 0xFFFFFFFFFFFFFFFF)
+        assert torch.equal(full, whole), P
+
+
+# ---- whole-file API (lib.rs:20-22 read_to_*) -----------------------------------------------------------
+def _images_equal(got, want):
+    assert len(got) == len(want)
+    for g, (w, h, stride, data) in zip(got, want):
+        assert (g.w, g.h, g.stride) == (w, h, stride)
+        assert g.data.tobytes() == data.tobytes()
+
+
+def test_read_to_all_targets_on_a_uastc_file(ctx, golden, oracle):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    dims = [(64, 32), (3, 5), (1, 1), (128, 96)]  # mip-chain-like sizes; the last one takes the sorted kernel
+    blocks = [np.concatenate([golden["uastc"][synth.gold_indices(x * y // 2, seed=i)], synth.atlas_rand(x * y - x * y // 2, seed=i)]) for i, (x, y) in enumerate(dims)]
+    f = bb.uastc_file(blocks, dims)
+    fns = {"rgba": lambda b: bu.read_to_rgba(b, ctx)[1], "etc1": lambda b: bu.read_to_etc1(b, ctx), "etc2": lambda b: bu.read_to_etc2(b, ctx),
+           "uastc": lambda b: bu.read_to_uastc(b, ctx), "astc": lambda b: bu.read_to_astc(b, ctx), "bc7": lambda b: bu.read_to_bc7(b, ctx)}
+    for name, fn in fns.items():
+        st, hdr, want = oracle.read_to(name, f)
+        assert st == 0
+        _images_equal(fn(f), want)
+    h, _ = bu.read_to_rgba(f, ctx)
+    assert h.as_list() == oracle.read_to("rgba", f)[1]
+    # a bad block inside slice 1 aborts the whole call with the reference's message
+    blocks[1] = blocks[1].copy()
+    blocks[1][7, 0] = 69
+    with pytest.raises(bu.BasisuError, match="invalid mode index"):
+        bu.read_to_bc7(bb.uastc_file(blocks, dims), ctx)
+    with pytest.raises(bu.BasisuError, match="Data CRC16 failed"):
+        bu.read_to_bc7(bb.uastc_file(blocks, dims, corrupt="data_crc"), ctx)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(alpha=True), dict(raw_selectors=False), dict(is_video=True), dict(grayscale=True)])
+def test_read_to_on_etc1s_files(ctx, oracle, kw):
+    """config 4 end to end: host BasisLZ decode + GPU codebook lookup / repack, against the oracle's whole-file path"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    rng = np.random.default_rng(17)
+    f, _, _ = bb.etc1s_file(rng, [(64, 64), (33, 17), (1, 1), (100, 80)], n_codebook=1024, **kw)
+    st, hdr, want = oracle.read_to("etc1", f)
+    assert st == 0
+    _images_equal(bu.read_to_etc1(f, ctx), want)
+    st, hdr, want = oracle.read_to("rgba", f)
+    assert st == 0
+    h, got = bu.read_to_rgba(f, ctx)
+    _images_equal(got, want)
+    assert h.as_list() == hdr
+    with pytest.raises(bu.BasisuError, match="not implemented"):
+        bu.read_to_bc7(f, ctx)
