@@ -97,6 +97,8 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
 // so global loads and stores stay fully coalesced (1 KiB per wave instruction).
 //   LDS per workgroup: tile 16 KiB + tables 5.8 KiB + 1 KiB status + counters.
+// modes by descending code-path length (BC7 VALU counts), 5 bits each: entries 0-11 / 12-19
+constexpr unsigned long long BU_COST_ORDER_LO = 0x2996161c4482643ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     __shared__ uint4 sblk[BU_TILE];
     __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
     __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
-    __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks;
+    __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks, next_chunk;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
     unsigned tile = blockIdx.x;
@@ -157,7 +159,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         BU_STAMP(3)
         // ---- B: run starts and the chunk list (one wave) ----
         if (wave == 0) {
-            const uint32_t c = lane < 20 ? cnt[lane] : 0u;
+            // lane l owns mode BU_COST_ORDER[l]: runs are laid out heaviest code path first, so the dynamically
+            // scheduled chunk loop below ends with the cheap chunks (longest-processing-time-first balancing)
+            const uint32_t mo = (uint32_t)((lane < 12 ? (BU_COST_ORDER_LO >> (5 * lane)) : (BU_COST_ORDER_HI >> (5 * (lane - 12)))) & 31u);
+            const uint32_t c = lane < 20 ? cnt[mo] : 0u;
             uint32_t incl = c, nch = (c + 63u) >> 6, cincl = nch;
 #pragma unroll
             for (int d = 1; d < 32; d <<= 1) {
@@ -168,15 +173,14 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                 }
             }
             const uint32_t st = incl - c, cst = cincl - nch;
-            if (lane < 20) {
-                start[lane] = st;
-                cnt[lane] = 0;
-            }
+            if (lane < 20) start[mo] = st;
             for (uint32_t k = 0; k < nch; k++) {
                 const uint32_t left = c - 64u * k;
-                chunk[cst + k] = lane | ((st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
+                chunk[cst + k] = mo | ((st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
             }
             if (lane == 19) n_chunks = cincl;
+            if (lane < 32) cnt[lane] = 0;
+            if (lane == 0) next_chunk = 0;
         }
         __syncthreads();
         BU_STAMP(4)
@@ -204,7 +208,11 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         BU_STAMP(5)
         // ---- C: whole chunks, wave-uniform mode ----
         const uint32_t nc = n_chunks;
-        for (uint32_t c = wave; c < nc; c += BU_WG / 64) {
+        for (;;) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&next_chunk, 1u);  // dynamic chunk scheduling: waves take the next chunk as they free up
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= nc) break;
             const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk[c]);
             const uint32_t m = desc & 31u, s0 = (desc >> 8) & 0xFFFFu, count = desc >> 24;
             const bool active = lane < count;

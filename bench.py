@@ -221,6 +221,42 @@ def main():
         extra["end_to_end_host_pointers"] = {"mblocks_s": round(N_BLOCKS / e2e_s / 1e6, 1), "ms_per_atlas": round(e2e_s * 1e3, 3),
                                              "verified": bool((host_out.reshape(-1, 16) == golden["bc7"][idx0]).all()),
                                              "note": "pageable host memory, includes PCIe both ways -- never the headline value"}
+        # the other block-linear targets of the same atlas (secondary rows; cold rotation over the same buffers)
+        for tname, tcode, bpb in (("astc", _lib.ASTC, 32), ("etc1", _lib.ETC1, 24), ("etc2", _lib.ETC2, 32)):
+            run(16, target=tcode)
+            ts = run(max(64, args.steps // 4), target=tcode) / 1e3 / max(64, args.steps // 4)
+            extra["uastc_to_" + tname] = {"gb_s": round(bpb * N_BLOCKS / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3),
+                                          "mblocks_s": round(N_BLOCKS / ts / 1e6, 1), "bytes_per_block": bpb}
+        # config 4 shape: ETC1S 2048x2048 (512x512 blocks), 4096-entry endpoint / 8192-entry selector codebooks
+        try:
+            from basisu_rs_amd import etc1s_selector_from_rows
+
+            ep, rows = synth.etc1s_codebooks(4096, 8192, seed=2)
+            sel = etc1s_selector_from_rows(rows)
+            nbl = 512 * 512
+            d_ep = torch.from_numpy(ep.view(np.int32)).to(dev)
+            d_sel = torch.from_numpy(sel).to(dev)
+            d_idx = [torch.from_numpy(synth.etc1s_indices(nbl, 4096, 8192, seed=100 + k).view(np.int32)).to(dev) for k in range(32)]
+            d_o8 = [torch.empty((nbl, 8), dtype=torch.uint8, device=dev) for _ in range(32)]
+            d_o64 = [torch.empty((nbl, 64), dtype=torch.uint8, device=dev) for _ in range(32)]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for name, fn, bpb in (("etc1s_to_etc1", lambda k: lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx[k].data_ptr(), nbl, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, d_o8[k].data_ptr(), None, sp), 12),
+                                  ("etc1s_to_rgba32", lambda k: lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx[k].data_ptr(), None, 512, 512, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, d_o64[k].data_ptr(), None, sp), 68)):
+                for k in range(32):
+                    fn(k)
+                torch.cuda.synchronize()
+                e0.record(stream)
+                reps = 256
+                for i in range(reps):
+                    fn(i % 32)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ts = e0.elapsed_time(e1) / 1e3 / reps
+                extra[name] = {"gb_s": round(bpb * nbl / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3), "mblocks_s": round(nbl / ts / 1e6, 1),
+                               "bytes_per_block": bpb, "blocks": nbl}
+            del d_idx, d_o8, d_o64
+        except Exception as e:  # secondary rows must never break the headline line
+            extra["etc1s_error"] = repr(e)
         # config 3: UASTC -> RGBA32 (16 B in, 64 B out)
         rg_n = min(nbuf, 16)
         rg_out = [torch.empty((N_BLOCKS, 64), dtype=torch.uint8, device=dev) for _ in range(rg_n)]
