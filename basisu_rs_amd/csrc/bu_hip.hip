@@ -124,10 +124,12 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                                                                 const BuTables* __restrict__ tables BU_STAMP_ARG)
 {
     BU_STAMP(0)
-    static_assert(TARGET != BU_TGT_RGBA || DIRECT, "RGBA32 needs DIRECT stores");
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
     __shared__ BuTables T;
     __shared__ uint4 sblk[BU_TILE];
+    // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
+    // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts)
+    __shared__ uint4 sout[(TARGET == BU_TGT_RGBA && !DIRECT) ? 4 * BU_TILE : 1];
     __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
     __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
     __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks, next_chunk;
@@ -254,6 +256,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                     } else {
                         reinterpret_cast<uint4*>(out)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
                     }
+                } else if constexpr (TARGET == BU_TGT_RGBA) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sout[r * BU_TILE + slot] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+                    sst[slot] = (uint8_t)st;
                 } else {
                     sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
                     sst[slot] = (uint8_t)st;
@@ -269,11 +275,18 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             for (int j = 0; j < BU_BPT; j++) {
                 if (mode[j] < 20u) {
                     const unsigned idx = tbase + j * BU_WG + tid;
-                    const uint4 r = sblk[dest[j]];
                     const uint32_t st = sst[dest[j]];
                     if (st) bu_report(status, base + idx, (int)st);
-                    if constexpr (TARGET == BU_TGT_ETC1) reinterpret_cast<uint2*>(out)[idx] = make_uint2(r.x, r.y);
-                    else reinterpret_cast<uint4*>(out)[idx] = r;
+                    if constexpr (TARGET == BU_TGT_RGBA) {
+                        const unsigned by = idx / bpr, bx = idx - by * bpr;
+                        uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) img[(size_t)((4 * by + r) * bpr + bx)] = sout[r * BU_TILE + dest[j]];
+                    } else {
+                        const uint4 r = sblk[dest[j]];
+                        if constexpr (TARGET == BU_TGT_ETC1) reinterpret_cast<uint2*>(out)[idx] = make_uint2(r.x, r.y);
+                        else reinterpret_cast<uint4*>(out)[idx] = r;
+                    }
                 }
             }
         }
@@ -493,7 +506,14 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
             case BU_TARGET_ETC1: BU_LAUNCH_SORTED(BU_TGT_ETC1) break;
-            case BU_TARGET_RGBA32: hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS); break;
+            case BU_TARGET_RGBA32: {
+                // 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows) so the image
+                // rows leave as coalesced 1 KiB stores; one 1024-thread workgroup per CU walks its tiles with prefetch
+                const size_t rtiles = (nb + 1023) / 1024;
+                const unsigned rgrid = (unsigned)(rtiles < (size_t)ctx->cu_count ? rtiles : (size_t)ctx->cu_count);
+                hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 1024, 1, 1, true, false>), dim3(rgrid), dim3(1024), 0, stream, pin, pout, (unsigned)nb,
+                                   (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
+            } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }
 #undef BU_LAUNCH_SORTED
