@@ -24,7 +24,7 @@ SYMBOLS = [
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
     "bu_basis_read_header", "bu_basis_read_slice_descs", "bu_basis_crc16", "bu_read_query", "bu_read_to", "bu_basislz_decode",
     "bu_basis_write_uastc",
-    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_copy_launches",
+    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_streams", "bu_time_copy_launches",
 ]
 
 # bu_read_target
@@ -124,6 +124,8 @@ def load():
     lib.bu_copy_ceiling_device.restype = c.c_int
     lib.bu_time_uastc_launches.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches.restype = c.c_int
+    lib.bu_time_uastc_launches_streams.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, c.c_int, c.POINTER(c.c_float)]
+    lib.bu_time_uastc_launches_streams.restype = c.c_int
     lib.bu_time_copy_launches.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), sz, sz, c.c_int, vp, c.POINTER(c.c_float)]
     lib.bu_time_copy_launches.restype = c.c_int
     _lib = lib

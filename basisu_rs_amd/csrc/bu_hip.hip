@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 
@@ -438,6 +439,7 @@ struct bu_context {
     size_t aux_cap = 0;
     unsigned long long* d_status = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::mutex lock;  // host-pointer entry points share the staging buffers
     char err[256] = {0};
 };
@@ -658,6 +660,8 @@ void bu_context_destroy(bu_context* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t es : ctx->extra_streams)
+        if (es) (void)hipStreamDestroy(es);
     delete ctx;
 }
 
@@ -977,49 +981,104 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         if (p.images.size() > max_images) return BU_ERR_OUTPUT_SIZE;
         for (size_t i = 0; i < p.images.size(); i++) images[i] = p.images[i];
     }
+    if (p.images.empty()) return BU_OK;
+    if (!p.etc1s && target == BU_READ_UASTC) {  // uastc.rs:85-87: plain copies, no device work
+        for (size_t k = 0; k < p.images.size(); k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
+            if (s.file_size) memcpy(out + p.images[k].offset, file + s.file_ofs, s.file_size);
+        }
+        return BU_OK;
+    }
+    // Batched front door: every slice's input is staged at an aligned offset of one device buffer, the device output
+    // buffer mirrors `out`, all launches go to the context stream back to back (one status word per image) and a
+    // single synchronisation ends the call.  The host-side BasisLZ decode of all slices happens before any upload.
     bu_host::BasisLz lz;
+    const size_t n_img = p.images.size();
+    std::vector<size_t> in_off(n_img, 0), ain_off(n_img, 0);
+    std::vector<uint32_t> idx_all;
+    size_t total_in = 0;
+    auto align_up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     if (p.etc1s) {
         st = bu_make_lz(file, len, p.h, lz);
         if (st) return st;
-    }
-    std::vector<uint32_t> idx, aidx;
-    for (size_t k = 0; k < p.images.size(); k++) {
-        const bu_slice_desc& s = p.slices[p.first_slice[k]];
-        const bu_image& im = p.images[k];
-        const uint8_t* data = file + s.file_ofs;
-        uint8_t* dst = out + im.offset;
-        uint64_t bad = 0;
-        if (p.etc1s) {
+        size_t words = 0;
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
             const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y;
-            idx.assign(nblk ? nblk : 1, 0);
-            st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, data, s.file_size, idx.data());
-            if (st) return st;
-            const uint32_t n_cb = (uint32_t)lz.endpoints.size();
-            if (target == BU_READ_RGBA) {
-                const uint32_t* ap = nullptr;
-                if (p.alpha_pairs) {
-                    const bu_slice_desc& a = p.slices[p.first_slice[k] + 1];
-                    aidx.assign(nblk ? nblk : 1, 0);
-                    st = lz.decode_slice(a.num_blocks_x, a.num_blocks_y, file + a.file_ofs, a.file_size, aidx.data());
-                    if (st) return st;
-                    ap = aidx.data();
-                }
-                st = bu_etc1s_decode_rgba(ctx, idx.data(), ap, s.num_blocks_x, s.num_blocks_y, lz.endpoints.data(), n_cb, lz.selectors.data(), n_cb,
-                                          dst, im.size, &bad);
-            } else {
-                st = bu_etc1s_transcode_etc1(ctx, idx.data(), nblk, lz.endpoints.data(), n_cb, lz.selectors.data(), n_cb, dst, im.size, &bad);
-            }
-        } else {
-            switch (target) {
-            case BU_READ_UASTC: memcpy(dst, data, s.file_size); st = BU_OK; break;  // uastc.rs:85-87
-            case BU_READ_RGBA: st = s.file_size ? bu_uastc_decode_to_rgba(ctx, data, s.file_size, s.num_blocks_x, dst, im.size, &bad) : BU_OK; break;
-            case BU_READ_ASTC: st = bu_uastc_transcode(ctx, BU_TARGET_ASTC, data, s.file_size, dst, im.size, &bad); break;
-            case BU_READ_BC7: st = bu_uastc_transcode(ctx, BU_TARGET_BC7, data, s.file_size, dst, im.size, &bad); break;
-            case BU_READ_ETC1: st = bu_uastc_transcode(ctx, BU_TARGET_ETC1, data, s.file_size, dst, im.size, &bad); break;
-            default: st = bu_uastc_transcode(ctx, BU_TARGET_ETC2, data, s.file_size, dst, im.size, &bad); break;
+            in_off[k] = words * 4;
+            words += (nblk + 63) & ~(size_t)63;
+            if (p.alpha_pairs) {
+                ain_off[k] = words * 4;
+                words += (nblk + 63) & ~(size_t)63;
             }
         }
-        if (st) return st;  // first Err aborts the whole call, like the `?` in the reference drivers
+        idx_all.assign(words ? words : 1, 0);
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
+            st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, file + s.file_ofs, s.file_size, idx_all.data() + in_off[k] / 4);
+            if (st) return st;
+            if (p.alpha_pairs) {
+                const bu_slice_desc& a = p.slices[p.first_slice[k] + 1];
+                st = lz.decode_slice(a.num_blocks_x, a.num_blocks_y, file + a.file_ofs, a.file_size, idx_all.data() + ain_off[k] / 4);
+                if (st) return st;
+            }
+        }
+        total_in = words * 4;
+    } else {
+        for (size_t k = 0; k < n_img; k++) {
+            in_off[k] = total_in;
+            total_in += align_up(p.slices[p.first_slice[k]].file_size);
+        }
+    }
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    if ((st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, total_in ? total_in : 16))) return st;
+    if ((st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, p.out_bytes ? p.out_bytes : 16))) return st;
+    const size_t ep_bytes = p.etc1s ? align_up(lz.endpoints.size() * 4) : 0, sel_bytes = p.etc1s ? align_up(lz.selectors.size()) : 0;
+    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + 8 * n_img + 256))) return st;
+    uint8_t* d_in = static_cast<uint8_t*>(ctx->d_in);
+    uint8_t* d_out = static_cast<uint8_t*>(ctx->d_out);
+    uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
+    uint64_t* d_status = reinterpret_cast<uint64_t*>(aux + ep_bytes + sel_bytes);
+    BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, 8 * n_img, ctx->stream));
+    if (p.etc1s) {
+        BU_HIP(ctx, hipMemcpyAsync(d_in, idx_all.data(), total_in, hipMemcpyHostToDevice, ctx->stream));
+        if (!lz.endpoints.empty()) BU_HIP(ctx, hipMemcpyAsync(aux, lz.endpoints.data(), lz.endpoints.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!lz.selectors.empty()) BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, lz.selectors.data(), lz.selectors.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const uint32_t n_cb = (uint32_t)lz.endpoints.size();
+    for (size_t k = 0; k < n_img; k++) {
+        const bu_slice_desc& s = p.slices[p.first_slice[k]];
+        const bu_image& im = p.images[k];
+        if (im.size == 0) continue;
+        if (p.etc1s) {
+            const uint32_t* di = reinterpret_cast<const uint32_t*>(d_in + in_off[k]);
+            const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y;
+            if (target == BU_READ_RGBA)
+                st = bu_etc1s_decode_rgba_device(ctx, di, p.alpha_pairs ? reinterpret_cast<const uint32_t*>(d_in + ain_off[k]) : nullptr, s.num_blocks_x,
+                                                 s.num_blocks_y, reinterpret_cast<const uint32_t*>(aux), n_cb, aux + ep_bytes, n_cb, d_out + im.offset,
+                                                 d_status + k, ctx->stream);
+            else
+                st = bu_etc1s_transcode_etc1_device(ctx, di, nblk, reinterpret_cast<const uint32_t*>(aux), n_cb, aux + ep_bytes, n_cb, d_out + im.offset,
+                                                    d_status + k, ctx->stream);
+        } else {
+            BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k], file + s.file_ofs, s.file_size, hipMemcpyHostToDevice, ctx->stream));
+            const bu_target bt = target == BU_READ_RGBA ? BU_TARGET_RGBA32
+                                 : target == BU_READ_ASTC ? BU_TARGET_ASTC
+                                 : target == BU_READ_BC7  ? BU_TARGET_BC7
+                                 : target == BU_READ_ETC1 ? BU_TARGET_ETC1
+                                                          : BU_TARGET_ETC2;
+            st = bu_launch_uastc(ctx, bt, d_in + in_off[k], s.file_size / 16, d_out + im.offset, s.num_blocks_x ? s.num_blocks_x : 1, 0, d_status + k, ctx->stream);
+        }
+        if (st) return st;
+    }
+    std::vector<uint64_t> words(n_img, 0);
+    BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
+    if (p.out_bytes) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < n_img; k++) {  // first Err (in slice order) aborts the whole call, like the `?` in the reference drivers
+        st = bu_status_word_decode(words[k], nullptr);
+        if (st) return st;
     }
     return BU_OK;
 }
@@ -1093,6 +1152,25 @@ bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* 
     BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
     BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
     BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
+
+bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                         size_t n_blocks, size_t blocks_per_row, int launches, int n_streams, float* out_ms)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_streams; i++)
+        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
+    BU_HIP(ctx, hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (size_t)i % n_buffers;
+        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, nullptr, ctx->extra_streams[i % n_streams]);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipDeviceSynchronize());
+    *out_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return BU_OK;
 }
 

@@ -194,6 +194,14 @@ def main():
         hot_s = run(args.steps, inp=one_in, outp=one_out, nb=1) / 1e3 / args.steps
         extra["hot_cache"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / hot_s / 1e9, 1), "us_per_launch": round(hot_s * 1e6, 3),
                               "note": "same atlas every launch (32 MiB working set sits in the 256 MiB Infinity Cache) -- NOT the headline"}
+        # independent atlases in flight on several streams (how a production loop over slices would run): throughput row
+        for ns in (2, 4):
+            ms = ctypes.c_float(0)
+            lib.bu_time_uastc_launches_streams(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, N_BLOCKS, NBX, 64, ns, ctypes.byref(ms))
+            lib.bu_time_uastc_launches_streams(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, N_BLOCKS, NBX, args.steps, ns, ctypes.byref(ms))
+            ss = ms.value / 1e3 / args.steps
+            extra["streams_%d" % ns] = {"us_per_atlas": round(ss * 1e6, 3), "mblocks_s": round(N_BLOCKS / ss / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / ss / 1e9, 1),
+                                        "note": "%d HIP streams, launches of independent atlases overlap; wall clock; not the roofline row" % ns}
         # mode-coherent atlases (mode chosen per 8x8-block tile): texture-like, waves see 1-2 modes
         coh = []
         for k in range(min(nbuf, 64)):

@@ -229,6 +229,11 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
 bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                  size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches,
                                  uint64_t* d_status, void* stream, float* out_ms);
+/* Same launches spread round-robin over `n_streams` context-owned streams (independent slices in flight together);
+ * wall-clock milliseconds between two device synchronisations.  Steady-state throughput row, not the roofline row. */
+bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
+                                         size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches, int n_streams,
+                                         float* out_ms);
 bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers,
                                 size_t n_blocks, int launches, void* stream, float* out_ms);
 
