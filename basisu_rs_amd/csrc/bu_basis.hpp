@@ -117,6 +117,25 @@ inline bu_status read_slice_descs(const uint8_t* file, size_t len, const bu_basi
 
 inline bool in_file(size_t len, size_t ofs, size_t size) { return ofs <= len && size <= len - ofs; }
 
+// etc::Selector::set_selector (etc.rs:363-393) for all 16 texels of one codebook entry: ETC1 code = [3,2,0,1][value],
+// pixel id = x*4 + y, MSB plane in bytes 4-5 (pixels 8-15, then 0-7), LSB plane in bytes 6-7; bytes 0-3 keep the raw rows
+inline void selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8])
+{
+    static const uint8_t to_etc1[4] = {3, 2, 0, 1};  // etc.rs:433
+    uint32_t msb = 0, lsb = 0;
+    for (unsigned y = 0; y < 4; y++)
+        for (unsigned x = 0; x < 4; x++) {
+            const unsigned code = to_etc1[(rows[y] >> (2 * x)) & 3u];
+            msb |= (code >> 1) << (x * 4 + y);
+            lsb |= (code & 1u) << (x * 4 + y);
+        }
+    memcpy(out_entry, rows, 4);
+    out_entry[4] = (uint8_t)(msb >> 8);
+    out_entry[5] = (uint8_t)(msb & 0xFF);
+    out_entry[6] = (uint8_t)(lsb >> 8);
+    out_entry[7] = (uint8_t)(lsb & 0xFF);
+}
+
 // ---- LSB-first bit reader with a 64-bit window ----
 class BitReader {
 public:
@@ -302,7 +321,7 @@ struct BasisLz {
                 }
                 prev[y] = rows[y];
             }
-            bu_etc1s_selector_from_rows(rows, &selectors[8 * i]);
+            selector_from_rows(rows, &selectors[8 * i]);
         }
         return BU_OK;
     }
@@ -454,5 +473,81 @@ struct BasisLz {
         return BU_OK;
     }
 };
+
+// ---- whole-file planning (basis.rs:8-260): every check of read_to_* that needs no block work ----
+struct BuFilePlan {
+    bu_basis_header h;
+    std::vector<bu_slice_desc> slices;
+    std::vector<bu_image> images;       // one per output image
+    std::vector<size_t> first_slice;    // slice feeding image i (its colour slice for RGBA+alpha)
+    size_t out_bytes = 0;
+    bool etc1s = false, alpha_pairs = false;
+};
+
+// everything of read_to_* that needs no block work: checks in the reference's order, image geometry
+inline bu_status bu_plan_file(bu_read_target target, const uint8_t* file, size_t len, BuFilePlan& p)
+{
+    if (!file) return BU_ERR_ARGUMENT;
+    if ((int)target < 0 || (int)target > 5) return BU_ERR_ARGUMENT;
+    bu_status st = read_header(file, len, &p.h);
+    if (st) return st;
+    if (crc16(file + 77, len - 77, 0) != p.h.data_crc16) return BU_ERR_DATA_CRC;  // to EOF, basis.rs:338-341
+    st = read_slice_descs(file, len, &p.h, p.slices);
+    if (st) return st;
+    if (p.h.tex_format > 1) return BU_ERR_TEX_FORMAT;
+    p.etc1s = p.h.tex_format == 0;
+    const bool has_alpha = (p.h.flags & 4) != 0;
+    if (p.etc1s && !(target == BU_READ_RGBA || target == BU_READ_ETC1)) return BU_ERR_UNSUPPORTED;
+    if (p.etc1s && has_alpha && (p.slices.size() % 2) != 0) return BU_ERR_ALPHA_SLICES;
+    p.alpha_pairs = p.etc1s && has_alpha && target == BU_READ_RGBA;
+    for (size_t i = 0; i < p.slices.size(); i++) {
+        const bu_slice_desc& s = p.slices[i];
+        if (!in_file(len, s.file_ofs, s.file_size)) return BU_ERR_BOUNDS;
+        if (p.alpha_pairs) {
+            if (i & 1) continue;
+            const bu_slice_desc& a = p.slices[i + 1];
+            if (!(a.flags & 1)) return BU_ERR_ALPHA_SLICES;
+            if (a.num_blocks_x != s.num_blocks_x || a.num_blocks_y != s.num_blocks_y) return BU_ERR_ALPHA_SLICES;
+        }
+        const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y, nb16 = s.file_size / 16;
+        bu_image im = {s.orig_width, s.orig_height, 0, 0, p.out_bytes, 0};
+        if (p.etc1s) {
+            if (target == BU_READ_RGBA) {
+                im.size = nblk * 64;
+                im.stride = 16u * s.orig_width;  // basis.rs:46,64 x4 (lib.rs:75): reference quirk, rows are 16*nbx apart
+            } else {
+                im.size = nblk * 8;
+                im.stride = 8u * s.num_blocks_x;
+            }
+        } else {
+            if (target != BU_READ_UASTC && s.file_size % 16) return BU_ERR_LENGTH;  // uastc.rs:54-59
+            switch (target) {
+            case BU_READ_RGBA:
+                if (s.num_blocks_x == 0 && nb16) return BU_ERR_BOUNDS;
+                if (s.num_blocks_x && nb16 % s.num_blocks_x) return BU_ERR_BOUNDS;  // the reference indexes past its image
+                im.size = nb16 * 64;
+                im.stride = 16u * s.num_blocks_x;
+                break;
+            case BU_READ_UASTC: im.size = s.file_size; im.stride = 16u * s.num_blocks_x; break;
+            case BU_READ_ETC1: im.size = nb16 * 8; im.stride = 8u * s.num_blocks_x; break;
+            default: im.size = nb16 * 16; im.stride = 16u * s.num_blocks_x; break;
+            }
+        }
+        p.images.push_back(im);
+        p.first_slice.push_back(i);
+        p.out_bytes += im.size;
+    }
+    return BU_OK;
+}
+
+inline bu_status bu_make_lz(const uint8_t* file, size_t len, const bu_basis_header& h, BasisLz& lz)
+{
+    if (!in_file(len, h.endpoint_cb_file_ofs, h.endpoint_cb_file_size) || !in_file(len, h.selector_cb_file_ofs, h.selector_cb_file_size) ||
+        !in_file(len, h.tables_file_ofs, h.tables_file_size) || !in_file(len, h.extended_file_ofs, h.extended_file_size))
+        return BU_ERR_BOUNDS;
+    // total_selectors for both codebooks: basis.rs:289-291
+    return lz.init(h.total_selectors, h.total_selectors, file + h.endpoint_cb_file_ofs, h.endpoint_cb_file_size, file + h.selector_cb_file_ofs,
+                   h.selector_cb_file_size, file + h.tables_file_ofs, h.tables_file_size, h.tex_type == 3);
+}
 
 }  // namespace bu_host

@@ -1,0 +1,81 @@
+// TEST-ONLY: the product's host-side container parser + BasisLZ decoder (csrc/bu_basis.hpp, the exact code that ships
+// inside libbasisu_hip.so) compiled with AddressSanitizer + UBSan, plus a corrupt-file fuzz loop.  GPU ASan is not
+// available on the pool, and this code is what faces untrusted `.basis` bytes, so it gets the sanitizer treatment.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "bu_basis.hpp"
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint32_t rnd()
+{
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return (uint32_t)(rng_state >> 11);
+}
+
+// plan + (for ETC1S) full host decode of every slice, as bu_read_to does before any upload
+static int process(const uint8_t* f, size_t len, int target)
+{
+    bu_host::BuFilePlan p;
+    bu_status st = bu_host::bu_plan_file((bu_read_target)target, f, len, p);
+    if (st) return st;
+    if (!p.etc1s) return 0;
+    bu_host::BasisLz lz;
+    st = bu_host::bu_make_lz(f, len, p.h, lz);
+    if (st) return st;
+    std::vector<uint32_t> idx;
+    for (size_t k = 0; k < p.slices.size(); k++) {
+        const bu_slice_desc& s = p.slices[k];
+        idx.assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
+        st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, idx.data());
+        if (st) return st;
+    }
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    const int iters = atoi(argv[2]);
+    FILE* fp = fopen(argv[1], "rb");
+    if (!fp) return 2;
+    std::vector<uint8_t> base;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) base.insert(base.end(), buf, buf + n);
+    fclose(fp);
+    int ok = 0, bad = 0;
+    if (process(base.data(), base.size(), BU_READ_RGBA) != 0) return 3;  // the pristine file must parse
+    for (int it = 0; it < iters; it++) {
+        std::vector<uint8_t> g = base;
+        const int kind = rnd() % 4;
+        const int flips = 1 + rnd() % 4;
+        for (int k = 0; k < flips; k++) {
+            size_t pos = kind == 0 ? rnd() % 77 : (kind == 1 ? 77 + rnd() % (g.size() > 200 ? 123 : 1) : rnd() % g.size());
+            if (pos >= g.size()) pos = g.size() - 1;
+            g[pos] ^= (uint8_t)(1u << (rnd() % 8));
+        }
+        if (kind == 3 && g.size() > 100) g.resize(77 + rnd() % (g.size() - 77));  // truncation
+        // re-seal both CRCs so the mutation reaches the parsers behind them
+        if (g.size() >= 77) {
+            const uint16_t dc = bu_host::crc16(g.data() + 77, g.size() - 77, 0);
+            g[12] = (uint8_t)dc;
+            g[13] = (uint8_t)(dc >> 8);
+            const uint16_t hc = bu_host::crc16(g.data() + 8, 69, 0);
+            g[6] = (uint8_t)hc;
+            g[7] = (uint8_t)(hc >> 8);
+        }
+        // heap copy of exact size so ASan sees any over-read of the file buffer
+        uint8_t* exact = (uint8_t*)malloc(g.size() ? g.size() : 1);
+        memcpy(exact, g.data(), g.size());
+        const int st = process(exact, g.size(), (it & 1) ? BU_READ_RGBA : BU_READ_ETC1);
+        free(exact);
+        st ? bad++ : ok++;
+    }
+    printf("fuzz done: %d parsed, %d rejected\n", ok, bad);
+    return 0;
+}
