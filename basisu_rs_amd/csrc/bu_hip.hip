@@ -150,12 +150,27 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     for (; tile < n_tiles; tile += gridDim.x) {
         const unsigned tbase = tile * BU_TILE;
         // ---- A: mode + rank within the mode (counting sort, pass 1) ----
+        // Rank within the mode = one LDS atomic per block.  64 lanes adding to ONE counter serialise, though, and that is
+        // exactly what coherent textures produce (flat regions: long runs of one mode).  A wave whose loads are each of a
+        // single mode therefore takes an aggregated path -- one atomic of 64 by lane 0 per load, rank = lane id -- chosen
+        // by a wave-uniform branch; every other wave runs the plain per-lane atomics unchanged.
         uint32_t mode[BU_BPT], pos[BU_BPT];
+        bool uniform = true;
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             const bool valid = tbase + j * BU_WG + tid < n_blocks;
             mode[j] = valid ? T.mode_lut[v[j].x & 127u] : 31u;
-            pos[j] = valid ? atomicAdd(&cnt[mode[j]], 1u) : 0u;
+            uniform = uniform && (__ballot(mode[j] == (uint32_t)__builtin_amdgcn_readfirstlane(mode[j])) == ~0ull) && mode[j] < 20u;
+        }
+        if (uniform) {
+            uint32_t lead[BU_BPT];
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) lead[j] = lane == 0 ? atomicAdd(&cnt[mode[j]], 64u) : 0u;
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) pos[j] = (uint32_t)__builtin_amdgcn_readfirstlane(lead[j]) + lane;
+        } else {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) pos[j] = mode[j] < 20u ? atomicAdd(&cnt[mode[j]], 1u) : 0u;
         }
         BU_STAMP(2)
         __syncthreads();

@@ -9,6 +9,18 @@
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
         stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = t_;        \
     }
+#define BU_CHUNK_DECL unsigned chunk_no_ = 0;
+// per-chunk stamps: slot k of chunk record n of this wave: [time, value]
+#define BU_CHUNK_STAMP(k, val)                                                                                     \
+    if (stamps && (threadIdx.x & 63u) == 0) {                                                                      \
+        unsigned long long t_;                                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                  \
+        unsigned long long* rec_ = stamps + ((size_t)gridDim.x * (blockDim.x >> 6)) * 16 +                          \
+                                   (((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 12 + (chunk_no_ % 12)) * 8; \
+        rec_[2 * (k)] = t_;                                                                                         \
+        rec_[2 * (k) + 1] = (unsigned long long)(val);                                                              \
+        if ((k) == 2) chunk_no_++;                                                                                  \
+    }
 #include "../../basisu_rs_amd/csrc/bu_hip.hip"
 
 namespace {
