@@ -192,9 +192,17 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             }
             const uint32_t st = incl - c, cst = cincl - nch;
             if (lane < 20) start[mo] = st;
-            for (uint32_t k = 0; k < nch; k++) {
-                const uint32_t left = c - 64u * k;
-                chunk[cst + k] = mo | ((st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
+            // chunk list: lanes l, l+20, l+40 share run l (k = 0,3,6.. / 1,4,7.. / 2,5,8..), so a tile made of one single
+            // mode (64 chunks in one run) costs 22 loop trips here instead of 64 while 15 other waves wait at the barrier
+            {
+                const int src = (int)(lane % 20u);
+                const uint32_t r_c = __shfl(c, src), r_st = __shfl(st, src), r_cst = __shfl(cst, src), r_mo = __shfl(mo, src);
+                const uint32_t r_nch = (r_c + 63u) >> 6;
+                if (lane < 60)
+                    for (uint32_t k = lane / 20u; k < r_nch; k += 3u) {
+                        const uint32_t left = r_c - 64u * k;
+                        chunk[r_cst + k] = r_mo | ((r_st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
+                    }
             }
             if (lane == 19) n_chunks = cincl;
             if (lane < 32) cnt[lane] = 0;
