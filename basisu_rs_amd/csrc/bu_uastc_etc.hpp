@@ -44,20 +44,19 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
     // every range is odd, so there are no .5 ties (tests/test_float_sites.py)
     const uint32_t num = (uint32_t)(2 * ((int)mn * (range + mm) - (int)mx * mm) + range);
     const int center = (int)((num * T.eac_magic[table]) >> 20);  // num <= 14791, 2*range <= 58: exact
-    int values[8];
+    // nearest of the 8 table values, first minimum wins (min_by_key): key = 8*|value - a| + index via v_sad_u32
+    uint32_t values8[8];
     BU_UNROLL
-    for (int k = 0; k < 8; k++) values[k] = bu_clampi(center + T.etc2_amod[8 * table + k] * mult, 0, 255);
+    for (int k = 0; k < 8; k++) values8[k] = 8u * (uint32_t)bu_clampi(center + T.etc2_amod[8 * table + k] * mult, 0, 255);
     uint64_t selectors = 0;
     BU_UNROLL
     for (int i = 0; i < 16; i++) {
-        const int a = (int)(px[i] >> 24);
-        uint32_t best = 0xFFFFFFFFu;
-        BU_UNROLL
-        for (int k = 0; k < 8; k++) {  // min_by_key keeps the first minimum: distance*8 + index
-            const int dlt = values[k] - a;
-            const uint32_t key = (uint32_t)(dlt < 0 ? -dlt : dlt) * 8u + (uint32_t)k;
-            best = key < best ? key : best;
-        }
+        const uint32_t a8 = (px[i] >> 24) * 8u;
+        const uint32_t k0 = bu_sad<0>(values8[0], a8), k1 = bu_sad<1>(values8[1], a8), k2 = bu_sad<2>(values8[2], a8), k3 = bu_sad<3>(values8[3], a8);
+        const uint32_t k4 = bu_sad<4>(values8[4], a8), k5 = bu_sad<5>(values8[5], a8), k6 = bu_sad<6>(values8[6], a8), k7 = bu_sad<7>(values8[7], a8);
+        const uint32_t m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3, m45 = k4 < k5 ? k4 : k5, m67 = k6 < k7 ? k6 : k7;
+        const uint32_t m03 = m01 < m23 ? m01 : m23, m47 = m45 < m67 ? m45 : m67;
+        const uint32_t best = m03 < m47 ? m03 : m47;
         const int id = (i % 4) * 4 + i / 4;  // column-major (etc.rs:324-327)
         selectors |= (uint64_t)(best & 7u) << (45 - 3 * id);
     }
@@ -66,14 +65,15 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
     out[1] = (slo >> 24) | (((slo >> 16) & 0xFFu) << 8) | (((slo >> 8) & 0xFFu) << 16) | ((slo & 0xFFu) << 24);
 }
 
-// apply_etc1_bias for one channel (etc.rs:236-255); delta in -2..1
+// apply_etc1_bias for one channel (etc.rs:236-255); delta in -2..1.  Branch-free: six of these per block would
+// otherwise be six divergent exec-mask regions.
 BU_DEV int bu_etc1_bias1(int v, int delta, int limit)
 {
-    if (v == 0) return v + (delta == -2 ? 3 : delta + 1);
-    if (v == limit) return v + delta - 1;
-    int r = v + delta;
-    if (r < 0 || r > limit) r = v - delta;
-    return r;
+    const int at0 = v + (delta == -2 ? 3 : delta + 1);
+    const int atl = v + delta - 1;
+    const int mid0 = v + delta;
+    const int mid = (mid0 < 0 || mid0 > limit) ? v - delta : mid0;
+    return v == 0 ? at0 : (v == limit ? atl : mid);
 }
 
 // out: ETC1 -> out[0..1]; ETC2 -> out[0..1] alpha, out[2..3] colour (etc.rs:19-30)
@@ -166,30 +166,42 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
         hdr |= (((i0 << 5) | (i1 << 2) | (d << 1) | f) & 0xFFu) << 24;  // etc.rs:151-158
         col[0] = hdr;
 
-        // luma thresholds per half (etc.rs:165-177)
-        int thr[2][3];
+        // luma thresholds per half (etc.rs:165-177).  The factors (108, 366, 38) are all even, so every luma is even:
+        // with lum = 2*L (L = 54r + 183g + 19b, one v_dot4_u32_u8) the reference's test lum >= (lum_a + lum_b)/2 is
+        // exactly L >= (L_a + L_b + 1) >> 1.
+        constexpr uint32_t LW = 54u | (183u << 8) | (19u << 16);
+        uint32_t thr[2][3];
         BU_UNROLL
         for (int sb = 0; sb < 2; sb++) {
             const uint32_t inten = sb ? i1 : i0;
-            int lum[4];
+            uint32_t lum[4];
             BU_UNROLL
             for (int k = 0; k < 4; k++) {
                 const int md = T.etc1_mod[inten * 4 + k];
-                lum[k] = bu_clampi(base[sb][0] + md, 0, 255) * 108 + bu_clampi(base[sb][1] + md, 0, 255) * 366 +
-                         bu_clampi(base[sb][2] + md, 0, 255) * 38;
+                const uint32_t cpk = (uint32_t)bu_clampi(base[sb][0] + md, 0, 255) | ((uint32_t)bu_clampi(base[sb][1] + md, 0, 255) << 8) |
+                                     ((uint32_t)bu_clampi(base[sb][2] + md, 0, 255) << 16);
+                lum[k] = bu_udot4(cpk, LW, 0u);
             }
-            thr[sb][0] = (lum[0] + lum[1]) >> 1;
-            thr[sb][1] = (lum[1] + lum[2]) >> 1;
-            thr[sb][2] = (lum[2] + lum[3]) >> 1;
+            thr[sb][0] = (lum[0] + lum[1] + 1u) >> 1;
+            thr[sb][1] = (lum[1] + lum[2] + 1u) >> 1;
+            thr[sb][2] = (lum[2] + lum[3] + 1u) >> 1;
+        }
+        // the top-right and bottom-left 2x2 quadrants change half with the flip bit: pick their thresholds once
+        uint32_t thq[4][3];
+        BU_UNROLL
+        for (int k = 0; k < 3; k++) {
+            thq[0][k] = thr[0][k];
+            thq[1][k] = f ? thr[0][k] : thr[1][k];  // x >= 2, y < 2
+            thq[2][k] = f ? thr[1][k] : thr[0][k];  // x < 2, y >= 2
+            thq[3][k] = thr[1][k];
         }
         uint32_t msbp = 0, lsbp = 0;  // bit pixel_id = x*4 + y (etc.rs:376-392)
         BU_UNROLL
         for (int i = 0; i < 16; i++) {
             const int y = i >> 2, x = i & 3;
-            const bool sb = f ? (y >= 2) : (x >= 2);
-            const int t0 = sb ? thr[1][0] : thr[0][0], t1 = sb ? thr[1][1] : thr[0][1], t2 = sb ? thr[1][2] : thr[0][2];
-            const int lum = (int)(px[i] & 0xFFu) * 108 + (int)((px[i] >> 8) & 0xFFu) * 366 + (int)((px[i] >> 16) & 0xFFu) * 38;
-            const uint32_t ge0 = lum >= t0, ge1 = lum >= t1, ge2 = lum >= t2;
+            const int q = ((y >> 1) << 1) | (x >> 1);
+            const uint32_t lum = bu_udot4(px[i], LW, 0u);
+            const uint32_t ge0 = lum >= thq[q][0], ge1 = lum >= thq[q][1], ge2 = lum >= thq[q][2];
             // sel = ge0+ge1+ge2; ETC1 code [3,2,0,1][sel]: high bit = sel<2, low bit = sel==0 || sel==3
             const uint32_t hi = ge1 ^ 1u, lo = (ge0 ^ 1u) | ge2;
             const int pid = x * 4 + y;

@@ -266,6 +266,30 @@ BU_DEV uint32_t bu_udot2(uint32_t a, uint32_t b, uint32_t c)
     return (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16) + c;
 #endif
 }
+// 4 x u8 dot product + accumulator (v_dot4_u32_u8)
+BU_DEV uint32_t bu_udot4(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    uint32_t r = c;
+    for (int k = 0; k < 4; k++) r += ((a >> (8 * k)) & 0xFFu) * ((b >> (8 * k)) & 0xFFu);
+    return r;
+#endif
+}
+// |a - b| + K with K a small literal (v_sad_u32).  Inline asm: left to itself hipcc expands the absolute difference
+// into max/min/sub (3 VALU) -- 8 candidates x 16 texels of those dominate the EAC search.
+template <int K>
+BU_DEV uint32_t bu_sad(uint32_t a, uint32_t b)
+{
+#if defined(__HIPCC__)
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(K));
+    return r;
+#else
+    return (a > b ? a - b : b - a) + (uint32_t)K;
+#endif
+}
 // bytes of a:b selected into one word (v_perm_b32): sel byte k picks byte (sel>>8k)&7 of {b (0-3), a (4-7)}, 0x0C = zero
 BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 {
