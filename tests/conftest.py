@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """a fresh checkout has no built artefacts (they are git-ignored): build the C-ABI library once, up front"""
+    from basisu_rs_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        from basisu_rs_amd import build
+
+        build.build_hip()
+
+
 def _make(path, target):
     if not os.path.exists(os.path.join(path, target)):
         subprocess.run(["make", "-C", path, target], check=True, capture_output=True)

@@ -255,3 +255,61 @@ def test_read_to_on_etc1s_files(ctx, oracle, kw):
     assert h.as_list() == hdr
     with pytest.raises(bu.BasisuError, match="not implemented"):
         bu.read_to_bc7(f, ctx)
+
+
+def test_config5_texture_array_full_size_on_device(ctx, golden):
+    """BASELINE config 5 at full size: 512 slices x (1024x1024 px = 65 536 blocks) = 33 554 432 blocks, 512 MiB in,
+    512 MiB out, generated and verified on the device (A-gold: expected output = known-answer output)."""
+    import torch
+
+    n = 512 * 65536
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    gb = torch.from_numpy(golden["bc7"]).cuda()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    idx = torch.randint(0, 608, (n,), device="cuda", generator=gen)
+    d_in = gu[idx].contiguous()
+    d_out = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    ctx.transcode_device(_lib.BC7, d_in, n, d_out, d_status=status)
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    ok = True
+    for lo in range(0, n, 1 << 22):  # compare in pieces to bound temporary memory
+        ok = ok and torch.equal(d_out[lo:lo + (1 << 22)], gb[idx[lo:lo + (1 << 22)]])
+    assert ok
+
+
+def test_launch_splitting_above_2_pow_26_blocks(ctx, golden):
+    """the kernels index with 32 bits; the host cuts larger inputs into launches of <= 2^26 blocks.  One block past the
+    limit, with an invalid block in the second piece to check that reported indices stay global."""
+    import torch
+
+    from basisu_rs_amd import BasisuError
+
+    n = (1 << 26) + 4097
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    gb = torch.from_numpy(golden["bc7"]).cuda()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(6)
+    idx = torch.randint(0, 608, (n,), device="cuda", generator=gen)
+    d_in = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    for lo in range(0, n, 1 << 22):  # torch's row gather rejects 2^26-row launches: build the input in pieces
+        d_in[lo:lo + (1 << 22)] = gu[idx[lo:lo + (1 << 22)]]
+    d_out = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    ctx.transcode_device(_lib.BC7, d_in, n, d_out, d_status=status)
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    for lo in (0, (1 << 26) - (1 << 20), n - (1 << 20)):
+        assert torch.equal(d_out[lo:lo + (1 << 20)], gb[idx[lo:lo + (1 << 20)]])
+    bad = (1 << 26) + 77
+    d_in[bad, 0] = 69
+    ctx.status_word_reset(status)
+    ctx.transcode_device(_lib.BC7, d_in, n, d_out, d_status=status)
+    torch.cuda.synchronize()
+    with pytest.raises(BasisuError, match="invalid mode index") as e:
+        ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    assert e.value.first_bad_block == bad
