@@ -9,5 +9,5 @@ echo "== pytest -m gpu" ; timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 
 echo "== smoke" ; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "== bench" ; timeout 900 python bench.py "$@" 2> gpurun_out/bench.err | tee gpurun_out/bench.json ; tail -5 gpurun_out/bench.err
 echo "== rocprofv3 kernel trace"
-rm -rf gpurun_out/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 200 --warmup 20 --no-cpu > gpurun_out/bench_prof.json 2> gpurun_out/prof.err
+rm -rf gpurun_out/prof && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 512 --warmup 64 --headline-only > gpurun_out/bench_prof.json 2> gpurun_out/prof.err
 find gpurun_out/prof -name "*kernel_stats*.csv" | head -2 | while read f; do echo "-- $f"; head -12 "$f"; done
