@@ -19,7 +19,7 @@ SYMBOLS = [
     "bu_uastc_transcode", "bu_uastc_decode_to_rgba",
     "bu_unpack_uastc_block_to_rgba", "bu_transcode_uastc_block_to_astc", "bu_transcode_uastc_block_to_bc7",
     "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2",
-    "bu_uastc_transcode_device", "bu_status_word_reset", "bu_status_word_decode",
+    "bu_uastc_transcode_device", "bu_status_word_reset", "bu_status_word_decode", "bu_host_alloc", "bu_host_free",
     "bu_etc1s_selector_from_rows", "bu_etc1s_transcode_etc1_device", "bu_etc1s_decode_rgba_device",
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
     "bu_basis_read_header", "bu_basis_read_slice_descs", "bu_basis_crc16", "bu_read_query", "bu_read_to", "bu_basislz_decode",
@@ -68,6 +68,12 @@ def load():
         raise RuntimeError(
             "basisu_rs_amd: %s is missing -- build it with `python -m basisu_rs_amd.build` "
             "(there is no CPU fallback)" % LIB_PATH)
+    try:
+        # PyTorch-ROCm ships its own libamdhip64.  Whichever HIP runtime is mapped first serves the whole process, and
+        # torch.cuda sees no devices when it is not torch's own -- so in a process that can import torch, import it first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, sz, u64p, u32 = c.c_void_p, c.c_size_t, c.POINTER(c.c_uint64), c.c_uint32
@@ -95,6 +101,10 @@ def load():
     lib.bu_status_word_reset.restype = c.c_int
     lib.bu_status_word_decode.argtypes = [c.c_uint64, u64p]
     lib.bu_status_word_decode.restype = c.c_int
+    lib.bu_host_alloc.argtypes = [vp, sz, c.POINTER(vp)]
+    lib.bu_host_alloc.restype = c.c_int
+    lib.bu_host_free.argtypes = [vp, vp]
+    lib.bu_host_free.restype = c.c_int
     lib.bu_etc1s_selector_from_rows.argtypes = [vp, vp]
     lib.bu_etc1s_selector_from_rows.restype = None
     lib.bu_etc1s_transcode_etc1_device.argtypes = [vp, vp, sz, vp, u32, vp, u32, vp, vp, vp]

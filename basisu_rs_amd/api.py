@@ -55,9 +55,13 @@ class Context:
             raise BasisuError(st)
         self._h = h
         self.device = int(device)
+        self._pinned = {}
 
     def close(self):
         if getattr(self, "_h", None):
+            for addr in list(getattr(self, "_pinned", {}).values()):
+                self._lib.bu_host_free(self._h, addr)
+            self._pinned = {}
             self._lib.bu_context_destroy(self._h)
             self._h = None
 
@@ -80,21 +84,41 @@ class Context:
         raise BasisuError(st, bad.value if bad is not None and st in (_lib.ERR_INVALID_MODE, _lib.ERR_INVALID_PATTERN, _lib.ERR_INDEX_RANGE) else None, detail)
 
     # ---- host-pointer slice API -----------------------------------------------------------------
-    def transcode(self, fmt, data):
-        """uastc::Decoder::transcode (uastc.rs:112-121): bytes in -> bytes out."""
+    def host_alloc(self, nbytes):
+        """A page-locked uint8 buffer (bu_host_alloc).  Slices handed to transcode()/decode_to_rgba() in such
+        buffers (input and `out=`) stream over PCIe with upload, kernels and download overlapped.  The memory
+        lives until host_free(buffer) or close()."""
+        p = ctypes.c_void_p(0)
+        self._check(self._lib.bu_host_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        if not p.value:
+            return np.empty(0, dtype=np.uint8)
+        arr = np.ctypeslib.as_array((ctypes.c_uint8 * int(nbytes)).from_address(p.value))
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        addr = self._pinned.pop(arr.ctypes.data, None)
+        if addr is not None:
+            self._check(self._lib.bu_host_free(self._h, addr))
+
+    def transcode(self, fmt, data, out=None):
+        """uastc::Decoder::transcode (uastc.rs:112-121): bytes in -> bytes out.  `out` (optional) is a caller
+        buffer of at least n_blocks * block_bytes, e.g. from host_alloc()."""
         a = _as_u8(data)
         n = a.size // 16
-        out = np.empty(max(n, 1) * _lib.BLOCK_BYTES[int(fmt)], dtype=np.uint8)
+        if out is None:
+            out = np.empty(max(n, 1) * _lib.BLOCK_BYTES[int(fmt)], dtype=np.uint8)
         bad = ctypes.c_uint64(0)
         st = self._lib.bu_uastc_transcode(self._h, int(fmt), a.ctypes.data, a.size, out.ctypes.data, out.size, ctypes.byref(bad))
         self._check(st, bad)
         return out[: n * _lib.BLOCK_BYTES[int(fmt)]]
 
-    def decode_to_rgba(self, data, blocks_per_row):
+    def decode_to_rgba(self, data, blocks_per_row, out=None):
         """uastc::Decoder::decode_to_rgba (uastc.rs:89-110): row-major RGBA8 bytes."""
         a = _as_u8(data)
         n = a.size // 16
-        out = np.empty(max(n, 1) * 64, dtype=np.uint8)
+        if out is None:
+            out = np.empty(max(n, 1) * 64, dtype=np.uint8)
         bad = ctypes.c_uint64(0)
         st = self._lib.bu_uastc_decode_to_rgba(self._h, a.ctypes.data, a.size, int(blocks_per_row), out.ctypes.data, out.size, ctypes.byref(bad))
         self._check(st, bad)

@@ -492,8 +492,13 @@ bu_status bu_reserve(bu_context* ctx, void** p, size_t* cap, size_t need)
     return BU_OK;
 }
 
+// workgroups of the zero-copy launches: enough loads in flight to cover PCIe latency, few enough that every workgroup
+// walks many tiles and reads overlap writes (measured on a 4096^2 atlas: 16 -> 0.52 ms, 64 -> 0.47, 256 -> 0.54, 1024 -> 0.56)
+constexpr unsigned BU_ZEROCOPY_GRID = 64;
+
+// grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
-                          uint64_t base, uint64_t* d_status, hipStream_t stream)
+                          uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0)
 {
     if (n_blocks == 0) return BU_OK;
     const unsigned grid = bu_grid_for(n_blocks, ctx->cu_count);
@@ -512,7 +517,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const uint4* pin = in + done;
             void* pout = static_cast<uint8_t*>(d_out) + done * obytes;  // RGBA32: done is a multiple of bpr -> whole rows
             const size_t tiles = (nb + BU_TILE - 1) / BU_TILE;
-            const size_t cap = (size_t)ctx->cu_count * 7;
+            const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * 7;
             const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
             const unsigned long long pbase = base + done;
             // large inputs: 4096-block tiles (1024 threads x 4) -- longer per-mode runs, so the <= 64-block chunks
@@ -524,7 +529,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     else                                                                                                                                \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
-            const bool big = target != BU_TARGET_RGBA32 && nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
+            const bool big = grid_cap == 0 && target != BU_TARGET_RGBA32 && nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
             const size_t btiles = (nb + 4095) / 4096;
             const unsigned bgrid = (unsigned)(btiles < (size_t)ctx->cu_count * 2 ? btiles : (size_t)ctx->cu_count * 2);
             switch (target) {
@@ -535,7 +540,8 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
                 // 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows) so the image
                 // rows leave as coalesced 1 KiB stores; one 1024-thread workgroup per CU walks its tiles with prefetch
                 const size_t rtiles = (nb + 1023) / 1024;
-                const unsigned rgrid = (unsigned)(rtiles < (size_t)ctx->cu_count ? rtiles : (size_t)ctx->cu_count);
+                const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count;
+                const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
                 hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 1024, 1, 1, true, false>), dim3(rgrid), dim3(1024), 0, stream, pin, pout, (unsigned)nb,
                                    (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
             } break;
@@ -558,6 +564,19 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     return BU_OK;
 }
 
+// device-side address of a page-locked host buffer; false for ordinary (pageable) memory
+bool bu_device_view(const void* p, void** dev)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory reports an error on some runtimes: not sticky
+        return false;
+    }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    *dev = a.devicePointer;
+    return true;
+}
+
 // host-pointer UASTC driver shared by transcode / decode_to_rgba / the per-block API
 bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, size_t in_bytes, size_t bpr, uint8_t* out,
                         size_t out_bytes, uint64_t* first_bad)
@@ -572,18 +591,36 @@ bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, si
     if (n == 0) return BU_OK;
     std::lock_guard<std::mutex> g(ctx->lock);
     BU_HIP(ctx, hipSetDevice(ctx->device));
-    bu_status st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, in_bytes);
+    bu_status st;
+    // Page-locked caller buffers (bu_host_alloc, or anything the caller page-locked with the HIP runtime) are visible to
+    // the GPU: the kernels read the slice and write the result straight over PCIe -- no staging copies at all.  A small
+    // persistent grid walks the tiles with prefetch, so tile k's posted writes travel upstream while tile k+1's reads
+    // come down (PCIe is full duplex): 0.47 ms per 4096^2 atlas against 0.69 ms for upload + kernel + download.
+    // Ordinary pageable memory cannot be mapped; it takes the staged path below.
+    {
+        void *zin = nullptr, *zout = nullptr;
+        if (bu_device_view(in, &zin) && bu_device_view(out, &zout)) {
+            uint64_t zword = 0;
+            BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
+            st = bu_launch_uastc(ctx, target, zin, n, zout, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream, BU_ZEROCOPY_GRID);
+            if (st) return st;
+            BU_HIP(ctx, hipMemcpyAsync(&zword, ctx->d_status, sizeof(zword), hipMemcpyDeviceToHost, ctx->stream));
+            BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return bu_status_word_decode(zword, first_bad);
+        }
+    }
+    st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, in_bytes);
     if (st) return st;
     // RGBA32: a ragged last block-row still writes whole rows of the image the caller sized as 64*n
     size_t out_need = n * bb;
     if (target == BU_TARGET_RGBA32) out_need = ((n + bpr - 1) / bpr) * bpr * 64;
     st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, out_need);
     if (st) return st;
+    uint64_t word = 0;
     BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
     st = bu_launch_uastc(ctx, target, ctx->d_in, n, ctx->d_out, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream);
     if (st) return st;
-    uint64_t word = 0;
     BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -700,6 +737,25 @@ bu_status bu_status_word_decode(uint64_t word, uint64_t* first_bad_block)
     if (word == BU_STATUS_WORD_CLEAR) return BU_OK;
     if (first_bad_block) *first_bad_block = word >> 8;
     return static_cast<bu_status>(word & 0xFFu);
+}
+
+bu_status bu_host_alloc(bu_context* ctx, size_t bytes, void** out_ptr)
+{
+    if (!ctx || !out_ptr) return BU_ERR_ARGUMENT;
+    *out_ptr = nullptr;
+    if (bytes == 0) return BU_OK;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    BU_HIP(ctx, hipHostMalloc(out_ptr, bytes, hipHostMallocDefault));
+    return BU_OK;
+}
+
+bu_status bu_host_free(bu_context* ctx, void* ptr)
+{
+    if (!ctx) return BU_ERR_ARGUMENT;
+    if (!ptr) return BU_OK;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    BU_HIP(ctx, hipHostFree(ptr));
+    return BU_OK;
 }
 
 bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,

@@ -118,6 +118,16 @@ bu_status bu_status_word_reset(bu_context* ctx, uint64_t* d_status, void* stream
 /* decode a status word copied back to the host */
 bu_status bu_status_word_decode(uint64_t word, uint64_t* first_bad_block);
 
+/* ---- page-locked host buffers ---------------------------------------------------------------------
+ * The reference's entry points take and return ordinary slices (`&[u8]` in, `Vec<u8>` out, uastc.rs:112);
+ * over PCIe the two copies are the whole cost of a call.  When BOTH buffers handed to
+ * bu_uastc_transcode / bu_uastc_decode_to_rgba come from bu_host_alloc() (or were page-locked by the
+ * caller through the HIP runtime), the kernels read the slice and write the result directly over PCIe --
+ * no staging copies, reads and writes overlapped.  Ordinary pageable memory keeps working through
+ * device staging buffers. */
+bu_status bu_host_alloc(bu_context* ctx, size_t bytes, void** out_ptr);
+bu_status bu_host_free(bu_context* ctx, void* ptr);
+
 /* ---- ETC1S block back-end (basis_lz/mod.rs:97-186) ---------------------------------------------
  * The serial BasisLZ entropy decode stays on the host and produces, per block in raster order,
  *   idx[i] = endpoint_index | selector_index << 16          (DecodedBlock, basis_lz/mod.rs:43-48)

@@ -313,3 +313,43 @@ def test_launch_splitting_above_2_pow_26_blocks(ctx, golden):
     with pytest.raises(BasisuError, match="invalid mode index") as e:
         ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
     assert e.value.first_bad_block == bad
+
+
+def test_page_locked_buffers_take_the_zero_copy_path_with_identical_results(ctx, golden):
+    """bu_host_alloc buffers: the kernels read and write host memory directly (no staging), on a small persistent grid.
+    Same bytes as the staged path, same lowest-failing-block semantics, RGBA32 row addressing, tiny and ragged sizes."""
+    from basisu_rs_amd import BasisuError
+
+    n = (1 << 19) + 4097  # ragged tail
+    idx = synth.gold_indices(n, seed=11)
+    pin_in = ctx.host_alloc(n * 16)
+    pin_in[:] = golden["uastc"][idx].reshape(-1)
+    for t in ("bc7", "etc1", "astc", "etc2"):
+        bb = golden[t].shape[1]
+        pin_out = ctx.host_alloc(n * bb)
+        pin_out[:] = 0xAA
+        out = ctx.transcode(FMT[t], pin_in, out=pin_out)
+        assert out.ctypes.data == pin_out.ctypes.data
+        assert (out.reshape(n, bb) == golden[t][idx]).all(), t
+        ctx.host_free(pin_out)
+    for m in (1, 63, 2047, 2049):  # below / around the sorted-kernel threshold
+        pin_out = ctx.host_alloc(m * 16)
+        assert (ctx.transcode(FMT["bc7"], pin_in[: m * 16], out=pin_out).reshape(m, 16) == golden["bc7"][idx[:m]]).all(), m
+        ctx.host_free(pin_out)
+    # RGBA32 with a row pitch that is not a multiple of anything convenient
+    nbx, nby = 1000, 525
+    m = nbx * nby
+    pin_rgba = ctx.host_alloc(m * 64)
+    img = ctx.decode_to_rgba(pin_in[: m * 16], nbx, out=pin_rgba).reshape(nby, 4, nbx, 16)
+    lin = np.ascontiguousarray(img.transpose(0, 2, 1, 3)).reshape(m, 64)
+    assert (lin == golden["rgba"][idx[:m]]).all()
+    ctx.host_free(pin_rgba)
+    # errors far apart (different workgroups): the lowest block index is reported, as the reference's sequential loop would
+    bad = synth.atlas_err(golden["uastc"], n, [400000, 140001, 300000])
+    pin_in[:] = bad.reshape(-1)
+    pin_out = ctx.host_alloc(n * 16)
+    with pytest.raises(BasisuError) as ex:
+        ctx.transcode(FMT["bc7"], pin_in, out=pin_out)
+    assert ex.value.first_bad_block == 140001
+    ctx.host_free(pin_out)
+    ctx.host_free(pin_in)
