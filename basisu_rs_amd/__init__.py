@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     crc16,
     etc1s_selector_from_rows,
     read_header,
+    read_query,
     read_slice_descs,
     read_to_astc,
     read_to_bc7,

@@ -255,42 +255,54 @@ def crc16(data, crc=0):
     return _lib.load().bu_basis_crc16(a.ctypes.data, a.size, crc)
 
 
-def _read_to(target, buf, ctx=None):
+def read_query(target, buf):
+    """(number of images, total output bytes) a read_to_* call on this file produces (bu_read_query; host only)"""
+    lib = _lib.load()
+    a = _as_u8(buf)
+    n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _check_host(lib.bu_read_query(int(target), a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb)))
+    return n.value, nb.value
+
+
+def _read_to(target, buf, ctx=None, out=None):
+    """`out`: optional caller buffer of at least read_query()[1] bytes; one from Context.host_alloc() is written by the
+    kernels directly over PCIe (no device output buffer, no download)."""
     lib = _lib.load()
     a = _as_u8(buf)
     n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
     _check_host(lib.bu_read_query(target, a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb)))
     c = ctx or default_context()
     imgs = (_lib.ImageDesc * max(n.value, 1))()
-    out = np.empty(max(nb.value, 1), dtype=np.uint8)
+    if out is None:
+        out = np.empty(max(nb.value, 1), dtype=np.uint8)
     h = _lib.BasisHeader()
     st = lib.bu_read_to(c.handle, target, a.ctypes.data, a.size, ctypes.byref(h), imgs, n.value, ctypes.byref(n), out.ctypes.data, out.size)
     c._check(st)
     return h, [Image(im.w, im.h, im.stride, out[im.offset:im.offset + im.size]) for im in imgs[: n.value]]
 
 
-def read_to_rgba(buf, ctx=None):  # basis.rs:8-90 -> (Header, Vec<Image<u8>>)
-    return _read_to(_lib.READ_RGBA, buf, ctx)
+def read_to_rgba(buf, ctx=None, out=None):  # basis.rs:8-90 -> (Header, Vec<Image<u8>>)
+    return _read_to(_lib.READ_RGBA, buf, ctx, out)
 
 
-def read_to_etc1(buf, ctx=None):  # basis.rs:92-143
-    return _read_to(_lib.READ_ETC1, buf, ctx)[1]
+def read_to_etc1(buf, ctx=None, out=None):  # basis.rs:92-143
+    return _read_to(_lib.READ_ETC1, buf, ctx, out)[1]
 
 
-def read_to_etc2(buf, ctx=None):  # basis.rs:145-173
-    return _read_to(_lib.READ_ETC2, buf, ctx)[1]
+def read_to_etc2(buf, ctx=None, out=None):  # basis.rs:145-173
+    return _read_to(_lib.READ_ETC2, buf, ctx, out)[1]
 
 
-def read_to_uastc(buf, ctx=None):  # basis.rs:175-202
-    return _read_to(_lib.READ_UASTC, buf, ctx)[1]
+def read_to_uastc(buf, ctx=None, out=None):  # basis.rs:175-202
+    return _read_to(_lib.READ_UASTC, buf, ctx, out)[1]
 
 
-def read_to_astc(buf, ctx=None):  # basis.rs:204-231
-    return _read_to(_lib.READ_ASTC, buf, ctx)[1]
+def read_to_astc(buf, ctx=None, out=None):  # basis.rs:204-231
+    return _read_to(_lib.READ_ASTC, buf, ctx, out)[1]
 
 
-def read_to_bc7(buf, ctx=None):  # basis.rs:233-260
-    return _read_to(_lib.READ_BC7, buf, ctx)[1]
+def read_to_bc7(buf, ctx=None, out=None):  # basis.rs:233-260
+    return _read_to(_lib.READ_BC7, buf, ctx, out)[1]
 
 
 def basislz_decode(buf, slice_index=None):

@@ -573,6 +573,7 @@ bool bu_device_view(const void* p, void** dev)
         return false;
     }
     if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    if (reinterpret_cast<uintptr_t>(a.devicePointer) % 16 != 0) return false;  // the kernels move 16-byte vectors
     *dev = a.devicePointer;
     return true;
 }
@@ -1020,11 +1021,14 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
     std::lock_guard<std::mutex> g(ctx->lock);
     BU_HIP(ctx, hipSetDevice(ctx->device));
     if ((st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, total_in ? total_in : 16))) return st;
-    if ((st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, p.out_bytes ? p.out_bytes : 16))) return st;
+    // a page-locked `out` (bu_host_alloc) receives the kernels' stores directly over PCIe: no device output buffer, no download
+    void* zout = nullptr;
+    const bool direct_out = bu_device_view(out, &zout);
+    if (!direct_out && (st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, p.out_bytes ? p.out_bytes : 16))) return st;
     const size_t ep_bytes = p.etc1s ? align_up(lz.endpoints.size() * 4) : 0, sel_bytes = p.etc1s ? align_up(lz.selectors.size()) : 0;
     if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + 8 * n_img + 256))) return st;
     uint8_t* d_in = static_cast<uint8_t*>(ctx->d_in);
-    uint8_t* d_out = static_cast<uint8_t*>(ctx->d_out);
+    uint8_t* d_out = direct_out ? static_cast<uint8_t*>(zout) : static_cast<uint8_t*>(ctx->d_out);
     uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
     uint64_t* d_status = reinterpret_cast<uint64_t*>(aux + ep_bytes + sel_bytes);
     BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, 8 * n_img, ctx->stream));
@@ -1055,13 +1059,14 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
                                  : target == BU_READ_BC7  ? BU_TARGET_BC7
                                  : target == BU_READ_ETC1 ? BU_TARGET_ETC1
                                                           : BU_TARGET_ETC2;
-            st = bu_launch_uastc(ctx, bt, d_in + in_off[k], s.file_size / 16, d_out + im.offset, s.num_blocks_x ? s.num_blocks_x : 1, 0, d_status + k, ctx->stream);
+            st = bu_launch_uastc(ctx, bt, d_in + in_off[k], s.file_size / 16, d_out + im.offset, s.num_blocks_x ? s.num_blocks_x : 1, 0, d_status + k, ctx->stream,
+                                 direct_out ? BU_ZEROCOPY_GRID : 0);
         }
         if (st) return st;
     }
     std::vector<uint64_t> words(n_img, 0);
     BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
-    if (p.out_bytes) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t k = 0; k < n_img; k++) {  // first Err (in slice order) aborts the whole call, like the `?` in the reference drivers
         st = bu_status_word_decode(words[k], nullptr);

@@ -224,6 +224,15 @@ def test_read_to_all_targets_on_a_uastc_file(ctx, golden, oracle):
         _images_equal(fn(f), want)
     h, _ = bu.read_to_rgba(f, ctx)
     assert h.as_list() == oracle.read_to("rgba", f)[1]
+    # the same calls into one page-locked output buffer: the kernels store straight into it (no device output, no download)
+    pinned = ctx.host_alloc(max(bu.read_query(t, f)[1] for t in range(6)))
+    for name, fn in (("rgba", lambda o: bu.read_to_rgba(f, ctx, out=o)[1]), ("etc1", lambda o: bu.read_to_etc1(f, ctx, out=o)),
+                     ("bc7", lambda o: bu.read_to_bc7(f, ctx, out=o)), ("astc", lambda o: bu.read_to_astc(f, ctx, out=o))):
+        pinned[:] = 0x5A
+        got = fn(pinned)
+        assert got[0].data.ctypes.data == pinned.ctypes.data
+        _images_equal(got, oracle.read_to(name, f)[2])
+    ctx.host_free(pinned)
     # a bad block inside slice 1 aborts the whole call with the reference's message
     blocks[1] = blocks[1].copy()
     blocks[1][7, 0] = 69
@@ -253,6 +262,9 @@ def test_read_to_on_etc1s_files(ctx, oracle, kw):
     h, got = bu.read_to_rgba(f, ctx)
     _images_equal(got, want)
     assert h.as_list() == hdr
+    pinned = ctx.host_alloc(bu.read_query(0, f)[1])
+    _images_equal(bu.read_to_rgba(f, ctx, out=pinned)[1], want)  # page-locked output, written by the kernel directly
+    ctx.host_free(pinned)
     with pytest.raises(bu.BasisuError, match="not implemented"):
         bu.read_to_bc7(f, ctx)
 
