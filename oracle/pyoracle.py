@@ -137,3 +137,42 @@ class Oracle:
         self.lib.bu_oracle_etc1s_to_rgba(idx16.ctypes.data, None if a16 is None else a16.ctypes.data, nbx, nby, ep.ctypes.data,
                                          sel.ctypes.data, out.ctypes.data)
         return out
+
+
+class Decoders:
+    """ctypes view of oracle/libbu_decoders.so: independent ASTC / BC7 / EAC decoders (bu_decoders.c) -- test-only."""
+
+    def __init__(self):
+        _make(os.path.join(ROOT, "oracle"), "libbu_decoders.so")
+        self.lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libbu_decoders.so"))
+        L, c = self.lib, ctypes
+        L.bu_dec_astc_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+        L.bu_dec_astc_batch.restype = None
+        L.bu_dec_bc7_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+        L.bu_dec_bc7_batch.restype = None
+        L.bu_dec_eac_batch.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_void_p]
+        L.bu_dec_eac_batch.restype = None
+        L.bu_dec_astc_partition_4x4.argtypes = [c.c_int] * 4
+        L.bu_dec_bc7_subset.argtypes = [c.c_int] * 3
+        L.bu_dec_bc7_anchor.argtypes = [c.c_int] * 3
+
+    def _batch(self, fn, blocks):
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
+        out = np.zeros((blocks.shape[0], 64), dtype=np.uint8)
+        st = np.zeros(blocks.shape[0], dtype=np.uint8)
+        fn(blocks.ctypes.data, blocks.shape[0], out.ctypes.data, st.ctypes.data)
+        return out, st
+
+    def astc(self, blocks):
+        """[n,16] ASTC 4x4 LDR blocks -> ([n,64] RGBA8 row-major texels, status[n])"""
+        return self._batch(self.lib.bu_dec_astc_batch, blocks)
+
+    def bc7(self, blocks):
+        return self._batch(self.lib.bu_dec_bc7_batch, blocks)
+
+    def eac_alpha(self, etc2_blocks):
+        """[n,16] ETC2 RGBA blocks -> [n,16] alpha of the EAC half, row-major texels"""
+        b = np.ascontiguousarray(etc2_blocks, dtype=np.uint8).reshape(-1, 16)
+        out = np.zeros((b.shape[0], 16), dtype=np.uint8)
+        self.lib.bu_dec_eac_batch(b.ctypes.data, 16, b.shape[0], out.ctypes.data)
+        return out
