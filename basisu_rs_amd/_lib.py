@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbasisu_hip.so")
+LIB_PATH = os.environ.get("BASISU_HIP_LIB") or os.path.join(HERE, "libbasisu_hip.so")  # the override exists for A/B kernel experiments (tools/exp)
 
 # bu_target
 ASTC, BC7, ETC1, ETC2, RGBA32 = 0, 1, 2, 3, 4

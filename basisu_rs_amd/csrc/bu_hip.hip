@@ -41,6 +41,28 @@ __device__ __forceinline__ void bu_report(unsigned long long* status, unsigned l
     if (status) atomicMin(status, (block << 8) | (unsigned long long)st);
 }
 
+// Every block is read once and every result written once: non-temporal (streaming) accesses keep the 32 MiB of a 4096^2
+// atlas from being allocated in L2 / Infinity Cache with normal retention.  Measured on the BC7 headline: 14.4 -> 13.7 us.
+typedef unsigned int bu_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int bu_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 bu_ld_stream(const uint4* p)
+{
+    const bu_v4u r = __builtin_nontemporal_load(reinterpret_cast<const bu_v4u*>(p));
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ void bu_st_stream(uint4* p, const uint4 v)
+{
+    bu_v4u r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    __builtin_nontemporal_store(r, reinterpret_cast<bu_v4u*>(p));
+}
+__device__ __forceinline__ void bu_st_stream(uint2* p, const uint2 v)
+{
+    bu_v2u r;
+    r.x = v.x; r.y = v.y;
+    __builtin_nontemporal_store(r, reinterpret_cast<bu_v2u*>(p));
+}
+
 // UASTC -> {ASTC, BC7, ETC1, ETC2, RGBA32}: replaces the loop of uastc.rs:157-165 / 96-107
 template <int TARGET>
 __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
@@ -51,7 +73,7 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
     const size_t stride = (size_t)gridDim.x * BU_WG;
     size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x;
     // first block load is issued before the table copy so both are in flight together
-    uint4 v = idx < n_blocks ? in[idx] : make_uint4(0, 0, 0, 0);
+    uint4 v = idx < n_blocks ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     bu_stage_tables(T, tables);
     __syncthreads();
     while (idx < n_blocks) {
@@ -103,6 +125,7 @@ constexpr unsigned long long BU_COST_ORDER_LO = 0x2996161c4482643ull, BU_COST_OR
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 
+
 template <int WGS>
 __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
 {
@@ -141,7 +164,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++) {
         const unsigned idx = tile * BU_TILE + j * BU_WG + tid;
-        v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+        v[j] = (tile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
     bu_stage_tables_n<WGS>(T, tables);
     if (tid < 32) cnt[tid] = 0;
@@ -227,7 +250,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
-                vn[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+                vn[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
         __syncthreads();
@@ -305,11 +328,11 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                         const unsigned by = idx / bpr, bx = idx - by * bpr;
                         uint4* img = reinterpret_cast<uint4*>(out);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) img[(size_t)((4 * by + r) * bpr + bx)] = sout[r * BU_TILE + dest[j]];
+                        for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)((4 * by + r) * bpr + bx), sout[r * BU_TILE + dest[j]]);
                     } else {
                         const uint4 r = sblk[dest[j]];
-                        if constexpr (TARGET == BU_TGT_ETC1) reinterpret_cast<uint2*>(out)[idx] = make_uint2(r.x, r.y);
-                        else reinterpret_cast<uint4*>(out)[idx] = r;
+                        if constexpr (TARGET == BU_TGT_ETC1) bu_st_stream(reinterpret_cast<uint2*>(out) + idx, make_uint2(r.x, r.y));
+                        else bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
                     }
                 }
             }
@@ -321,7 +344,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
-                v[j] = (ntile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
+                v[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
         __syncthreads();
@@ -333,7 +356,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 __global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * BU_WG;
-    for (size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x; idx < n; idx += stride) out[idx] = in[idx];
+    for (size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x; idx < n; idx += stride) bu_st_stream(out + idx, bu_ld_stream(in + idx));  // same streaming hints as the transcoders
+
 }
 
 // ---- ETC1S back-end ----------------------------------------------------------------------------
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_etc1_kernel(const uint32_t* __
 {
     const size_t stride = (size_t)gridDim.x * BU_WG;
     for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
-        const uint32_t ix = idx[i];
+        const uint32_t ix = __builtin_nontemporal_load(idx + i);  // streamed once; the codebook gathers below stay cached
         const uint32_t e = ix & 0xFFFFu, s = ix >> 16;
         uint2 o = make_uint2(0, 0);
         if (e >= n_ep || s >= n_sel) {
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_etc1_kernel(const uint32_t* __
             o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
             o.y = selectors[s].y;
         }
-        out[i] = o;
+        bu_st_stream(out + i, o);
     }
 }
 
@@ -388,12 +412,12 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * BU_WG;
     for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
-        const uint32_t ix = idx[i];
+        const uint32_t ix = __builtin_nontemporal_load(idx + i);
         const uint32_t e = ix & 0xFFFFu, s = ix >> 16;
         uint32_t ae = 0, as = 0;
         bool bad = e >= n_ep || s >= n_sel;
         if (aidx) {
-            const uint32_t ax = aidx[i];
+            const uint32_t ax = __builtin_nontemporal_load(aidx + i);
             ae = ax & 0xFFFFu;
             as = ax >> 16;
             bad = bad || ae >= n_ep || as >= n_sel;
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
         }
         const size_t by = i / nbx, bx = i - by * nbx;
 #pragma unroll
-        for (int r = 0; r < 4; r++) out[(4 * by + r) * (size_t)nbx + bx] = make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]);
+        for (int r = 0; r < 4; r++) bu_st_stream(out + (4 * by + r) * (size_t)nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
     }
 }
 
