@@ -124,6 +124,23 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 constexpr unsigned long long BU_COST_ORDER_LO = 0x2996161c4482643ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
+// The large-input configuration: 512 threads x 4 blocks = 2048-block tiles, two workgroups resident per CU (16 waves, 80 KiB
+// of LDS).  Measured on the BC7 headline (A/B inside one run, tools/exp/ab.sh): 1024x4 one per CU 13.65 us, 512x4 12.80,
+// 256x4 13.80, 512x8 16.2, 1024x2 15.9, 256x8 15.7 -- two half-size workgroups per CU overlap each other's barrier- and
+// latency-bound sort phases, while the <= 64-block chunks stay as full as with 4096-block tiles (108 blocks per mode).
+#ifndef BU_BIG_WGS
+#define BU_BIG_WGS 512
+#define BU_BIG_BPT 4
+#endif
+#ifndef BU_BIG_WG_PER_CU
+#define BU_BIG_WG_PER_CU 2
+#endif
+// the second half of a big launch starts ~1 us late (s_sleep 40 = 2560 cycles): the two workgroups sharing a CU then sit
+// in different phases instead of marching in lockstep (12.78 -> 12.65 us; 0 -> 12.78, 10 -> 12.70, 80 -> 13.6, 127 -> 14.1)
+#ifndef BU_BIG_SKEW
+#define BU_BIG_SKEW 40
+#endif
+constexpr int BU_BIG_TILE = BU_BIG_WGS * BU_BIG_BPT;
 
 
 template <int WGS>
@@ -142,12 +159,15 @@ __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables*
 // DIRECT: results are stored to global memory straight from the chunk loop at the block's original
 // index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
 // RGBA32 (64 B per block do not fit a second LDS tile; `bpr` = blocks per image row).
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA)>
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTables* __restrict__ tables BU_STAMP_ARG)
 {
     BU_STAMP(0)
+    if constexpr (SKEW > 0) {
+        if (blockIdx.x >= gridDim.x / 2 && gridDim.x > 1) __builtin_amdgcn_s_sleep(SKEW);
+    }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
     __shared__ BuTables T;
     __shared__ uint4 sblk[BU_TILE];
@@ -544,18 +564,17 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * 7;
             const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
             const unsigned long long pbase = base + done;
-            // large inputs: 4096-block tiles (1024 threads x 4) -- longer per-mode runs, so the <= 64-block chunks
-            // are fuller (96 % vs 84 %) and the table blob is staged 4x less often; measured 14.1 vs 15.3 us at 2^20 blocks
+            // large inputs: the BU_BIG_* configuration (2048-block tiles, two workgroups per CU), see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
     if (big)                                                                                                                            \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 4, 1, false>), dim3(bgrid), dim3(1024), 0, stream, pin, pout, (unsigned)nb, \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_BIG_WGS, BU_BIG_BPT, 1, false, false, BU_BIG_SKEW>), dim3(bgrid), dim3(BU_BIG_WGS), 0, stream, pin, pout, (unsigned)nb, \
                            (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                                      \
     else                                                                                                                                \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
             const bool big = grid_cap == 0 && target != BU_TARGET_RGBA32 && nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
-            const size_t btiles = (nb + 4095) / 4096;
-            const unsigned bgrid = (unsigned)(btiles < (size_t)ctx->cu_count * 2 ? btiles : (size_t)ctx->cu_count * 2);
+            const size_t btiles = (nb + BU_BIG_TILE - 1) / BU_BIG_TILE;
+            const unsigned bgrid = (unsigned)(btiles < (size_t)ctx->cu_count * BU_BIG_WG_PER_CU ? btiles : (size_t)ctx->cu_count * BU_BIG_WG_PER_CU);
             switch (target) {
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
