@@ -135,6 +135,9 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 #ifndef BU_BIG_WG_PER_CU
 #define BU_BIG_WG_PER_CU 2
 #endif
+#ifndef BU_BIG_MINW
+#define BU_BIG_MINW 1
+#endif
 // the second half of a big launch starts ~1 us late (s_sleep 40 = 2560 cycles): the two workgroups sharing a CU then sit
 // in different phases instead of marching in lockstep (12.78 -> 12.65 us; 0 -> 12.78, 10 -> 12.70, 80 -> 13.6, 127 -> 14.1)
 #ifndef BU_BIG_SKEW
@@ -567,7 +570,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             // large inputs: the BU_BIG_* configuration (2048-block tiles, two workgroups per CU), see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
     if (big)                                                                                                                            \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_BIG_WGS, BU_BIG_BPT, 1, false, false, BU_BIG_SKEW>), dim3(bgrid), dim3(BU_BIG_WGS), 0, stream, pin, pout, (unsigned)nb, \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_BIG_WGS, BU_BIG_BPT, BU_BIG_MINW, false, false, BU_BIG_SKEW>), dim3(bgrid), dim3(BU_BIG_WGS), 0, stream, pin, pout, (unsigned)nb, \
                            (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                                      \
     else                                                                                                                                \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
@@ -637,36 +640,34 @@ bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, si
     BU_HIP(ctx, hipSetDevice(ctx->device));
     bu_status st;
     // Page-locked caller buffers (bu_host_alloc, or anything the caller page-locked with the HIP runtime) are visible to
-    // the GPU: the kernels read the slice and write the result straight over PCIe -- no staging copies at all.  A small
-    // persistent grid walks the tiles with prefetch, so tile k's posted writes travel upstream while tile k+1's reads
-    // come down (PCIe is full duplex): 0.47 ms per 4096^2 atlas against 0.69 ms for upload + kernel + download.
-    // Ordinary pageable memory cannot be mapped; it takes the staged path below.
-    {
-        void *zin = nullptr, *zout = nullptr;
-        if (bu_device_view(in, &zin) && bu_device_view(out, &zout)) {
-            uint64_t zword = 0;
-            BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
-            st = bu_launch_uastc(ctx, target, zin, n, zout, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream, BU_ZEROCOPY_GRID);
-            if (st) return st;
-            BU_HIP(ctx, hipMemcpyAsync(&zword, ctx->d_status, sizeof(zword), hipMemcpyDeviceToHost, ctx->stream));
-            BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            return bu_status_word_decode(zword, first_bad);
-        }
+    // the GPU: the kernels read the slice and / or write the result straight over PCIe -- no staging copy on that side.
+    // A small persistent grid walks the tiles with prefetch, so tile k's posted writes travel upstream while tile k+1's
+    // reads come down (PCIe is full duplex): 0.45 ms per 4096^2 atlas with both sides mapped, against 0.69 ms for upload +
+    // kernel + download.  Ordinary pageable memory cannot be mapped and is staged through the context's device buffers.
+    void *zin = nullptr, *zout = nullptr;
+    const bool map_in = bu_device_view(in, &zin);
+    // RGBA32 with a ragged last block row stores whole image rows, past the 64*n bytes the caller sized: keep that staged
+    const bool map_out = !(target == BU_TARGET_RGBA32 && n % bpr != 0) && bu_device_view(out, &zout);
+    if (!map_in) {
+        st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, in_bytes);
+        if (st) return st;
     }
-    st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, in_bytes);
-    if (st) return st;
-    // RGBA32: a ragged last block-row still writes whole rows of the image the caller sized as 64*n
-    size_t out_need = n * bb;
-    if (target == BU_TARGET_RGBA32) out_need = ((n + bpr - 1) / bpr) * bpr * 64;
-    st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, out_need);
-    if (st) return st;
+    if (!map_out) {
+        size_t out_need = n * bb;
+        if (target == BU_TARGET_RGBA32) out_need = ((n + bpr - 1) / bpr) * bpr * 64;
+        st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, out_need);
+        if (st) return st;
+    }
+    const void* din = map_in ? zin : ctx->d_in;
+    void* dout = map_out ? zout : ctx->d_out;
     uint64_t word = 0;
-    BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!map_in) BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
-    st = bu_launch_uastc(ctx, target, ctx->d_in, n, ctx->d_out, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream);
+    st = bu_launch_uastc(ctx, target, din, n, dout, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream,
+                         (map_in || map_out) ? BU_ZEROCOPY_GRID : 0);
     if (st) return st;
     BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
-    BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
+    if (!map_out) BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return bu_status_word_decode(word, first_bad);
 }

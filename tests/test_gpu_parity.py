@@ -356,6 +356,14 @@ def test_page_locked_buffers_take_the_zero_copy_path_with_identical_results(ctx,
     lin = np.ascontiguousarray(img.transpose(0, 2, 1, 3)).reshape(m, 64)
     assert (lin == golden["rgba"][idx[:m]]).all()
     ctx.host_free(pin_rgba)
+    # mixed: only one side page-locked (the other side is staged)
+    pageable_out = ctx.transcode(FMT["bc7"], pin_in)
+    assert (pageable_out.reshape(n, 16) == golden["bc7"][idx]).all()
+    pin_out = ctx.host_alloc(n * 16)
+    assert (ctx.transcode(FMT["bc7"], golden["uastc"][idx], out=pin_out).reshape(n, 16) == golden["bc7"][idx]).all()
+    ctx.host_free(pin_out)
+    with pytest.raises(BasisuError, match="invalid argument"):  # ragged last block row: rejected as on the staged path
+        ctx.decode_to_rgba(pin_in[: (1000 * 3 + 17) * 16], 1000)
     # errors far apart (different workgroups): the lowest block index is reported, as the reference's sequential loop would
     bad = synth.atlas_err(golden["uastc"], n, [400000, 140001, 300000])
     pin_in[:] = bad.reshape(-1)

@@ -1,0 +1,48 @@
+"""EXPERIMENT: in-kernel phase stamps (s_memtime) of the sorted BC7 kernel: python stamps_run.py VARIANT LOG2_BLOCKS WAVES_PER_WG TILE"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from basisu_rs_amd import synth
+variant, lg, wpw, tile = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "exp", "libbu_exp.so"))
+vp = ctypes.c_void_p
+lib.bu_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+lib.bu_exp_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+lib.bu_exp_set_stamps.argtypes = [vp]
+h = vp(); assert lib.bu_context_create(0, ctypes.byref(h)) == 0
+g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+dev = torch.device("cuda", 0); N = 1 << lg; NBUF = 64
+gu = torch.from_numpy(g["uastc"]).to(dev)
+gold = []
+for k in range(NBUF):
+    gen = torch.Generator(device=dev); gen.manual_seed(k + 1)
+    gold.append(gu[torch.randint(0, 608, (N,), device=dev, generator=gen)].contiguous())
+outs = [torch.empty((N, 16), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+sp = vp(torch.cuda.current_stream().cuda_stream)
+A = vp * NBUF
+ip, op = A(*[x.data_ptr() for x in gold]), A(*[x.data_ptr() for x in outs])
+ms = ctypes.c_float(0)
+lib.bu_exp_time(h, variant, ip, op, NBUF, N, 32, sp, ctypes.byref(ms))
+best = 1e9
+for _ in range(3):
+    assert lib.bu_exp_time(h, variant, ip, op, NBUF, N, 256, sp, ctypes.byref(ms)) == 0
+    best = min(best, ms.value / 256 * 1e3)
+print("variant %d, 2^%d blocks: %.2f us per launch (no stamps)" % (variant, lg, best))
+n_wg = (N + tile - 1) // tile
+nw = n_wg * wpw
+buf = torch.zeros(nw * 16 + 64, dtype=torch.int64, device=dev)
+lib.bu_exp_set_stamps(vp(buf.data_ptr()))
+# one launch on a cold buffer, preceded by a few others so that clocks are up
+lib.bu_exp_time(h, variant, ip, op, NBUF, N, 5, sp, ctypes.byref(ms))
+torch.cuda.synchronize()
+lib.bu_exp_set_stamps(None)
+s = buf.cpu().numpy()[: nw * 16].reshape(nw, 16)[:, :9].astype(np.float64)
+names = ["start", "tables+loads", "A done", "bar1", "B done(bar2)", "scatter(bar3)", "C done", "bar4", "end"]
+t0 = s[:, 0].min()
+print("shader clocks since the first wave started: mean / min / p50 / max   (per-wave delta mean)")
+for k in range(9):
+    a = s[:, k] - t0
+    d = (s[:, k] - s[:, k - 1]).mean() if k else 0
+    print("  %-14s %8.0f %8.0f %8.0f %8.0f   (%6.0f)" % (names[k], a.mean(), a.min(), np.median(a), a.max(), d))
+print("kernel span first start -> last end: %.0f clocks" % (s[:, 8].max() - t0))
