@@ -41,6 +41,7 @@ struct BuTables {
     uint32_t eac_magic[16];   // ceil(2^20 / (2*range)) per EAC modifier table (etc.rs:297-307 as integers)
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
+    uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
 
@@ -58,6 +59,15 @@ static inline int bu_quant_p(int x, int S, int p)
     int q = ((x * S - 255 * p + 255) / 510) * 2 + p;
     int lo = p, hi = S - 1 + p;
     return q < lo ? lo : (q > hi ? hi : q);
+}
+
+// apply_etc1_bias for one channel (etc.rs:236-255); delta in -2..1, v in 0..limit
+static inline int bu_etc1_bias1_host(int v, int delta, int limit)
+{
+    if (v == 0) return delta == -2 ? 3 : delta + 1;
+    if (v == limit) return v + delta - 1;
+    const int m = v + delta;
+    return (m < 0 || m > limit) ? v - delta : m;
 }
 
 static inline void bu_build_tables(BuTables* t)
@@ -165,6 +175,12 @@ static inline void bu_build_tables(BuTables* t)
             }
         t->etc1_bias[bias] = packed;
     }
+    for (int d = 0; d < 2; d++)
+        for (int dc = 0; dc < 4; dc++)
+            for (int v = 0; v < 32; v++) {
+                const int limit = d ? 31 : 15;
+                t->etc1_biasv[(d << 7) | (dc << 5) | v] = v <= limit ? (uint8_t)bu_etc1_bias1_host(v, dc - 2, limit) : 0;
+            }
     for (int i = 0; i < 16; i++) {
         int mn = BU_ETC2_ALPHA_MOD[8 * i + 3], mx = BU_ETC2_ALPHA_MOD[8 * i + 7];
         int range = mx - mn;

@@ -44,36 +44,26 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
     // every range is odd, so there are no .5 ties (tests/test_float_sites.py)
     const uint32_t num = (uint32_t)(2 * ((int)mn * (range + mm) - (int)mx * mm) + range);
     const int center = (int)((num * T.eac_magic[table]) >> 20);  // num <= 14791, 2*range <= 58: exact
-    // nearest of the 8 table values, first minimum wins (min_by_key): key = 8*|value - a| + index via v_sad_u32
+    // nearest of the 8 table values, first minimum wins (min_by_key): key = 8*|value - a| + index via v_sad_u32, an
+    // 8-way minimum as three v_min3_u32 + one v_min_u32.  The index is the low 3 bits of the winning key, and one
+    // v_alignbit_b32 per texel funnels exactly those 3 bits into the top of an accumulator -- texels are visited in
+    // descending column-major id, so id 0 ends up highest, as etc.rs:324-327 lays the 48-bit string out.
     uint32_t values8[8];
     BU_UNROLL
     for (int k = 0; k < 8; k++) values8[k] = 8u * (uint32_t)bu_clampi(center + T.etc2_amod[8 * table + k] * mult, 0, 255);
-    uint64_t selectors = 0;
+    uint32_t acc[2] = {0, 0};  // acc[0]: ids 0..7 in bits 8..31 (id 0 on top), acc[1]: ids 8..15
     BU_UNROLL
-    for (int i = 0; i < 16; i++) {
-        const uint32_t a8 = (px[i] >> 24) * 8u;
+    for (int id = 15; id >= 0; id--) {
+        const int i = (id % 4) * 4 + id / 4;  // column-major id -> row-major texel (etc.rs:324-327)
+        const uint32_t a8 = (px[i] >> 21) & 0x7F8u;
         const uint32_t k0 = bu_sad<0>(values8[0], a8), k1 = bu_sad<1>(values8[1], a8), k2 = bu_sad<2>(values8[2], a8), k3 = bu_sad<3>(values8[3], a8);
         const uint32_t k4 = bu_sad<4>(values8[4], a8), k5 = bu_sad<5>(values8[5], a8), k6 = bu_sad<6>(values8[6], a8), k7 = bu_sad<7>(values8[7], a8);
-        const uint32_t m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3, m45 = k4 < k5 ? k4 : k5, m67 = k6 < k7 ? k6 : k7;
-        const uint32_t m03 = m01 < m23 ? m01 : m23, m47 = m45 < m67 ? m45 : m67;
-        const uint32_t best = m03 < m47 ? m03 : m47;
-        const int id = (i % 4) * 4 + i / 4;  // column-major (etc.rs:324-327)
-        selectors |= (uint64_t)(best & 7u) << (45 - 3 * id);
+        const uint32_t best = bu_umin(bu_umin3(k0, k1, k2), bu_umin3(k6, k7, bu_umin3(k3, k4, k5)));
+        acc[id >> 3] = bu_alignbit(best, acc[id >> 3], 3);
     }
-    const uint32_t shi = (uint32_t)(selectors >> 32), slo = (uint32_t)selectors;
-    out[0] = (uint32_t)center | (etc2tm << 8) | (((shi >> 8) & 0xFFu) << 16) | ((shi & 0xFFu) << 24);
-    out[1] = (slo >> 24) | (((slo >> 16) & 0xFFu) << 8) | (((slo >> 8) & 0xFFu) << 16) | ((slo & 0xFFu) << 24);
-}
-
-// apply_etc1_bias for one channel (etc.rs:236-255); delta in -2..1.  Branch-free: six of these per block would
-// otherwise be six divergent exec-mask regions.
-BU_DEV int bu_etc1_bias1(int v, int delta, int limit)
-{
-    const int at0 = v + (delta == -2 ? 3 : delta + 1);
-    const int atl = v + delta - 1;
-    const int mid0 = v + delta;
-    const int mid = (mid0 < 0 || mid0 > limit) ? v - delta : mid0;
-    return v == 0 ? at0 : (v == limit ? atl : mid);
+    // bytes 2..7 of the block are the 48-bit string big-endian: acc[0] bytes 3,2,1 then acc[1] bytes 3,2,1
+    out[0] = bu_perm(acc[0], (uint32_t)center | (etc2tm << 8), 0x06070100u);
+    out[1] = bu_perm(acc[1], acc[0], 0x05060701u);
 }
 
 // out: ETC1 -> out[0..1]; ETC2 -> out[0..1] alpha, out[2..3] colour (etc.rs:19-30)
@@ -139,11 +129,13 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
                 }
         }
         if constexpr (!L::m1012) {
-            const uint32_t packed = T.etc1_bias[bu_bits(b, L::pos_etc1bias, 5)];
+            // apply_etc1_bias (etc.rs:203-259): the six per-channel adjustments are one LUT read each
+            const uint32_t p5 = (uint32_t)T.etc1_bias[bu_bits(b, L::pos_etc1bias, 5)] << 5, dsel = d << 7;
             BU_UNROLL
             for (int sb = 0; sb < 2; sb++)
                 BU_UNROLL
-                for (int ch = 0; ch < 3; ch++) c[sb][ch] = bu_etc1_bias1(c[sb][ch], (int)((packed >> (2 * (sb * 3 + ch))) & 3u) - 2, limit);
+                for (int ch = 0; ch < 3; ch++)
+                    c[sb][ch] = (int)T.etc1_biasv[((p5 >> (2 * (sb * 3 + ch))) & 0x60u) | dsel | (uint32_t)c[sb][ch]];
         }
         int base[2][3];
         uint32_t hdr = 0;

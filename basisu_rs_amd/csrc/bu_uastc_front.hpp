@@ -290,6 +290,17 @@ BU_DEV uint32_t bu_sad(uint32_t a, uint32_t b)
     return (a > b ? a - b : b - a) + (uint32_t)K;
 #endif
 }
+BU_DEV uint32_t bu_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+BU_DEV uint32_t bu_umin3(uint32_t a, uint32_t b, uint32_t c) { return bu_umin(bu_umin(a, b), c); }  // -> v_min3_u32
+// ({hi, lo} >> sh) & 0xFFFFFFFF for 0 < sh < 32 (v_alignbit_b32)
+BU_DEV uint32_t bu_alignbit(uint32_t hi, uint32_t lo, int sh)
+{
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+}
 // bytes of a:b selected into one word (v_perm_b32): sel byte k picks byte (sel>>8k)&7 of {b (0-3), a (4-7)}, 0x0C = zero
 BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 {
