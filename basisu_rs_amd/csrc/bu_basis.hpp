@@ -13,31 +13,177 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/basisu_hip.h"
 
 namespace bu_host {
 
+// ---- host worker pool --------------------------------------------------------------------------------------------
+// The reference is single-threaded; the host work that stays serial per item here (one slice's symbol stream, one piece
+// of a CRC) is spread over items.  Threads are created once (thread start costs ~50 us, as much as half a small slice)
+// and parked on a condition variable.  A forked child finds no threads and runs inline.
+class Pool {
+    std::mutex run_m, m;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void()>* job = nullptr;
+    unsigned epoch = 0, want = 0, started = 0, running = 0;
+    bool stop = false;
+    int owner_pid = 0;
+
+    void worker()
+    {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (epoch != seen && started < want); });
+            if (stop) return;
+            seen = epoch;
+            started++;
+            const std::function<void()>* f = job;
+            lk.unlock();
+            (*f)();
+            lk.lock();
+            if (--running == 0) cv_done.notify_all();
+        }
+    }
+
+public:
+    static unsigned capacity()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        return hw < 32u ? hw : 32u;
+    }
+    // runs f on the calling thread and on up to `helpers` pool threads at once; returns when every copy has returned
+    void run(unsigned helpers, const std::function<void()>& f)
+    {
+        std::lock_guard<std::mutex> serial(run_m);
+        const int pid = (int)getpid();
+        if (owner_pid != pid) {  // first use, or a forked child (threads do not survive fork: forget them)
+            for (std::thread& t : th) t.detach();
+            th.clear();
+            owner_pid = pid;
+        }
+        if (helpers > capacity()) helpers = capacity();
+        while (th.size() < helpers) th.emplace_back([this] { worker(); });
+        if (helpers) {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f;
+            want = helpers;
+            started = 0;
+            running = helpers;
+            epoch++;
+        }
+        cv.notify_all();
+        f();
+        if (helpers) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return running == 0; });
+            job = nullptr;
+            want = 0;
+        }
+    }
+    ~Pool()
+    {
+        if (owner_pid != (int)getpid()) {
+            for (std::thread& t : th) t.detach();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (std::thread& t : th) t.join();
+    }
+};
+inline Pool& pool()
+{
+    static Pool p;
+    return p;
+}
+
 // ---- CRC-16/GENIBUS (basis.rs:364-372): poly 0x1021, init 0xFFFF, xorout 0xFFFF, not reflected ----
+// Slicing-by-8: t[k][b] = register after byte b followed by k zero bytes, so 8 message bytes cost 8 independent lookups.
 struct Crc16Table {
-    uint16_t t[256];
+    uint16_t t[8][256];
     Crc16Table()
     {
         for (int b = 0; b < 256; b++) {
             uint16_t crc = (uint16_t)(b << 8);
             for (int k = 0; k < 8; k++) crc = (uint16_t)((crc & 0x8000) ? ((crc << 1) ^ 0x1021) : (crc << 1));
-            t[b] = crc;
+            t[0][b] = crc;
         }
+        for (int k = 1; k < 8; k++)
+            for (int b = 0; b < 256; b++) t[k][b] = (uint16_t)((t[k - 1][b] << 8) ^ t[0][t[k - 1][b] >> 8]);
     }
 };
-inline uint16_t crc16(const uint8_t* p, size_t n, uint16_t crc)
+// raw register update (no init / final complement)
+inline uint16_t crc16_raw(const uint8_t* p, size_t n, uint16_t s)
 {
     static const Crc16Table tab;
-    crc = (uint16_t)~crc;
-    for (size_t i = 0; i < n; i++) crc = (uint16_t)((crc << 8) ^ tab.t[((crc >> 8) ^ p[i]) & 0xFF]);
-    return (uint16_t)~crc;
+    while (n >= 8) {
+        s = (uint16_t)(tab.t[7][p[0] ^ (s >> 8)] ^ tab.t[6][p[1] ^ (s & 0xFF)] ^ tab.t[5][p[2]] ^ tab.t[4][p[3]] ^ tab.t[3][p[4]] ^ tab.t[2][p[5]] ^
+                       tab.t[1][p[6]] ^ tab.t[0][p[7]]);
+        p += 8;
+        n -= 8;
+    }
+    for (size_t i = 0; i < n; i++) s = (uint16_t)((s << 8) ^ tab.t[0][((s >> 8) ^ p[i]) & 0xFF]);
+    return s;
+}
+// a * b in GF(2)[x] / (x^16 + x^12 + x^5 + 1)
+inline uint16_t crc16_gf_mul(uint16_t a, uint16_t b)
+{
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; i--) {
+        r <<= 1;
+        if (r & 0x10000u) r ^= 0x11021u;
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return (uint16_t)r;
+}
+// register s after n zero bytes = s * x^(8n)
+inline uint16_t crc16_shift(uint16_t s, size_t n)
+{
+    uint16_t result = 1, base = 0x0100;
+    for (; n; n >>= 1) {
+        if (n & 1) result = crc16_gf_mul(result, base);
+        base = crc16_gf_mul(base, base);
+    }
+    return crc16_gf_mul(s, result);
+}
+// The CRC is linear: register(s, A || B) = register(s, A) * x^(8|B|) + register(0, B).  Large payloads (a 4096^2 UASTC
+// file is 16 MiB; config 5 is 512 MiB) are cut into pieces whose registers are computed concurrently and then folded.
+inline uint16_t crc16(const uint8_t* p, size_t n, uint16_t crc)
+{
+    uint16_t s = (uint16_t)~crc;
+    constexpr size_t PIECE = (size_t)1 << 18;
+    const size_t pieces = (n + PIECE - 1) / PIECE;
+    if (pieces < 4) return (uint16_t)~crc16_raw(p, n, s);
+    std::vector<uint16_t> part(pieces, 0);
+    std::atomic<size_t> next{0};
+    const std::function<void()> work = [&] {
+        for (size_t k; (k = next.fetch_add(1)) < pieces;) {
+            const size_t lo = k * PIECE, len = (n - lo < PIECE) ? n - lo : PIECE;
+            part[k] = crc16_raw(p + lo, len, 0);
+        }
+    };
+    pool().run((unsigned)(pieces - 1 < Pool::capacity() ? pieces - 1 : Pool::capacity()), work);
+    for (size_t k = 0; k < pieces; k++) {
+        const size_t lo = k * PIECE, len = (n - lo < PIECE) ? n - lo : PIECE;
+        s = (uint16_t)(crc16_shift(s, len) ^ part[k]);
+    }
+    return (uint16_t)~s;
 }
 
 inline uint32_t le(const uint8_t* p, int n)
@@ -473,6 +619,42 @@ struct BasisLz {
         return BU_OK;
     }
 };
+
+// ---- all slices of a file ----
+// The reference decodes slice after slice (basis.rs:42-58, 103-123).  The symbol stream is serial WITHIN a slice, but
+// slices share nothing except the read-only codebooks and Huffman tables (the "previous frame" of texture video is
+// re-zeroed per slice, mod.rs:236-237), so they decode concurrently on the host cores.  The visible result is that of
+// the sequential loop: the status of the first failing slice in file order.
+struct SliceJob {
+    size_t nbx, nby;
+    const uint8_t* data;
+    size_t len;
+    uint32_t* idx;
+    bu_status st;
+};
+
+inline bu_status decode_slices(const BasisLz& lz, std::vector<SliceJob>& jobs, unsigned max_threads = 0, size_t min_parallel_blocks = 16384)
+{
+    size_t total = 0;
+    for (const SliceJob& j : jobs) total += j.nbx * j.nby;
+    unsigned nt = max_threads ? max_threads : Pool::capacity() + 1;
+    if (nt > jobs.size()) nt = (unsigned)jobs.size();
+    if (nt <= 1 || total < min_parallel_blocks) {
+        for (SliceJob& j : jobs) {
+            j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx);
+            if (j.st) return j.st;
+        }
+        return BU_OK;
+    }
+    std::atomic<size_t> next{0};
+    const std::function<void()> work = [&] {
+        for (size_t k; (k = next.fetch_add(1)) < jobs.size();) jobs[k].st = lz.decode_slice(jobs[k].nbx, jobs[k].nby, jobs[k].data, jobs[k].len, jobs[k].idx);
+    };
+    pool().run(nt - 1, work);
+    for (const SliceJob& j : jobs)
+        if (j.st) return j.st;
+    return BU_OK;
+}
 
 // ---- whole-file planning (basis.rs:8-260): every check of read_to_* that needs no block work ----
 struct BuFilePlan {

@@ -1003,8 +1003,18 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
                      size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
 {
     if (!ctx || !out) return BU_ERR_ARGUMENT;
+    const bool trace = getenv("BU_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t = now();
+        fprintf(stderr, "[bu_read_to] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     BuFilePlan p;
     bu_status st = bu_plan_file(target, file, len, p);
+    lap("plan (parse + 2 CRCs)");
     if (st) return st;
     if (header_out) *header_out = p.h;
     if (n_images) *n_images = p.images.size();
@@ -1033,6 +1043,7 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
     if (p.etc1s) {
         st = bu_make_lz(file, len, p.h, lz);
         if (st) return st;
+        lap("codebooks + tables");
         size_t words = 0;
         for (size_t k = 0; k < n_img; k++) {
             const bu_slice_desc& s = p.slices[p.first_slice[k]];
@@ -1045,16 +1056,19 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
             }
         }
         idx_all.assign(words ? words : 1, 0);
+        std::vector<bu_host::SliceJob> jobs;  // file order: colour slice, then its alpha slice
+        jobs.reserve(n_img * (p.alpha_pairs ? 2 : 1));
         for (size_t k = 0; k < n_img; k++) {
             const bu_slice_desc& s = p.slices[p.first_slice[k]];
-            st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, file + s.file_ofs, s.file_size, idx_all.data() + in_off[k] / 4);
-            if (st) return st;
+            jobs.push_back({s.num_blocks_x, s.num_blocks_y, file + s.file_ofs, s.file_size, idx_all.data() + in_off[k] / 4, BU_OK});
             if (p.alpha_pairs) {
                 const bu_slice_desc& a = p.slices[p.first_slice[k] + 1];
-                st = lz.decode_slice(a.num_blocks_x, a.num_blocks_y, file + a.file_ofs, a.file_size, idx_all.data() + ain_off[k] / 4);
-                if (st) return st;
+                jobs.push_back({a.num_blocks_x, a.num_blocks_y, file + a.file_ofs, a.file_size, idx_all.data() + ain_off[k] / 4, BU_OK});
             }
         }
+        st = bu_host::decode_slices(lz, jobs);  // host cores in parallel; the symbol stream is serial only within a slice
+        if (st) return st;
+        lap("slice symbol streams");
         total_in = words * 4;
     } else {
         for (size_t k = 0; k < n_img; k++) {
@@ -1108,10 +1122,12 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         }
         if (st) return st;
     }
+    lap("reserve + enqueue");
     std::vector<uint64_t> words(n_img, 0);
     BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
     if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lap("download + synchronise");
     for (size_t k = 0; k < n_img; k++) {  // first Err (in slice order) aborts the whole call, like the `?` in the reference drivers
         st = bu_status_word_decode(words[k], nullptr);
         if (st) return st;

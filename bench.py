@@ -281,6 +281,51 @@ def main():
             del d_idx, d_o8, d_o64
         except Exception as e:  # secondary rows must never break the headline line
             extra["etc1s_error"] = repr(e)
+        # config 4 end to end: a .basis ETC1S file (16 slices x 16 384 blocks) through read_to_rgba -- host BasisLZ decode of
+        # the slices (concurrent on the host cores) + one GPU launch per slice.  The entropy decode is the whole cost.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import basis_builder as bb  # test-only encoder: synthesises the input file
+            import basisu_rs_amd as bu
+            fbytes, _, _ = bb.etc1s_file(np.random.default_rng(44), [(128, 128)] * 16, n_codebook=4096)
+            bu.read_to_rgba(fbytes, ctx)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hdr_f, imgs_f = bu.read_to_rgba(fbytes, ctx)
+            file_s = (time.perf_counter() - t0) / 3
+            t0 = time.perf_counter()
+            for k in range(16):
+                bu.basislz_decode(fbytes, k)
+            seq_s = time.perf_counter() - t0
+            extra["etc1s_file_read_to_rgba"] = {"slices": 16, "blocks": 16 * 16384, "file_bytes": len(fbytes), "ms_per_file": round(file_s * 1e3, 3),
+                                                "mblocks_s": round(16 * 16384 / file_s / 1e6, 1),
+                                                "ms_slice_by_slice_host_decode_only": round(seq_s * 1e3, 3),
+                                                "note": "whole-file API: parse + CRC + BasisLZ decode of all slices on the host cores + GPU decode + download"}
+        except Exception as e:
+            extra["etc1s_file_error"] = repr(e)
+        # configs 1/2 through the whole-file API: a .basis UASTC file holding the 4096x4096 atlas -> read_to_bc7
+        # (header + payload CRC-16 on the host cores, upload, one launch, download)
+        try:
+            import basisu_rs_amd as bu
+            ufile = bu.write_uastc_file([dict(data=host_in, orig_w=4096, orig_h=4096, nbx=1024, nby=1024)])
+            pin_file_out = ctx.host_alloc(N_BLOCKS * 16)
+            bu.read_to_bc7(ufile, ctx, out=pin_file_out)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                imgs_u = bu.read_to_bc7(ufile, ctx, out=pin_file_out)
+            ufile_s = (time.perf_counter() - t0) / 5
+            t0 = time.perf_counter()
+            for _ in range(5):
+                bu.crc16(ufile[77:])
+            crc_s = (time.perf_counter() - t0) / 5
+            extra["uastc_file_read_to_bc7"] = {"file_bytes": len(ufile), "ms_per_file": round(ufile_s * 1e3, 3), "mblocks_s": round(N_BLOCKS / ufile_s / 1e6, 1),
+                                               "ms_payload_crc16": round(crc_s * 1e3, 3),
+                                               "verified": bool((np.asarray(imgs_u[0].data).reshape(-1, 16) == golden["bc7"][idx0]).all()),
+                                               "note": "whole-file API on a page-locked output buffer: parse + CRC-16 (host cores) + upload + kernel; never the headline value"}
+            ctx.host_free(pin_file_out)
+            del ufile
+        except Exception as e:
+            extra["uastc_file_error"] = repr(e)
         # config 3: UASTC -> RGBA32 (16 B in, 64 B out)
         rg_n = min(nbuf, 16)
         rg_out = [torch.empty((N_BLOCKS, 64), dtype=torch.uint8, device=dev) for _ in range(rg_n)]

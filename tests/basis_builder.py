@@ -425,3 +425,13 @@ def etc1s_file(rng, dims, n_codebook=256, history_size=32, alpha=False, raw_sele
     flags = 1 | (4 if alpha else 0)
     return build_basis_file(0, slices, flags=flags, tex_type=3 if is_video else 0, total_endpoints=n_codebook, endpoint_cb=ecb,
                             total_selectors=n_codebook, selector_cb=scb, tables=tables, total_images=len(dims)), ep, rows
+
+
+def reseal(file_bytes):
+    """recompute both CRCs of a (deliberately damaged) file so that the damage reaches the parsers behind them"""
+    g = bytearray(file_bytes)
+    dc = crc16(bytes(g[77:]))
+    g[12], g[13] = dc & 0xFF, dc >> 8
+    hc = crc16(bytes(g[8:77]))
+    g[6], g[7] = hc & 0xFF, hc >> 8
+    return bytes(g)

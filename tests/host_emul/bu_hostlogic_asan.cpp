@@ -27,14 +27,33 @@ static int process(const uint8_t* f, size_t len, int target)
     bu_host::BasisLz lz;
     st = bu_host::bu_make_lz(f, len, p.h, lz);
     if (st) return st;
-    std::vector<uint32_t> idx;
+    // sequential, as the reference does it ...
+    std::vector<std::vector<uint32_t>> seq(p.slices.size()), par(p.slices.size());
+    bu_status seq_st = BU_OK;
+    for (size_t k = 0; k < p.slices.size() && !seq_st; k++) {
+        const bu_slice_desc& s = p.slices[k];
+        seq[k].assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
+        seq_st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, seq[k].data());
+    }
+    // ... and on 4 threads, as bu_read_to does it (threading forced: these files are tiny): same status, same indices
+    std::vector<bu_host::SliceJob> jobs;
     for (size_t k = 0; k < p.slices.size(); k++) {
         const bu_slice_desc& s = p.slices[k];
-        idx.assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
-        st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, idx.data());
-        if (st) return st;
+        par[k].assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
+        jobs.push_back({s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, par[k].data(), BU_OK});
     }
-    return 0;
+    const bu_status par_st = bu_host::decode_slices(lz, jobs, 4, 0);
+    if (par_st != seq_st) {
+        fprintf(stderr, "parallel decode status %d != sequential %d\n", (int)par_st, (int)seq_st);
+        abort();
+    }
+    if (!seq_st)
+        for (size_t k = 0; k < p.slices.size(); k++)
+            if (seq[k] != par[k]) {
+                fprintf(stderr, "parallel decode differs in slice %zu\n", k);
+                abort();
+            }
+    return seq_st;
 }
 
 int main(int argc, char** argv)

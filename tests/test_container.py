@@ -43,6 +43,12 @@ def test_crc16_is_genibus(oracle):
     for n in (0, 1, 2, 77, 1000, 65537):
         d = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
         assert bu.crc16(d) == oracle.crc16(d)
+    # sizes around the slicing-by-8 stride and the 256 KiB pieces of the concurrent path (>= 4 pieces -> host threads),
+    # with non-zero start values: the folded result must equal the byte-serial oracle
+    big = rng.integers(0, 256, size=(1 << 22) + 12345, dtype=np.uint8).tobytes()
+    for n in (7, 8, 9, 15, 16, 17, (1 << 18) - 1, 1 << 18, (1 << 18) + 1, 3 << 18, (3 << 18) + 1, 1 << 20, (1 << 20) + 3, len(big)):
+        for start in (0, 0xBEEF):
+            assert bu.crc16(big[:n], start) == oracle.crc16(big[:n], start), (n, start)
     d = rng.integers(0, 256, size=999, dtype=np.uint8).tobytes()
     # the `crc` argument continues a previous result (the ~ at entry undoes the ~ at exit), as in the reference
     assert bu.crc16(d[500:], bu.crc16(d[:500])) == bu.crc16(d) == oracle.crc16(d[500:], oracle.crc16(d[:500]))
@@ -179,4 +185,20 @@ def test_host_parser_is_memory_safe_on_corrupt_files(tmp_path, kw):
     path.write_bytes(f)
     r = subprocess.run([os.path.join(he, "bu_hostlogic_asan"), str(path), "4000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert "fuzz done" in r.stdout
+
+
+def test_concurrent_slice_decode_is_race_free(tmp_path):
+    """bu_read_to decodes the slices of an ETC1S file on several host threads (bu_host::decode_slices); the same harness
+    under ThreadSanitizer, with threading forced and every result compared with the sequential loop"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    he = os.path.join(root, "tests", "host_emul")
+    subprocess.run(["make", "-C", he, "bu_hostlogic_tsan"], check=True, capture_output=True)
+    f, _, _ = bb.etc1s_file(np.random.default_rng(4), [(9, 7), (4, 4), (13, 2), (6, 6), (5, 3), (8, 8)], n_codebook=70, alpha=True)
+    path = tmp_path / "t.basis"
+    path.write_bytes(f)
+    r = subprocess.run([os.path.join(he, "bu_hostlogic_tsan"), str(path), "300"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
     assert "fuzz done" in r.stdout

@@ -373,3 +373,33 @@ def test_page_locked_buffers_take_the_zero_copy_path_with_identical_results(ctx,
     assert ex.value.first_bad_block == 140001
     ctx.host_free(pin_out)
     ctx.host_free(pin_in)
+
+
+def test_read_to_on_a_many_slice_etc1s_file_decodes_slices_concurrently(ctx, oracle):
+    """24 576 blocks in 6 slices (+ alpha): enough for bu_read_to to spread the BasisLZ decode over host threads;
+    the result must be that of the oracle's sequential whole-file path"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    f, _, _ = bb.etc1s_file(np.random.default_rng(23), [(64, 64)] * 6, n_codebook=2048, alpha=True)
+    st, hdr, want = oracle.read_to("rgba", f)
+    assert st == 0 and len(want) == 6
+    h, got = bu.read_to_rgba(f, ctx)
+    _images_equal(got, want)
+    st, _, want = oracle.read_to("etc1", f)
+    assert st == 0
+    _images_equal(bu.read_to_etc1(f, ctx), want)
+    # a corrupted symbol stream in slice 3 fails the whole call, as the sequential loop would
+    sd = bu.read_slice_descs(f)
+    g = bytearray(f)
+    for k in range(sd[3].file_ofs, sd[3].file_ofs + min(64, sd[3].file_size)):
+        g[k] ^= 0xFF
+    g = bb.reseal(bytes(g))
+    st_o = oracle.read_to("rgba", g)[0]
+    assert st_o != 0  # 64 inverted bytes do not survive the symbol decoder
+    with pytest.raises(bu.BasisuError):
+        bu.read_to_rgba(g, ctx)
