@@ -270,13 +270,18 @@ def _read_to(target, buf, ctx=None, out=None):
     lib = _lib.load()
     a = _as_u8(buf)
     n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    _check_host(lib.bu_read_query(target, a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb)))
-    c = ctx or default_context()
-    imgs = (_lib.ImageDesc * max(n.value, 1))()
     if out is None:
+        _check_host(lib.bu_read_query(target, a.ctypes.data, a.size, ctypes.byref(n), ctypes.byref(nb)))
         out = np.empty(max(nb.value, 1), dtype=np.uint8)
+        max_images = n.value
+    else:  # the caller sized the buffer (read_query): no second pass over the payload CRC, one image per slice at most
+        hq = _lib.BasisHeader()
+        _check_host(lib.bu_basis_read_header(a.ctypes.data, a.size, ctypes.byref(hq)))
+        max_images = hq.total_slices
+    c = ctx or default_context()
+    imgs = (_lib.ImageDesc * max(max_images, 1))()
     h = _lib.BasisHeader()
-    st = lib.bu_read_to(c.handle, target, a.ctypes.data, a.size, ctypes.byref(h), imgs, n.value, ctypes.byref(n), out.ctypes.data, out.size)
+    st = lib.bu_read_to(c.handle, target, a.ctypes.data, a.size, ctypes.byref(h), imgs, max_images, ctypes.byref(n), out.ctypes.data, out.size)
     c._check(st)
     return h, [Image(im.w, im.h, im.stride, out[im.offset:im.offset + im.size]) for im in imgs[: n.value]]
 

@@ -667,13 +667,15 @@ struct BuFilePlan {
 };
 
 // everything of read_to_* that needs no block work: checks in the reference's order, image geometry
-inline bu_status bu_plan_file(bu_read_target target, const uint8_t* file, size_t len, BuFilePlan& p)
+// check_data_crc = false: the caller verifies the payload CRC itself (bu_read_to overlaps it with the upload) and gives
+// a CRC failure precedence over any later error, as the reference's order of checks would
+inline bu_status bu_plan_file(bu_read_target target, const uint8_t* file, size_t len, BuFilePlan& p, bool check_data_crc = true)
 {
     if (!file) return BU_ERR_ARGUMENT;
     if ((int)target < 0 || (int)target > 5) return BU_ERR_ARGUMENT;
     bu_status st = read_header(file, len, &p.h);
     if (st) return st;
-    if (crc16(file + 77, len - 77, 0) != p.h.data_crc16) return BU_ERR_DATA_CRC;  // to EOF, basis.rs:338-341
+    if (check_data_crc && crc16(file + 77, len - 77, 0) != p.h.data_crc16) return BU_ERR_DATA_CRC;  // to EOF, basis.rs:338-341
     st = read_slice_descs(file, len, &p.h, p.slices);
     if (st) return st;
     if (p.h.tex_format > 1) return BU_ERR_TEX_FORMAT;

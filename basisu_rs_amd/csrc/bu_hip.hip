@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <future>
 #include <mutex>
 #include <new>
 
@@ -1013,9 +1014,30 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         t_prev = t;
     };
     BuFilePlan p;
-    bu_status st = bu_plan_file(target, file, len, p);
-    lap("plan (parse + 2 CRCs)");
-    if (st) return st;
+    // Large UASTC files: the payload CRC (0.3 ms per 16 MiB on the host cores) runs beside the upload instead of before
+    // it.  The reference checks it before anything else behind the header (basis.rs:338-341), so a CRC failure takes
+    // precedence over every later error, and nothing is reported as success before it is known.
+    std::future<bool> crc_later;
+    bool crc_deferred = false;
+    {
+        bu_basis_header h0;
+        if (file && len >= ((size_t)1 << 20) && bu_host::read_header(file, len, &h0) == BU_OK && h0.tex_format == 1 && target != BU_READ_UASTC) {
+            crc_deferred = true;
+            const uint16_t want = h0.data_crc16;
+            crc_later = std::async(std::launch::async, [file, len, want] { return bu_host::crc16(file + 77, len - 77, 0) == want; });
+        }
+    }
+    auto settle = [&](bu_status s) {  // the status to report once the deferred CRC is known
+        if (crc_deferred) {
+            crc_deferred = false;
+            if (!crc_later.get()) return BU_ERR_DATA_CRC;
+        }
+        return s;
+    };
+    bu_status st = bu_plan_file(target, file, len, p, !crc_deferred);
+    lap("plan (parse + CRCs)");
+    if (st) return settle(st);
+    const auto rest = [&]() -> bu_status {
     if (header_out) *header_out = p.h;
     if (n_images) *n_images = p.images.size();
     if (out_bytes < p.out_bytes) return BU_ERR_OUTPUT_SIZE;
@@ -1133,6 +1155,8 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         if (st) return st;
     }
     return BU_OK;
+    };
+    return settle(rest());
 }
 
 bu_status bu_basis_write_uastc(const bu_slice_desc* descs, const uint8_t* const* slice_data, const size_t* slice_bytes, size_t n_slices,

@@ -288,11 +288,15 @@ def main():
             import basis_builder as bb  # test-only encoder: synthesises the input file
             import basisu_rs_amd as bu
             fbytes, _, _ = bb.etc1s_file(np.random.default_rng(44), [(128, 128)] * 16, n_codebook=4096)
-            bu.read_to_rgba(fbytes, ctx)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                hdr_f, imgs_f = bu.read_to_rgba(fbytes, ctx)
-            file_s = (time.perf_counter() - t0) / 3
+            file_out = ctx.host_alloc(bu.read_query(_lib.READ_RGBA, fbytes)[1])
+            bu.read_to_rgba(fbytes, ctx, out=file_out)
+            times = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                hdr_f, imgs_f = bu.read_to_rgba(fbytes, ctx, out=file_out)
+                times.append(time.perf_counter() - t0)
+            file_s = sorted(times)[len(times) // 2]  # median: waking parked host threads is noisy
+            ctx.host_free(file_out)
             t0 = time.perf_counter()
             for k in range(16):
                 bu.basislz_decode(fbytes, k)

@@ -403,3 +403,36 @@ def test_read_to_on_a_many_slice_etc1s_file_decodes_slices_concurrently(ctx, ora
     assert st_o != 0  # 64 inverted bytes do not survive the symbol decoder
     with pytest.raises(bu.BasisuError):
         bu.read_to_rgba(g, ctx)
+
+
+def test_large_uastc_file_checks_the_payload_crc_beside_the_upload(ctx, golden, oracle):
+    """files >= 1 MiB: bu_read_to verifies the payload CRC on host threads while the slice uploads; results and error
+    precedence must be those of the reference's order of checks (CRC before anything behind the header)"""
+    import basisu_rs_amd as bu
+
+    nbx, nby = 320, 300  # 96 000 blocks = 1.5 MB
+    idx = synth.gold_indices(nbx * nby, seed=5)
+    blocks = golden["uastc"][idx]
+    f = bu.write_uastc_file([dict(data=blocks, orig_w=4 * nbx, orig_h=4 * nby, nbx=nbx, nby=nby)])
+    assert len(f) >= 1 << 20
+    imgs = bu.read_to_bc7(f, ctx)
+    assert (np.asarray(imgs[0].data).reshape(-1, 16) == golden["bc7"][idx]).all()
+    _images_equal(bu.read_to_rgba(f, ctx)[1], oracle.read_to("rgba", f)[2])
+    g = bytearray(f)
+    g[len(g) // 2] ^= 0x10  # payload damage, CRC not re-sealed
+    with pytest.raises(bu.BasisuError, match="Data CRC16 failed"):
+        bu.read_to_bc7(bytes(g), ctx)
+    # payload damage that also makes a block invalid: the CRC failure is what the reference would report
+    g = bytearray(f)
+    ofs = bu.read_slice_descs(f)[0].file_ofs
+    g[ofs + 16 * 1000] = (g[ofs + 16 * 1000] & 0x80) | 69
+    with pytest.raises(bu.BasisuError, match="Data CRC16 failed"):
+        bu.read_to_astc(bytes(g), ctx)
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+
+    with pytest.raises(bu.BasisuError, match="invalid mode index"):  # CRC re-sealed: now the block error surfaces
+        bu.read_to_astc(bb.reseal(bytes(g)), ctx)
