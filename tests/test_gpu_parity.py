@@ -436,3 +436,36 @@ def test_large_uastc_file_checks_the_payload_crc_beside_the_upload(ctx, golden, 
 
     with pytest.raises(bu.BasisuError, match="invalid mode index"):  # CRC re-sealed: now the block error surfaces
         bu.read_to_astc(bb.reseal(bytes(g)), ctx)
+
+
+@pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2"])
+def test_large_configuration_with_a_ragged_last_tile(ctx, golden, target):
+    """the two-workgroups-per-CU configuration (>= 2^19 blocks) on a size that is not a multiple of its 2048-block
+    tile, with an invalid block in the ragged tail: every block transcoded, lowest failing index reported"""
+    import torch
+
+    from basisu_rs_amd import BasisuError
+
+    n = (1 << 19) + 2048 * 3 + 777
+    idx = synth.gold_indices(n, seed=77)
+    blocks = golden["uastc"][idx].copy()
+    d_in = torch.from_numpy(blocks).cuda()
+    bb_out = golden[target].shape[1]
+    d_out = torch.full((n + 64, bb_out), 0xCD, dtype=torch.uint8, device="cuda")  # 64 guard rows behind the output
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    ctx.transcode_device(FMT[target], d_in, n, d_out, d_status=status)
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    got = d_out.cpu().numpy()
+    assert (got[:n] == golden[target][idx]).all()
+    assert (got[n:] == 0xCD).all()  # nothing written past the last block
+    blocks[n - 5, 0] = 69
+    blocks[n - 300, 0] = 69
+    d_in = torch.from_numpy(blocks).cuda()
+    ctx.status_word_reset(status)
+    ctx.transcode_device(FMT[target], d_in, n, d_out, d_status=status)
+    torch.cuda.synchronize()
+    with pytest.raises(BasisuError, match="invalid mode index") as e:
+        ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    assert e.value.first_bad_block == n - 300
