@@ -643,7 +643,7 @@ int bu_oracle_read_to(int which, const uint8_t *buf, size_t len, uint32_t header
                 if (s->file_size % 16) { st = 3; break; }
                 if (out) {
                     if (used + im.size > out_cap) { st = OB_ERR_BOUNDS; break; }
-                    if (s->num_blocks_x == 0) { st = OB_ERR_BOUNDS; break; } /* i % 0 panics */
+                    if (s->num_blocks_x == 0 && nb16) { st = OB_ERR_BOUNDS; break; } /* i % 0 panics -- only if a block exists (uastc.rs:98-100) */
                     st = bu_oracle_decode_to_rgba(data, s->file_size, s->num_blocks_x, out + used, &fb);
                 }
             } else if (which == RD_UASTC) {

@@ -363,6 +363,7 @@ def build_basis_file(tex_format, slices, flags=0, tex_type=0, total_endpoints=0,
     body = bytearray()
     for s in slices:
         d = s["data"]
+        body += bytes(s.get("pad", 0))  # optional gap before this slice's data (slices need not be back to back)
         descs += struct.pack("<I", s.get("image_index", 0))[:3] + struct.pack("<BBHHHHIIH", s.get("level", 0), s.get("flags", 0), s["orig_w"],
                                                                                s["orig_h"], s["nbx"], s["nby"], ofs + len(body), len(d),
                                                                                crc16(d))
@@ -399,10 +400,10 @@ def build_basis_file(tex_format, slices, flags=0, tex_type=0, total_endpoints=0,
     return bytes(out)
 
 
-def uastc_file(block_arrays, dims, **kw):
-    """block_arrays: list of [n,16] uint8; dims: list of (nbx, nby)"""
+def uastc_file(block_arrays, dims, pads=None, **kw):
+    """block_arrays: list of [n,16] uint8; dims: list of (nbx, nby); pads: optional gap in bytes before each slice"""
     slices = [dict(data=np.ascontiguousarray(b, dtype=np.uint8).tobytes(), orig_w=4 * nbx - 1 if nbx else 0, orig_h=4 * nby - 2 if nby else 0, nbx=nbx,
-                   nby=nby, image_index=i) for i, (b, (nbx, nby)) in enumerate(zip(block_arrays, dims))]
+                   nby=nby, image_index=i, pad=(pads[i] if pads else 0)) for i, (b, (nbx, nby)) in enumerate(zip(block_arrays, dims))]
     return build_basis_file(1, slices, **kw)
 
 

@@ -469,3 +469,78 @@ def test_large_configuration_with_a_ragged_last_tile(ctx, golden, target):
     with pytest.raises(BasisuError, match="invalid mode index") as e:
         ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
     assert e.value.first_bad_block == n - 300
+
+
+def test_read_to_merges_back_to_back_slices_and_keeps_gapped_ones_apart(ctx, golden, oracle):
+    """bu_read_to uploads and (for block-linear targets) launches once per run of slices that sit back to back in the
+    file.  Mixed layout: runs {0,1,2}, {3,4} behind a 7-byte gap (unaligned file offset), {5} behind a 16-byte gap,
+    an empty slice, and a 40-slice array; results and error reporting must be those of the slice-by-slice oracle."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    dims = [(40, 30), (20, 15), (10, 8), (64, 64), (32, 32), (5, 3), (0, 0)] + [(32, 32)] * 40
+    pads = [0, 0, 0, 7, 0, 16, 0] + [0] * 40
+    blocks = [np.concatenate([golden["uastc"][synth.gold_indices(x * y // 2, seed=i)], synth.atlas_rand(x * y - x * y // 2, seed=i)]).reshape(-1, 16)
+              for i, (x, y) in enumerate(dims)]
+    f = bb.uastc_file(blocks, dims, pads=pads)
+    fns = {"rgba": lambda b: bu.read_to_rgba(b, ctx)[1], "etc1": lambda b: bu.read_to_etc1(b, ctx), "etc2": lambda b: bu.read_to_etc2(b, ctx),
+           "astc": lambda b: bu.read_to_astc(b, ctx), "bc7": lambda b: bu.read_to_bc7(b, ctx)}
+    for name, fn in fns.items():
+        st, _, want = oracle.read_to(name, f)
+        assert st == 0 and len(want) == len(dims)
+        _images_equal(fn(f), want)
+    # errors: a bad pattern in slice 4 (second run) and a bad mode in slice 20 (array run): slice 4's error is reported
+    blocks[20] = blocks[20].copy()
+    blocks[20][5, 0] = 69
+    bad4 = blocks[4].copy()
+    bad4[100] = synth.atlas_err(golden["uastc"], 2, [0, 1])[1]  # mode 3 with an out-of-range pattern
+    with pytest.raises(bu.BasisuError, match="invalid mode index"):
+        bu.read_to_bc7(bb.uastc_file(blocks, dims, pads=pads), ctx)
+    blocks[4] = bad4
+    g = bb.uastc_file(blocks, dims, pads=pads)
+    assert oracle.read_to("bc7", g)[0] != 0
+    with pytest.raises(bu.BasisuError, match="block pattern is not valid"):
+        bu.read_to_bc7(g, ctx)
+    with pytest.raises(bu.BasisuError, match="block pattern is not valid"):
+        bu.read_to_rgba(g, ctx)
+
+
+def test_read_to_pieced_two_stream_pipeline_on_a_mapped_output(ctx, golden, monkeypatch):
+    """large runs with a page-locked output are uploaded and transcoded in pieces on two streams (16 MiB pieces by
+    default; 1 MiB here to exercise it on a small file): same bytes, lowest failing block across pieces"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    monkeypatch.setenv("BU_RUN_PIECE_MIB", "1")
+    dims = [(256, 256)] * 3 + [(128, 37)]  # 3 x 1 MiB + 74 KiB: one run of 3.07 MiB -> 4 pieces, the last one ragged
+    idx = [synth.gold_indices(x * y, seed=90 + i) for i, (x, y) in enumerate(dims)]
+    blocks = [golden["uastc"][ix].copy() for ix in idx]
+    f = bb.uastc_file(blocks, dims)
+    for name, fn, tgt in (("bc7", bu.read_to_bc7, _lib.READ_BC7), ("etc1", bu.read_to_etc1, _lib.READ_ETC1), ("astc", bu.read_to_astc, _lib.READ_ASTC)):
+        pinned = ctx.host_alloc(bu.read_query(tgt, f)[1])
+        pinned[:] = 0x77
+        imgs = fn(f, ctx, out=pinned)
+        for k in range(len(dims)):
+            bb_out = golden[name].shape[1]
+            assert (np.asarray(imgs[k].data).reshape(-1, bb_out) == golden[name][idx[k]]).all(), (name, k)
+        ctx.host_free(pinned)
+    blocks[2][40000, 0] = 69  # third piece
+    blocks[1][65535, 0] = 69  # end of the second piece: the lower global index
+    bad = synth.atlas_err(golden["uastc"], 2, [0, 1])[1]
+    blocks[2][50000] = bad
+    pinned = ctx.host_alloc(bu.read_query(_lib.READ_BC7, f)[1])
+    with pytest.raises(bu.BasisuError, match="invalid mode index"):
+        bu.read_to_bc7(bb.uastc_file(blocks, dims), ctx, out=pinned)
+    blocks[1][65535] = golden["uastc"][idx[1][65535]]
+    blocks[2][40000] = golden["uastc"][idx[2][40000]]
+    with pytest.raises(bu.BasisuError, match="block pattern is not valid"):
+        bu.read_to_bc7(bb.uastc_file(blocks, dims), ctx, out=pinned)
+    ctx.host_free(pinned)
