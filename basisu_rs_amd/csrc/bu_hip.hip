@@ -145,6 +145,18 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 #define BU_BIG_SKEW 40
 #endif
 constexpr int BU_BIG_TILE = BU_BIG_WGS * BU_BIG_BPT;
+// RGBA32 configuration (tile = 1024 blocks either way)
+#ifndef BU_RGBA_WGS
+#define BU_RGBA_WGS 512
+#define BU_RGBA_BPT 2
+#define BU_RGBA_WG_PER_CU 2
+#endif
+#ifndef BU_RGBA_PREFETCH
+#define BU_RGBA_PREFETCH true
+#endif
+#ifndef BU_RGBA_SKEW
+#define BU_RGBA_SKEW 20
+#endif
 
 
 template <int WGS>
@@ -174,10 +186,15 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
     __shared__ BuTables T;
-    __shared__ uint4 sblk[BU_TILE];
     // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
-    // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts)
-    __shared__ uint4 sout[(TARGET == BU_TGT_RGBA && !DIRECT) ? 4 * BU_TILE : 1];
+    // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts).  The sorted input tile
+    // lives IN row 0 of that output tile: a lane reads its block from slot s and later overwrites exactly slot s with
+    // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
+    // which is what lets two workgroups share a CU.
+    constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
+    __shared__ uint4 sblk_store[BU_ALIAS ? 1 : BU_TILE];
+    __shared__ uint4 sout[BU_ALIAS ? 4 * BU_TILE : 1];
+    uint4* const sblk = BU_ALIAS ? sout : sblk_store;
     __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
     __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
     __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks, next_chunk;
@@ -584,13 +601,14 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
             case BU_TARGET_ETC1: BU_LAUNCH_SORTED(BU_TGT_ETC1) break;
             case BU_TARGET_RGBA32: {
-                // 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows) so the image
-                // rows leave as coalesced 1 KiB stores; one 1024-thread workgroup per CU walks its tiles with prefetch
-                const size_t rtiles = (nb + 1023) / 1024;
-                const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count;
+                // 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows, the input tile
+                // aliased into row 0) so the image rows leave as coalesced 1 KiB stores; persistent workgroups walk their
+                // tiles with prefetch.  BU_RGBA_WGS threads x BU_RGBA_BPT blocks, BU_RGBA_WG_PER_CU resident per CU.
+                const size_t rtiles = (nb + (BU_RGBA_WGS * BU_RGBA_BPT) - 1) / (BU_RGBA_WGS * BU_RGBA_BPT);
+                const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * BU_RGBA_WG_PER_CU;
                 const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
-                hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 1024, 1, 1, true, false>), dim3(rgrid), dim3(1024), 0, stream, pin, pout, (unsigned)nb,
-                                   (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
+                hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_RGBA_WGS, BU_RGBA_BPT, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(BU_RGBA_WGS), 0, stream, pin,
+                                   pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
             } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }
