@@ -544,3 +544,41 @@ def test_read_to_pieced_two_stream_pipeline_on_a_mapped_output(ctx, golden, monk
     with pytest.raises(bu.BasisuError, match="block pattern is not valid"):
         bu.read_to_bc7(bb.uastc_file(blocks, dims), ctx, out=pinned)
     ctx.host_free(pinned)
+
+
+def test_host_threads_share_a_context_and_use_their_own(ctx, golden):
+    """the reference's functions are pure and re-entrant: concurrent callers on one context serialise on
+    its staging buffers, separate contexts run side by side; every result must be right"""
+    import threading
+
+    from basisu_rs_amd import Context
+
+    own = [Context(0) for _ in range(2)]
+    errors = []
+
+    def worker(c, seed):
+        try:
+            for it in range(6):
+                n = 3000 + 517 * ((seed + it) % 7)
+                idx = synth.gold_indices(n, seed=1000 * seed + it)
+                blocks = golden["uastc"][idx]
+                t = ("bc7", "astc", "etc1", "etc2")[(seed + it) % 4]
+                got = c.transcode(FMT[t], blocks).reshape(n, -1)
+                if not (got == golden[t][idx]).all():
+                    errors.append((seed, it, t))
+                img = c.decode_to_rgba(blocks[: 64 * 40], 64).reshape(40, 4, 64, 16)
+                lin = np.ascontiguousarray(img.transpose(0, 2, 1, 3)).reshape(-1, 64)
+                if not (lin == golden["rgba"][idx[: 64 * 40]]).all():
+                    errors.append((seed, it, "rgba"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(ctx, s)) for s in range(4)]
+    threads += [threading.Thread(target=worker, args=(own[s % 2], 10 + s)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in own:
+        c.close()
+    assert not errors, errors[:5]
