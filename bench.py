@@ -168,10 +168,10 @@ def main():
     t0 = time.perf_counter()
     ev_ms = run(args.steps)  # K launches, hipEvents recorded on the launch stream around them
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks below is the job's time
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     t = torch.tensor([dt, ev_ms / 1e3], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
