@@ -5,7 +5,7 @@
 //   ASTC/BC7/ETC2    n x 16-byte blocks, same order                                -> written once as uint4
 //   ETC1             n x  8-byte blocks                                            -> uint2
 //   RGBA32           row-major image, pitch 16*blocks_per_row bytes (uastc.rs:96) -> 4 x uint4 per block
-//   tables           one BuTables blob (5.8 KiB), copied to LDS by every workgroup
+//   tables           one BuTables blob (5.9 KiB), copied to LDS by every workgroup
 // Mapping: one lane = one block.  A wave reads 64 x 16 B = 1 KiB contiguous and writes 1 KiB (512 B
 // for ETC1; for RGBA32 four 1 KiB row segments when the row has >= 64 blocks).  No MFMA: the work is
 // bit-field surgery on 128-bit values; the bound is HBM (see DESIGN.md for bytes/block).
@@ -111,16 +111,18 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Mode-sorted variant for the block-linear targets (ASTC, BC7, ETC1, ETC2).
+// Mode-sorted kernel (every target; RGBA32 returns its 64 B per block through an LDS row tile).
 //
-// The per-mode code paths are straight-line and short (~130 VALU each for BC7) but there are 19 of
+// The per-mode code paths are straight-line and short (100-260 VALU each for BC7) but there are 19 of
 // them: a wave whose 64 lanes hold a random mix of modes executes all 19 serially (measured: 69 us
 // per 4096x4096 atlas vs a 7 us copy).  So each workgroup first sorts its tile of BU_TILE blocks by
 // mode through LDS (counting sort: one LDS atomic per block), cuts every mode's run into chunks of
 // <= 64 blocks, and each wave then transcodes whole chunks with a wave-uniform mode (scalar branch,
 // no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
 // so global loads and stores stay fully coalesced (1 KiB per wave instruction).
-//   LDS per workgroup: tile 16 KiB + tables 5.8 KiB + 1 KiB status + counters.
+//   LDS per workgroup: tile 16 B x BU_TILE + tables 5.9 KiB + 1 B x BU_TILE status + counters and the chunk list.
+// Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr),
+// BU_RUN_PIECE_MIB (piece size of the two-stream upload pipeline, 0 = off).
 // modes by descending code-path length (BC7 VALU counts), 5 bits each: entries 0-11 / 12-19
 constexpr unsigned long long BU_COST_ORDER_LO = 0x2996161c4482643ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
