@@ -178,28 +178,33 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
             thr[sb][1] = (lum[1] + lum[2] + 1u) >> 1;
             thr[sb][2] = (lum[2] + lum[3] + 1u) >> 1;
         }
-        // the top-right and bottom-left 2x2 quadrants change half with the flip bit: pick their thresholds once
-        uint32_t thq[4][3];
+        // the top-right and bottom-left 2x2 quadrants change half with the flip bit: pick their thresholds once.
+        // Kept NEGATED: v_dot4_u32_u8 adds an accumulator for free, so dot4(texel, LW, -thr) = luma - thr in one instruction
+        // and bit 31 of the result is the comparison (both operands < 2^31).
+        uint32_t nthq[4][3];
         BU_UNROLL
         for (int k = 0; k < 3; k++) {
-            thq[0][k] = thr[0][k];
-            thq[1][k] = f ? thr[0][k] : thr[1][k];  // x >= 2, y < 2
-            thq[2][k] = f ? thr[1][k] : thr[0][k];  // x < 2, y >= 2
-            thq[3][k] = thr[1][k];
+            const uint32_t n0 = 0u - thr[0][k], n1 = 0u - thr[1][k];
+            nthq[0][k] = n0;
+            nthq[1][k] = f ? n0 : n1;  // x >= 2, y < 2
+            nthq[2][k] = f ? n1 : n0;  // x < 2, y >= 2
+            nthq[3][k] = n1;
         }
-        uint32_t msbp = 0, lsbp = 0;  // bit pixel_id = x*4 + y (etc.rs:376-392)
+        // sel = #thresholds <= luma; ETC1 code [3,2,0,1][sel]: high bit = sel < 2 = (luma < thr1), low bit = sel == 0 or
+        // sel == 3 = NOT (luma < thr0 xor luma < thr2) (the thresholds are monotone).  Texels are visited in descending
+        // pixel id (x*4 + y, etc.rs:376-392) and one v_alignbit_b32 per plane shifts the sign bit in from the right.
+        uint32_t msbp = 0, lsbx = 0;
         BU_UNROLL
-        for (int i = 0; i < 16; i++) {
-            const int y = i >> 2, x = i & 3;
+        for (int pid = 15; pid >= 0; pid--) {
+            const int x = pid >> 2, y = pid & 3;
             const int q = ((y >> 1) << 1) | (x >> 1);
-            const uint32_t lum = bu_udot4(px[i], LW, 0u);
-            const uint32_t ge0 = lum >= thq[q][0], ge1 = lum >= thq[q][1], ge2 = lum >= thq[q][2];
-            // sel = ge0+ge1+ge2; ETC1 code [3,2,0,1][sel]: high bit = sel<2, low bit = sel==0 || sel==3
-            const uint32_t hi = ge1 ^ 1u, lo = (ge0 ^ 1u) | ge2;
-            const int pid = x * 4 + y;
-            msbp |= hi << pid;
-            lsbp |= lo << pid;
+            const uint32_t t = px[y * 4 + x];
+            const uint32_t d0 = bu_udot4(t, LW, nthq[q][0]), d1 = bu_udot4(t, LW, nthq[q][1]), d2 = bu_udot4(t, LW, nthq[q][2]);
+            msbp = bu_alignbit(msbp, d1, 31);       // (msbp << 1) | (luma < thr1)
+            lsbx = bu_alignbit(lsbx, d0 ^ d2, 31);  // (lsbx << 1) | (lt0 ^ lt2)
         }
+        const uint32_t lsbp = ~lsbx & 0xFFFFu;
+        msbp &= 0xFFFFu;
         col[1] = ((msbp >> 8) & 0xFFu) | ((msbp & 0xFFu) << 8) | (((lsbp >> 8) & 0xFFu) << 16) | ((lsbp & 0xFFu) << 24);
         return BU_ST_OK;
     }
