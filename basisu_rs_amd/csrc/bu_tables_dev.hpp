@@ -42,6 +42,7 @@ struct BuTables {
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
     uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
+    uint32_t wpack[64];       // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
 
@@ -181,6 +182,12 @@ static inline void bu_build_tables(BuTables* t)
                 const int limit = d ? 31 : 15;
                 t->etc1_biasv[(d << 7) | (dc << 5) | v] = v <= limit ? (uint8_t)bu_etc1_bias1_host(v, dc - 2, limit) : 0;
             }
+    for (int bits = 1; bits <= 5; bits++)
+        for (int r = 0; r < (1 << bits); r++) {
+            // uastc.rs:697-719 (LUT1..LUT5) as arithmetic, then the operand form of the v_dot2 interpolation
+            const int w = bits == 1 ? r << 6 : bits == 2 ? r * 21 + (r >> 1) : bits == 3 ? r * 9 + (r >> 2) : bits == 4 ? r * 4 + (r >> 2) + (r >> 3) : r * 2 + ((r >> 4) << 1);
+            t->wpack[(1 << bits) - 2 + r] = (uint32_t)w * 0x3FFFCu + 256u;
+        }
     for (int i = 0; i < 16; i++) {
         int mn = BU_ETC2_ALPHA_MOD[8 * i + 3], mx = BU_ETC2_ALPHA_MOD[8 * i + 7];
         int range = mx - mn;

@@ -377,8 +377,8 @@ BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
             const uint32_t unrot = compsel == 0 ? 0x00020103u : compsel == 1 ? 0x01020300u : compsel == 2 ? 0x02030100u : 0x03020100u;
             BU_UNROLL
             for (int i = 0; i < 16; i++) {
-                const uint32_t b0 = bu_wdeq<wb>(bu_wfield<wb>(W, 2 * i)) * 0x3FFFCu + 256u;
-                const uint32_t b1 = bu_wdeq<wb>(bu_wfield<wb>(W, 2 * i + 1)) * 0x3FFFCu + 256u;
+                const uint32_t b0 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, 2 * i)];
+                const uint32_t b1 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, 2 * i + 1)];
                 const uint32_t v0 = bu_udot2(As[0], b0, 128u), v1 = bu_udot2(As[1], b0, 128u);
                 const uint32_t v2 = bu_udot2(As[2], b0, 128u), v3 = bu_udot2(As[3], b1, 128u);
                 const uint32_t q = bu_perm(v1, v0, 0x0C0C0602u) | bu_perm(v3, v2, 0x06020C0Cu);
@@ -390,10 +390,10 @@ BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
         for (int i = 0; i < 16; i++) {
             uint32_t sid = 0;
             if constexpr (subsets > 1) sid = (upat >> (2 * i)) & 3u;
-            // weights x4, packed (256-4w) | 4w << 16
-            const uint32_t b0 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes)) * 0x3FFFCu + 256u;
+            // weights x4, packed (256-4w) | 4w << 16: one LUT read per weight (dequantisation and packing folded in)
+            const uint32_t b0 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i * planes)];
             uint32_t b1 = b0;
-            if constexpr (planes == 2) b1 = bu_wdeq<wb>(bu_wfield<wb>(W, i * planes + 1)) * 0x3FFFCu + 256u;
+            if constexpr (planes == 2) b1 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i * planes + 1)];
             uint32_t v[4];
             BU_UNROLL
             for (int c = 0; c < NC; c++) {
