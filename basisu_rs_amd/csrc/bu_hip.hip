@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr),
 // BU_RUN_PIECE_MIB (piece size of the two-stream upload pipeline, 0 = off).
 // modes by descending code-path length (BC7 VALU counts), 5 bits each: entries 0-11 / 12-19
-constexpr unsigned long long BU_COST_ORDER_LO = 0x2996161c4482643ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
+constexpr unsigned long long BU_COST_ORDER_LO = 0x2c8cb0b0e281123ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // The large-input configuration: 512 threads x 4 blocks = 2048-block tiles, two workgroups resident per CU (16 waves, 80 KiB

@@ -42,6 +42,7 @@ struct BuTables {
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
     uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
+    uint8_t w5to4x2[1024];    // two 5-bit weights (10 bits) -> two 4-bit BC7 weights, x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
     uint32_t wpack[64];       // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
@@ -182,6 +183,11 @@ static inline void bu_build_tables(BuTables* t)
                 const int limit = d ? 31 : 15;
                 t->etc1_biasv[(d << 7) | (dc << 5) | v] = v <= limit ? (uint8_t)bu_etc1_bias1_host(v, dc - 2, limit) : 0;
             }
+    for (int i = 0; i < 1024; i++) {
+        const int a = i & 31, b = i >> 5;
+        const int va = (a >> 1) - (a == 14) + (a == 17), vb = (b >> 1) - (b == 14) + (b == 17);
+        t->w5to4x2[i] = (uint8_t)(va | (vb << 4));
+    }
     for (int bits = 1; bits <= 5; bits++)
         for (int r = 0; r < (1 << bits); r++) {
             // uastc.rs:697-719 (LUT1..LUT5) as arithmetic, then the operand form of the v_dot2 interpolation

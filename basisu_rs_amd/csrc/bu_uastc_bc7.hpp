@@ -174,11 +174,13 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
             } else {  // 5 -> 4 bits: x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
                 static_assert(wb == 5 && bwb == 4, "unexpected weight remap");
                 BU_UNROLL
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t x = bu_wfield<5>(W, i);
-                    const uint32_t v = (x >> 1) - (x == 14u) + (x == 17u);
-                    if (i < 8) w0lo |= v << (4 * i);
-                    else w0hi |= v << (4 * (i - 8));
+                for (int i = 0; i < 8; i++) {  // two weights per LUT read
+                    const int pos = 10 * i, wi = pos >> 5, sh = pos & 31;
+                    uint32_t x = W[wi] >> sh;
+                    if (sh + 10 > 32) x |= W[wi + 1] << (32 - sh);
+                    const uint32_t v = T.w5to4x2[x & 1023u];
+                    if (i < 4) w0lo |= v << (8 * i);
+                    else w0hi |= v << (8 * (i - 4));
                 }
             }
         } else {
