@@ -379,8 +379,9 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                     }
                     const bool p1 = (sum >> 8) < (sum & 0xFFu);  // err1 < err0
                     pb |= (p1 ? 1u : 0u) << (2 * s + k);
+                    const uint32_t sh = p1 ? 8u : 0u;  // one select per endpoint, then a variable-offset field extract per channel
                     BU_UNROLL
-                    for (int ch = 0; ch < 4; ch++) qv[s][k][ch] = p1 ? ((en[ch] >> 8) & 0xFFu) : (en[ch] & 0xFFu);
+                    for (int ch = 0; ch < 4; ch++) qv[s][k][ch] = (en[ch] >> sh) & 0xFFu;
                 }
             BU_UNROLL
             for (int ch = 0; ch < 4; ch++)
@@ -412,10 +413,11 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                     }
                 const bool p1 = (sum >> 8) < (sum & 0xFFu);
                 sp |= (p1 ? 1u : 0u) << s;
+                const uint32_t sh = p1 ? 8u : 0u;
                 BU_UNROLL
                 for (int k = 0; k < 2; k++)
                     BU_UNROLL
-                    for (int ch = 0; ch < 3; ch++) qv[s][k][ch] = p1 ? ((en[k][ch] >> 8) & 0xFFu) : (en[k][ch] & 0xFFu);
+                    for (int ch = 0; ch < 3; ch++) qv[s][k][ch] = (en[k][ch] >> sh) & 0xFFu;
             }
             BU_UNROLL
             for (int ch = 0; ch < 3; ch++)
