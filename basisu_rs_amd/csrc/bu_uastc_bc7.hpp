@@ -85,6 +85,16 @@ BU_DEV uint32_t bu_pbit8(uint32_t c, uint32_t* p)
 
 // ---- emit helpers ------------------------------------------------------------------------------
 BU_DEV uint32_t bu_byte(uint32_t c, int ch) { return (c >> (8 * ch)) & 0xFFu; }
+// four W-bit fields sitting in the four bytes of x -> one 4W-bit string, byte 0 lowest (two SWAR squeezes:
+// bytes -> 16-bit lanes -> word; 6 VALU instead of a shift / mask / or per field)
+template <int W>
+BU_DEV uint32_t bu_pack4(uint32_t x)
+{
+    constexpr uint32_t f = (1u << W) - 1u, g = 8 - W;
+    const uint32_t p = (x & (f | (f << 16))) | ((x >> g) & ((f << W) | (f << (W + 16))));
+    constexpr uint32_t f2 = (1u << (2 * W)) - 1u;
+    return (p & f2) | ((p >> (2 * g)) & (f2 << (2 * W)));
+}
 
 template <int M>
 BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
@@ -93,40 +103,28 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
     if constexpr (M == 8) {
         // ---- solid colour (bc7.rs:18-59, 312-375) ----
         const uint32_t c = bu_bits(b, 5, 32);
-        uint32_t n255 = 0, n0 = 0;
-        BU_UNROLL
-        for (int ch = 0; ch < 4; ch++) {
-            n255 += bu_byte(c, ch) == 255u;  // mode_6_optimal_endpoint_err(c, p=0)
-            n0 += bu_byte(c, ch) == 0u;      // mode_6_optimal_endpoint_err(c, p=1)
-        }
-        if (n255 > 0 && n0 > 0) {
+        // n0 = #channels equal to 0 (mode_6_optimal_endpoint_err with p = 1), n255 = #channels equal to 255 (p = 0).
+        // Only "is there one" matters: both -> BC7 mode 5; otherwise mode 6 with p = (n0 < n255) = (no zero and a 255).
+        const uint32_t nc = ~c;
+        const bool has0 = (((c - 0x01010101u) & nc) & 0x80808080u) != 0u, has255 = (((nc - 0x01010101u) & c) & 0x80808080u) != 0u;
+        if (has0 && has255) {
             // BC7 mode 5: colour weights all 1, alpha weights all 0, rotation 0
+            const uint32_t rg = (uint32_t)T.m5opt[bu_byte(c, 0)] | ((uint32_t)T.m5opt[bu_byte(c, 1)] << 16);  // bytes R0 R1 G0 G1
+            const uint32_t bl = T.m5opt[bu_byte(c, 2)];
             bu_put(out, 0, 6, 1u << 5);
-            int pos = 8;
-            BU_UNROLL
-            for (int ch = 0; ch < 3; ch++) {
-                const uint32_t o = T.m5opt[bu_byte(c, ch)];
-                bu_put(out, pos, 7, o & 0xFFu);
-                bu_put(out, pos + 7, 7, o >> 8);
-                pos += 14;
-            }
-            bu_put(out, pos, 8, bu_byte(c, 3));
-            bu_put(out, pos + 8, 8, bu_byte(c, 3));
-            pos += 16;                    // = 66
-            bu_put(out, pos, 1, 1u);      // anchor: 1 bit
-            bu_put(out, pos + 1, 30, 0x15555555u);  // 15 x 0b01
+            bu_put(out, 8, 28, bu_pack4<7>(rg));
+            bu_put(out, 36, 14, (bl & 0x7Fu) | ((bl >> 1) & 0x3F80u));
+            bu_put(out, 50, 16, (c >> 24) * 0x0101u);
+            bu_put(out, 66, 1, 1u);               // anchor: 1 bit
+            bu_put(out, 67, 30, 0x15555555u);     // 15 x 0b01
         } else {
-            const uint32_t p = n0 < n255 ? 1u : 0u;  // best_err1 < best_err0
+            const uint32_t p = (has255 && !has0) ? 1u : 0u, ofs = p ^ 1u;  // best_err1 < best_err0
+            const uint32_t rg = (uint32_t)T.m6opt[bu_byte(c, 0) + ofs] | ((uint32_t)T.m6opt[bu_byte(c, 1) + ofs] << 16);
+            const uint32_t ba = (uint32_t)T.m6opt[bu_byte(c, 2) + ofs] | ((uint32_t)T.m6opt[bu_byte(c, 3) + ofs] << 16);
             bu_put(out, 0, 7, 1u << 6);
-            int pos = 7;
-            BU_UNROLL
-            for (int ch = 0; ch < 4; ch++) {
-                const uint32_t o = T.m6opt[bu_byte(c, ch) + (p ^ 1u)];
-                bu_put(out, pos, 7, o & 0xFFu);
-                bu_put(out, pos + 7, 7, o >> 8);
-                pos += 14;
-            }
-            bu_put(out, pos, 2, p * 3u);  // = 63
+            bu_put(out, 7, 28, bu_pack4<7>(rg));
+            bu_put(out, 35, 28, bu_pack4<7>(ba));
+            bu_put(out, 63, 2, p * 3u);
             // weights all 5: anchor 3 bits (0b101) then 15 x 0b0101, from bit 65
             bu_put(out, 65, 3, 5u);
             bu_put(out, 68, 28, 0x5555555u);
@@ -332,12 +330,11 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
         if constexpr (BM == 6) {
             uint32_t p0, p1;
             const uint32_t q0 = bu_pbit8<4>(blo[0], &p0), q1 = bu_pbit8<4>(bhi[0], &p1);
-            BU_UNROLL
-            for (int ch = 0; ch < 4; ch++) {
-                bu_put(out, pos, 7, bu_byte(q0, ch));
-                bu_put(out, pos + 7, 7, bu_byte(q1, ch));
-                pos += 14;
-            }
+            // R0 R1 G0 G1 | B0 B1 A0 A1, 7 bits each: interleave the bytes of the two endpoints, squeeze 8 -> 7
+            const uint32_t rg = bu_pack4<7>(bu_perm(q1, q0, 0x05010400u)), ba = bu_pack4<7>(bu_perm(q1, q0, 0x07030602u));
+            bu_put(out, pos, 28, rg);
+            bu_put(out, pos + 28, 28, ba);
+            pos += 56;
             bu_put(out, pos, 2, p0 | (p1 << 1));
             pos += 2;  // = 65
             bu_put(out, pos, 31, w0lo & 0x7FFFFFFFu);
