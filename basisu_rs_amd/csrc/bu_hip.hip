@@ -141,6 +141,9 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 #ifndef BU_BIG_MINW
 #define BU_BIG_MINW 1
 #endif
+#ifndef BU_BIG_PREFETCH
+#define BU_BIG_PREFETCH false
+#endif
 // the second half of a big launch starts ~1 us late (s_sleep 40 = 2560 cycles): the two workgroups sharing a CU then sit
 // in different phases instead of marching in lockstep (12.78 -> 12.65 us; 0 -> 12.78, 10 -> 12.70, 80 -> 13.6, 127 -> 14.1)
 #ifndef BU_BIG_SKEW
@@ -595,7 +598,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             // large inputs: the BU_BIG_* configuration (2048-block tiles, two workgroups per CU), see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
     if (big)                                                                                                                            \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_BIG_WGS, BU_BIG_BPT, BU_BIG_MINW, false, false, BU_BIG_SKEW>), dim3(bgrid), dim3(BU_BIG_WGS), 0, stream, pin, pout, (unsigned)nb, \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_BIG_WGS, BU_BIG_BPT, BU_BIG_MINW, BU_BIG_PREFETCH, false, BU_BIG_SKEW>), dim3(bgrid), dim3(BU_BIG_WGS), 0, stream, pin, pout, (unsigned)nb, \
                            (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                                      \
     else                                                                                                                                \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
