@@ -10,7 +10,8 @@
  *   - plain pointers and sizes only; no ownership is transferred; outputs are caller-allocated.
  *   - `*_device` entry points take device pointers and a hipStream_t (passed as void*), never
  *     synchronise, never allocate, and are graph-capturable.  The other entry points take host
- *     pointers, stage through the context's device buffers and return after the result is in `out`.
+ *     pointers -- pageable memory is staged through the context's device buffers, page-locked memory
+ *     (bu_host_alloc) is read and written by the kernels directly -- and return after the result is in `out`.
  *   - errors of the reference (`Result<_, String>`, lib.rs:26-27) become bu_status codes;
  *     bu_status_string() returns the reference's message text for the hot-path errors.
  *   - "first failing block aborts the call" (uastc.rs:157-165): on a block error the returned status
