@@ -127,29 +127,25 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 constexpr unsigned long long BU_COST_ORDER_LO = 0x2c8cb0b0e281123ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
-// The large-input configuration: 512 threads x 4 blocks = 2048-block tiles, two workgroups resident per CU (16 waves, 80 KiB
-// of LDS).  Measured on the BC7 headline (A/B inside one run, tools/exp/ab.sh): 1024x4 one per CU 13.65 us, 512x4 12.80,
-// 256x4 13.80, 512x8 16.2, 1024x2 15.9, 256x8 15.7 -- two half-size workgroups per CU overlap each other's barrier- and
-// latency-bound sort phases, while the <= 64-block chunks stay as full as with 4096-block tiles (108 blocks per mode).
-#ifndef BU_BIG_WGS
-#define BU_BIG_WGS 512
-#define BU_BIG_BPT 4
-#endif
-#ifndef BU_BIG_WG_PER_CU
-#define BU_BIG_WG_PER_CU 2
-#endif
-#ifndef BU_BIG_MINW
-#define BU_BIG_MINW 1
-#endif
-#ifndef BU_BIG_PREFETCH
-#define BU_BIG_PREFETCH false
-#endif
-// the second half of a big launch starts ~1 us late (s_sleep 40 = 2560 cycles): the two workgroups sharing a CU then sit
-// in different phases instead of marching in lockstep (12.78 -> 12.65 us; 0 -> 12.78, 10 -> 12.70, 80 -> 13.6, 127 -> 14.1)
-#ifndef BU_BIG_SKEW
-#define BU_BIG_SKEW 40
-#endif
-constexpr int BU_BIG_TILE = BU_BIG_WGS * BU_BIG_BPT;
+// The large-input configurations (>= 512 Ki blocks), per target; all A/B'd inside one run (tools/exp/ab.sh) on the
+// BC7 headline, a 4096^2 atlas = 4096 blocks per CU:
+//   1024 x 4 (4096-block tile), one workgroup per CU                          13.65 us
+//   512 x 4 (2048), two per CU (16 waves)                                     12.80    -- half-size workgroups overlap each
+//   + second half of the grid started ~1 us late (s_sleep 40)                 12.65       other's barrier-bound sort phases
+//   256x4 13.8, 512x8 16.2, 1024x2 15.9, 256x8 15.7 at the same register count
+// The kernels are built with machine-LICM off (basisu_rs_amd/build.py): hoisting every mode path's constants out of the
+// chunk loop cost ~30 VGPRs.  BC7 then needs 62 instead of 93, which allows 32 waves per CU:
+//   1024 x 2 (2048), two per CU (32 waves)                                    11.6
+//   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7
+// ASTC (88 VGPRs) and ETC1/ETC2 (75) do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
+template <int TARGET>
+struct BuBigCfg {
+    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40;
+};
+template <>
+struct BuBigCfg<BU_TGT_BC7> {
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0;
+};
 // RGBA32 configuration (tile = 1024 blocks either way)
 #ifndef BU_RGBA_WGS
 #define BU_RGBA_WGS 512
@@ -595,17 +591,18 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * 7;
             const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
             const unsigned long long pbase = base + done;
-            // large inputs: the BU_BIG_* configuration (2048-block tiles, two workgroups per CU), see its definition
+            // large inputs: the per-target BuBigCfg configuration, see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
-    if (big)                                                                                                                            \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_BIG_WGS, BU_BIG_BPT, BU_BIG_MINW, BU_BIG_PREFETCH, false, BU_BIG_SKEW>), dim3(bgrid), dim3(BU_BIG_WGS), 0, stream, pin, pout, (unsigned)nb, \
-                           (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                                      \
-    else                                                                                                                                \
+    if (big) {                                                                                                                          \
+        using C = BuBigCfg<T>;                                                                                                          \
+        const size_t btiles = (nb + (size_t)C::WGS * C::BPT - 1) / ((size_t)C::WGS * C::BPT);                                           \
+        const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, 1, false, false, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
+                           dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);      \
+    } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
             const bool big = grid_cap == 0 && target != BU_TARGET_RGBA32 && nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
-            const size_t btiles = (nb + BU_BIG_TILE - 1) / BU_BIG_TILE;
-            const unsigned bgrid = (unsigned)(btiles < (size_t)ctx->cu_count * BU_BIG_WG_PER_CU ? btiles : (size_t)ctx->cu_count * BU_BIG_WG_PER_CU);
             switch (target) {
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
