@@ -140,11 +140,15 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // ASTC (88 VGPRs) and ETC1/ETC2 (75) do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
 template <int TARGET>
 struct BuBigCfg {
-    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40;
+    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
 };
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
-    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0;
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+};
+template <>
+struct BuBigCfg<BU_TGT_ASTC> {
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
 };
 // RGBA32 configuration (tile = 1024 blocks either way)
 #ifndef BU_RGBA_WGS
@@ -326,8 +330,13 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             int st = BU_ST_BAD_MODE;
             if (active) {
                 switch (m) {
+#ifdef BU_EXP_SKIP_MASK
+#define BU_CASE(k) \
+    case k: if constexpr (!((BU_EXP_SKIP_MASK >> k) & 1)) st = bu_block_mode<TARGET, k>(T, b, o); break;
+#else
 #define BU_CASE(k) \
     case k: st = bu_block_mode<TARGET, k>(T, b, o); break;
+#endif
                     BU_CASE(0) BU_CASE(1) BU_CASE(2) BU_CASE(3) BU_CASE(4) BU_CASE(5) BU_CASE(6) BU_CASE(7) BU_CASE(8) BU_CASE(9)
                     BU_CASE(10) BU_CASE(11) BU_CASE(12) BU_CASE(13) BU_CASE(14) BU_CASE(15) BU_CASE(16) BU_CASE(17) BU_CASE(18)
 #undef BU_CASE
@@ -597,7 +606,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         using C = BuBigCfg<T>;                                                                                                          \
         const size_t btiles = (nb + (size_t)C::WGS * C::BPT - 1) / ((size_t)C::WGS * C::BPT);                                           \
         const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, 1, false, false, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
                            dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);      \
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \

@@ -42,6 +42,9 @@ struct BuTables {
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
     uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
+    uint8_t astc_trit_pk[1024];  // five trits packed 2 bits each -> ASTC trit byte (astc.rs:247-264 re-indexed; digit 3 never occurs)
+    uint8_t astc_quint_pk[512];  // three quints packed 3 bits each -> ASTC quint code (astc.rs:208-217 re-indexed)
+    int16_t pairdiff7[256];      // BISE range 7: index tq_lo | tq_hi << 2 | eb_lo << 4 | eb_hi << 6 -> deq(hi) - deq(lo)  (astc.rs:57-66)
     uint8_t w5to4x2[1024];    // two 5-bit weights (10 bits) -> two 4-bit BC7 weights, x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
     uint32_t wpack[64];       // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
 };
@@ -183,6 +186,25 @@ static inline void bu_build_tables(BuTables* t)
                 const int limit = d ? 31 : 15;
                 t->etc1_biasv[(d << 7) | (dc << 5) | v] = v <= limit ? (uint8_t)bu_etc1_bias1_host(v, dc - 2, limit) : 0;
             }
+    for (int i = 0; i < 1024; i++) {
+        int id = 0, mul = 1, okd = 1;
+        for (int k = 0; k < 5; k++) {
+            const int d = (i >> (2 * k)) & 3;
+            if (d == 3) okd = 0;
+            id += d * mul;
+            mul *= 3;
+        }
+        t->astc_trit_pk[i] = okd ? BU_ASTC_TRIT_ENC[id] : 0;
+    }
+    for (int i = 0; i < 512; i++) {
+        const int d0 = i & 7, d1 = (i >> 3) & 7, d2 = i >> 6;
+        t->astc_quint_pk[i] = (d0 < 5 && d1 < 5 && d2 < 5) ? BU_ASTC_QUINT_ENC[(d2 * 5 + d1) * 5 + d0] : 0;
+    }
+    for (int i = 0; i < 256; i++) {
+        const int tl = i & 3, th = (i >> 2) & 3, el = (i >> 4) & 3, eh = (i >> 6) & 3;
+        // range 7 sits at offset 0 of deq[] with index tq << 2 | eb (bu_deq_ofs)
+        t->pairdiff7[i] = (tl < 3 && th < 3) ? (int16_t)((int)t->deq[(th << 2) | eh] - (int)t->deq[(tl << 2) | el]) : 0;
+    }
     for (int i = 0; i < 1024; i++) {
         const int a = i & 31, b = i >> 5;
         const int va = (a >> 1) - (a == 14) + (a == 17), vb = (b >> 1) - (b == 14) + (b == 17);
