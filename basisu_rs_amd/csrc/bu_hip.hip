@@ -136,8 +136,9 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // The kernels are built with machine-LICM off (basisu_rs_amd/build.py): hoisting every mode path's constants out of the
 // chunk loop cost ~30 VGPRs.  BC7 then needs 62 instead of 93, which allows 32 waves per CU:
 //   1024 x 2 (2048), two per CU (32 waves)                                    11.6
-//   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7
-// ASTC (88 VGPRs) and ETC1/ETC2 (75) do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
+//   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
+// ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp); ETC1/ETC2 (81)
+// do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
 template <int TARGET>
 struct BuBigCfg {
     static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
@@ -164,12 +165,17 @@ struct BuBigCfg<BU_TGT_ASTC> {
 #endif
 
 
-template <int WGS>
+// stage the parts of the table blob TARGET reads (bu_table_range), 16 bytes per thread per step
+template <int WGS, int TARGET>
 __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
 {
+    constexpr BuTableRange R = bu_table_range(TARGET);
     const uint4* s = reinterpret_cast<const uint4*>(src);
     uint4* d = reinterpret_cast<uint4*>(&dst);
-    for (int i = threadIdx.x; i < BU_TABLE_VEC; i += WGS) d[i] = s[i];
+    for (int i = R.lo / 16 + threadIdx.x; i < (int)(R.hi / 16); i += WGS) d[i] = s[i];
+    if constexpr (R.lo2 < R.hi2) {
+        for (int i = R.lo2 / 16 + threadIdx.x; i < (int)(R.hi2 / 16); i += WGS) d[i] = s[i];
+    }
 }
 
 #ifndef BU_STAMP
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         const unsigned idx = tile * BU_TILE + j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
-    bu_stage_tables_n<WGS>(T, tables);
+    bu_stage_tables_n<WGS, TARGET>(T, tables);
     if (tid < 32) cnt[tid] = 0;
     __syncthreads();
     BU_STAMP(1)
@@ -330,13 +336,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             int st = BU_ST_BAD_MODE;
             if (active) {
                 switch (m) {
-#ifdef BU_EXP_SKIP_MASK
-#define BU_CASE(k) \
-    case k: if constexpr (!((BU_EXP_SKIP_MASK >> k) & 1)) st = bu_block_mode<TARGET, k>(T, b, o); break;
-#else
 #define BU_CASE(k) \
     case k: st = bu_block_mode<TARGET, k>(T, b, o); break;
-#endif
                     BU_CASE(0) BU_CASE(1) BU_CASE(2) BU_CASE(3) BU_CASE(4) BU_CASE(5) BU_CASE(6) BU_CASE(7) BU_CASE(8) BU_CASE(9)
                     BU_CASE(10) BU_CASE(11) BU_CASE(12) BU_CASE(13) BU_CASE(14) BU_CASE(15) BU_CASE(16) BU_CASE(17) BU_CASE(18)
 #undef BU_CASE

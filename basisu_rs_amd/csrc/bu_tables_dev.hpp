@@ -5,6 +5,7 @@
 // LDS reads, never global gathers).  All LUTs are derived here from the format constants of
 // bu_tables.h, so the kernels never divide, never take a modulo and never run a search.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -19,36 +20,60 @@ static_assert(sizeof(BuPart) == 16, "BuPart must be 16 bytes");
 
 // offsets (bytes) into BuTables::deq of the dequantisation LUT of each BISE range UASTC uses
 // (index = trit_or_quint << bits | bits_value); filled from BU_BISE[].lut_ofs_div8
+// Members are grouped by who reads them, each group 16-byte aligned, so that a kernel stages only what its target needs
+// (bu_table_range below): every workgroup copies its tables from L2 into LDS, and with four workgroups per CU on
+// 1024-block tiles the whole 9.3 KiB blob would be more than half of the 16 KiB of payload the workgroup moves.
+//   [BC7 only][common front-end][texel unpack: RGBA32, ETC][ASTC only][ETC only]
 struct BuTables {
-    uint16_t trit5[256];   // 8-bit group -> 5 trits, digit i in bits [2i,2i+2)   (uastc.rs:657-685)
-    uint16_t quint3[128];  // 7-bit group -> 3 quints, digit i in bits [3i,3i+3)  (uastc.rs:629-655)
-    uint8_t deq[504];      // endpoint dequantisation, ranges 7,8,11,12,13,18,19  (uastc.rs:585-614)
-    uint8_t deq5[56];      // (deq*31+127)/255 for ranges 7 (ofs 0) and 12 (ofs 16): BC7 mode 2 endpoints (bc7.rs:262-264)
-    BuPart part[61];       // partition records
+    // ---- BC7 only ----
+    alignas(16) uint8_t deq5[56];  // (deq*31+127)/255 for ranges 7 (ofs 0) and 12 (ofs 16): BC7 mode 2 endpoints (bc7.rs:262-264)
     uint32_t w3mask[30][2];  // 2-subset patterns, BC7 subset-1 texel mask at 3 bits/texel (48 bits)
-    uint32_t w3mask_u[30][2];  // same for the UASTC/ASTC subset-1 texels (ASTC weight inversion, astc.rs:162-170)
     uint32_t pbit6[256];   // unique p-bit LUT, 6 total bits: q0>>1 | (q1>>1)<<8 | err0<<16 | err1<<24 (bc7.rs:478-553)
     uint32_t pbit7[16];    // shared p-bit LUT, 7 total bits, input = 17*index (bc7.rs:408-475)
     uint16_t m5opt[256];   // BC7 mode 5 solid colour lo | hi<<8 (bc7.rs:734-863)
     uint16_t m6opt[258];   // BC7 mode 6 solid colour lo | hi<<8, index c + !p (bc7.rs:866-1136)
+    uint8_t w5to4x2[1024];    // two 5-bit weights (10 bits) -> two 4-bit BC7 weights, x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
+    // ---- common front-end (every target) ----
+    alignas(16) uint16_t trit5[256];  // 8-bit group -> 5 trits, digit i in bits [2i,2i+2)   (uastc.rs:657-685)
+    uint16_t quint3[128];  // 7-bit group -> 3 quints, digit i in bits [3i,3i+3)  (uastc.rs:629-655)
+    uint8_t deq[504];      // endpoint dequantisation, ranges 7,8,11,12,13,18,19  (uastc.rs:585-614)
+    uint8_t mode_lut[128];    // uastc.rs:560-577
+    BuPart part[61];       // partition records
+    // ---- texel unpack (RGBA32, ETC1, ETC2) ----
+    alignas(16) uint32_t wpack[64];  // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
+    // ---- ASTC only ----
+    alignas(16) uint32_t w3mask_u[30][2];  // 2-subset patterns, UASTC/ASTC subset-1 texel mask at 3 bits/texel (astc.rs:162-170)
     uint8_t astc_trit[244];   // astc.rs:247-264
     uint8_t astc_quint[128];  // astc.rs:208-217
     uint16_t astc_mode13[20]; // astc.rs:333-354
-    int16_t etc1_mod[32];     // etc.rs:435-445
+    uint8_t astc_trit_pk[1024];  // five trits packed 2 bits each -> ASTC trit byte (astc.rs:247-264 re-indexed; digit 3 never occurs)
+    uint8_t astc_quint_pk[512];  // three quints packed 3 bits each -> ASTC quint code (astc.rs:208-217 re-indexed)
+    int16_t pairdiff7[256];      // BISE range 7: index tq_lo | tq_hi << 2 | eb_lo << 4 | eb_hi << 6 -> deq(hi) - deq(lo)  (astc.rs:57-66)
+    // ---- ETC1 / ETC2 only ----
+    alignas(16) int16_t etc1_mod[32];  // etc.rs:435-445
     int8_t etc2_amod[128];    // etc.rs:450-468
-    uint8_t mode_lut[128];    // uastc.rs:560-577
     uint16_t etc1_bias[32];   // apply_etc1_bias deltas (etc.rs:203-234): field (2*subblock*3 + 2*c) = delta + 2
     uint32_t eac_magic[16];   // ceil(2^20 / (2*range)) per EAC modifier table (etc.rs:297-307 as integers)
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
     uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
-    uint8_t astc_trit_pk[1024];  // five trits packed 2 bits each -> ASTC trit byte (astc.rs:247-264 re-indexed; digit 3 never occurs)
-    uint8_t astc_quint_pk[512];  // three quints packed 3 bits each -> ASTC quint code (astc.rs:208-217 re-indexed)
-    int16_t pairdiff7[256];      // BISE range 7: index tq_lo | tq_hi << 2 | eb_lo << 4 | eb_hi << 6 -> deq(hi) - deq(lo)  (astc.rs:57-66)
-    uint8_t w5to4x2[1024];    // two 5-bit weights (10 bits) -> two 4-bit BC7 weights, x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
-    uint32_t wpack[64];       // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
+    alignas(16) uint8_t end_marker[16];
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
+
+// byte ranges [lo, hi) of BuTables a target reads (target ids as in bu_uastc_dispatch.hpp: 0 ASTC, 1 BC7, 2 ETC1, 3 ETC2,
+// 4 RGBA32); a second range is empty unless lo2 < hi2.  All bounds are multiples of 16.
+struct BuTableRange {
+    unsigned lo, hi, lo2, hi2;
+};
+constexpr BuTableRange bu_table_range(int target)
+{
+    return target == 1   ? BuTableRange{(unsigned)offsetof(BuTables, deq5), (unsigned)offsetof(BuTables, wpack), 0u, 0u}
+           : target == 0 ? BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, etc1_mod), 0u, 0u}
+           : target == 4 ? BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, w3mask_u), 0u, 0u}
+                         : BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, w3mask_u),
+                                        (unsigned)offsetof(BuTables, etc1_mod), (unsigned)offsetof(BuTables, end_marker)};
+}
 
 // deq offsets per range, compile-time (must match tools/gen_tables.py's packing order: 7,8,11,12,13,18,19,20)
 // sizes: r7 3*4=12->16, r8 16, r11 32, r12 5*8=40, r13 3*16=48, r18 5*32=160, r19 3*64=192 = 504; r20 is the identity
