@@ -27,7 +27,10 @@ namespace {
 
 constexpr int BU_WG = 256;            // 4 waves
 constexpr int BU_TABLE_VEC = (int)(sizeof(BuTables) / 16);
-constexpr int BU_SORT_MIN_BLOCKS = 2048;  // below this the plain one-lane-per-block kernel is used
+// Below this the plain one-lane-per-block kernel is used.  It runs one mode path per DISTINCT mode present, so it only
+// wins for a handful of blocks (BC7: 1 block 2.3 vs 3.3 us, 8 blocks 4.2 vs 3.7 us, 64 blocks 7.8 vs 4.4 us,
+// 1024 blocks 16.1 vs 4.8 us; ETC1 at 128 blocks 38.6 vs 15.0 us).
+constexpr int BU_SORT_MIN_BLOCKS = 8;
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bu_stage_tables(BuTables& dst, const BuTables* __restrict__ src)
@@ -142,14 +145,17 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 template <int TARGET>
 struct BuBigCfg {
     static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
+    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the 256 x 4 prefetching shape is faster (ETC1 at 2^16 blocks: 14.1 vs 17.5 us)
 };
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
     static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
 };
 template <>
 struct BuBigCfg<BU_TGT_ASTC> {
     static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr bool ALL_SIZES = true;
 };
 // RGBA32 configuration (tile = 1024 blocks either way)
 #ifndef BU_RGBA_WGS
@@ -603,7 +609,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const unsigned long long pbase = base + done;
             // large inputs: the per-target BuBigCfg configuration, see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
-    if (big) {                                                                                                                          \
+    if (grid_cap == 0 && (many || BuBigCfg<T>::ALL_SIZES)) {                                                                           \
         using C = BuBigCfg<T>;                                                                                                          \
         const size_t btiles = (nb + (size_t)C::WGS * C::BPT - 1) / ((size_t)C::WGS * C::BPT);                                           \
         const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
@@ -612,7 +618,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
-            const bool big = grid_cap == 0 && target != BU_TARGET_RGBA32 && nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
+                        const bool many = nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
             switch (target) {
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;

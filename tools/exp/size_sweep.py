@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 gu = torch.from_numpy(g["uastc"]).to(dev)
 sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 target = int(os.environ.get("TARGET", _lib.BC7))
-for lg in range(11, 26):
+for lg in range(int(os.environ.get("LG_LO", 11)), int(os.environ.get("LG_HI", 26))):
     N = 1 << lg
     nbuf = max(2, min(64, (1 << 30) // (N * 16)))
     ins, outs = [], []
