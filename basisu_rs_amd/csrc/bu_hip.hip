@@ -145,7 +145,7 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 template <int TARGET>
 struct BuBigCfg {
     static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
-    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the 256 x 4 prefetching shape is faster (ETC1 at 2^16 blocks: 14.1 vs 17.5 us)
+    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
@@ -615,10 +615,14 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
                            dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);      \
+    } else if (grid_cap == 0) {                                                                                                         \
+        /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(512), 0, stream, pin, pout, \
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                         \
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
-                        const bool many = nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
+            const bool many = nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
             switch (target) {
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
