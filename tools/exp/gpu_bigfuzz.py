@@ -1,0 +1,38 @@
+"""one-off: HIP path vs oracle on millions of random blocks (valid and raw), all targets, statuses included"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+from basisu_rs_amd import Context, _lib, synth, BasisuError
+from oracle.pyoracle import Oracle
+ctx = Context(0); o = Oracle()
+FMT = {"astc": _lib.ASTC, "bc7": _lib.BC7, "etc1": _lib.ETC1, "etc2": _lib.ETC2}
+t0 = time.time(); total = 0
+for seed in range(4):
+    n = 1 << 20
+    for kind in ("valid", "raw"):
+        if kind == "valid":
+            blocks = synth.atlas_rand(n, seed=500 + seed)
+        else:
+            blocks = np.random.Generator(np.random.PCG64(900 + seed)).integers(0, 256, size=(n, 16), dtype=np.uint8)
+        for t in ("astc", "bc7", "etc1", "etc2", "rgba"):
+            want, st = o.batch(t, blocks)
+            bad = np.where(st != 0)[0]
+            use = blocks
+            if bad.size:  # the GPU call aborts at the first bad block: check that, then neutralise the bad blocks
+                try:
+                    ctx.transcode(FMT[t], blocks) if t != "rgba" else ctx.decode_to_rgba(blocks, 1024)
+                    raise SystemExit("expected an error")
+                except BasisuError as e:
+                    assert e.first_bad_block == bad[0], (t, e.first_bad_block, bad[0])
+                use = blocks.copy(); use[bad] = synth.atlas_rand(1, seed=1)[0]
+                want, st2 = o.batch(t, use); assert (st2 == 0).all()
+            if t == "rgba":
+                img = ctx.decode_to_rgba(use, 1024).reshape(n // 1024, 4, 1024, 16)
+                got = np.ascontiguousarray(img.transpose(0, 2, 1, 3)).reshape(n, 64)
+            else:
+                got = ctx.transcode(FMT[t], use).reshape(n, -1)
+            assert (got == want).all(), (seed, kind, t, np.where((got != want).any(axis=1))[0][:5])
+        total += n
+    print("seed", seed, "ok  %.0fs" % (time.time() - t0), flush=True)
+print("blocks per target:", total)
