@@ -57,6 +57,8 @@ struct BuTables {
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
     uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
+    uint32_t etc1_thrcol[512];  // index diff << 8 | inten << 5 | c: the channel's four modified base values clamp(base + ETC1_MODIFIERS[inten][k]),
+                                // k in byte k; base = c*17 (individual, c < 16) or c<<3 | c>>2 (differential)  (etc.rs:165-171, 396-431)
     alignas(16) uint8_t end_marker[16];
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
@@ -241,6 +243,18 @@ static inline void bu_build_tables(BuTables* t)
             const int w = bits == 1 ? r << 6 : bits == 2 ? r * 21 + (r >> 1) : bits == 3 ? r * 9 + (r >> 2) : bits == 4 ? r * 4 + (r >> 2) + (r >> 3) : r * 2 + ((r >> 4) << 1);
             t->wpack[(1 << bits) - 2 + r] = (uint32_t)w * 0x3FFFCu + 256u;
         }
+    for (int d = 0; d < 2; d++)
+        for (int inten = 0; inten < 8; inten++)
+            for (int c = 0; c < 32; c++) {
+                const int base = d ? ((c << 3) | (c >> 2)) : ((c & 15) * 17);
+                uint32_t v = 0;
+                for (int k = 0; k < 4; k++) {
+                    int x = base + BU_ETC1_MOD[inten * 4 + k];
+                    x = x < 0 ? 0 : (x > 255 ? 255 : x);
+                    v |= (uint32_t)x << (8 * k);
+                }
+                t->etc1_thrcol[(d << 8) | (inten << 5) | c] = v;
+            }
     for (int i = 0; i < 16; i++) {
         int mn = BU_ETC2_ALPHA_MOD[8 * i + 3], mx = BU_ETC2_ALPHA_MOD[8 * i + 7];
         int range = mx - mn;

@@ -137,43 +137,36 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
                 for (int ch = 0; ch < 3; ch++)
                     c[sb][ch] = (int)T.etc1_biasv[((p5 >> (2 * (sb * 3 + ch))) & 0x60u) | dsel | (uint32_t)c[sb][ch]];
         }
-        int base[2][3];
+        // header bytes; cq[sb][ch] = the quantised base colour each half actually decodes with (etc.rs:113-158)
+        uint32_t cq[2][3];
         uint32_t hdr = 0;
         BU_UNROLL
         for (int ch = 0; ch < 3; ch++) {
-            uint32_t byte;
-            if (!d) {  // individual 4+4 bits (etc.rs:122-129)
-                byte = (((uint32_t)c[0][ch] << 4) | (uint32_t)c[1][ch]) & 0xFFu;
-                base[0][ch] = c[0][ch] * 17;
-                base[1][ch] = c[1][ch] * 17;
-            } else {  // differential 5 bits + clamped 3-bit delta (etc.rs:130-149)
-                const int dl = bu_clampi(c[1][ch] - c[0][ch], -4, 3);
-                byte = (((uint32_t)c[0][ch] << 3) | ((uint32_t)dl & 7u)) & 0xFFu;
-                const int c1 = (c[0][ch] + dl) & 0xFF;
-                base[0][ch] = ((c[0][ch] << 3) | (c[0][ch] >> 2)) & 0xFF;
-                base[1][ch] = ((c1 << 3) | (c1 >> 2)) & 0xFF;
-            }
-            hdr |= byte << (8 * ch);
+            // individual: 4+4 bits (etc.rs:122-129); differential: 5 bits + clamped 3-bit delta, and the second half decodes
+            // from c0 + delta (etc.rs:130-149).  Branch-free: both forms are a few ALU ops, `d` only selects.
+            const int dl = bu_clampi(c[1][ch] - c[0][ch], -4, 3);
+            const uint32_t byte_i = (((uint32_t)c[0][ch] << 4) | (uint32_t)c[1][ch]) & 0xFFu;
+            const uint32_t byte_d = (((uint32_t)c[0][ch] << 3) | ((uint32_t)dl & 7u)) & 0xFFu;
+            hdr |= (d ? byte_d : byte_i) << (8 * ch);
+            cq[0][ch] = (uint32_t)c[0][ch];
+            cq[1][ch] = d ? (uint32_t)((c[0][ch] + dl) & 31) : (uint32_t)c[1][ch];
         }
         hdr |= (((i0 << 5) | (i1 << 2) | (d << 1) | f) & 0xFFu) << 24;  // etc.rs:151-158
         col[0] = hdr;
 
         // luma thresholds per half (etc.rs:165-177).  The factors (108, 366, 38) are all even, so every luma is even:
-        // with lum = 2*L (L = 54r + 183g + 19b, one v_dot4_u32_u8) the reference's test lum >= (lum_a + lum_b)/2 is
-        // exactly L >= (L_a + L_b + 1) >> 1.
+        // with lum = 2*L (L = 54r + 183g + 19b) the reference's test lum >= (lum_a + lum_b)/2 is exactly
+        // L >= (L_a + L_b + 1) >> 1.  The four modified base colours of a half come from one LUT read per channel (byte k =
+        // clamp(base + modifier k)); their lumas are three v_dot4_u32_u8 each with single-byte weight words.
         constexpr uint32_t LW = 54u | (183u << 8) | (19u << 16);
         uint32_t thr[2][3];
         BU_UNROLL
         for (int sb = 0; sb < 2; sb++) {
-            const uint32_t inten = sb ? i1 : i0;
+            const uint32_t sel = (d << 8) | ((sb ? i1 : i0) << 5);
+            const uint32_t r4 = T.etc1_thrcol[sel | cq[sb][0]], g4 = T.etc1_thrcol[sel | cq[sb][1]], b4 = T.etc1_thrcol[sel | cq[sb][2]];
             uint32_t lum[4];
             BU_UNROLL
-            for (int k = 0; k < 4; k++) {
-                const int md = T.etc1_mod[inten * 4 + k];
-                const uint32_t cpk = (uint32_t)bu_clampi(base[sb][0] + md, 0, 255) | ((uint32_t)bu_clampi(base[sb][1] + md, 0, 255) << 8) |
-                                     ((uint32_t)bu_clampi(base[sb][2] + md, 0, 255) << 16);
-                lum[k] = bu_udot4(cpk, LW, 0u);
-            }
+            for (int k = 0; k < 4; k++) lum[k] = bu_udot4(b4, 19u << (8 * k), bu_udot4(g4, 183u << (8 * k), bu_udot4(r4, 54u << (8 * k), 0u)));
             thr[sb][0] = (lum[0] + lum[1] + 1u) >> 1;
             thr[sb][1] = (lum[1] + lum[2] + 1u) >> 1;
             thr[sb][2] = (lum[2] + lum[3] + 1u) >> 1;
