@@ -349,10 +349,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #undef BU_CASE
                 default: break;
                 }
-                if (st) {
-#pragma unroll
-                    for (int i = 0; i < NO; i++) o[i] = 0;
-                }
+                // (a failing block leaves o[] at the zeros it was initialised with: every path checks before it writes)
                 if constexpr (DIRECT) {
                     const unsigned idx = tbase + sorig[slot];
                     if (st) bu_report(status, base + idx, st);
