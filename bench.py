@@ -40,7 +40,12 @@ def pmc_traffic():
     gfx950 x2 correction + WRITE_SIZE; tools/gpu_pmc.sh), or None when no summary is committed"""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bc7.json")))
+    import re
+
+    def version_key(path):  # r01_v9 < r01_v10: compare the numbers, not the characters
+        return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bc7.json")), key=version_key)
     if not files:
         return None
     try:
