@@ -35,6 +35,9 @@ def build_hip(force=False, verbose=False):
            # machine-LICM hoists every mode path's constants out of the chunk loop of the sorted kernel: ~30 extra VGPRs
            # (BC7 93 -> 62 without it), which decides between 16 and 32 resident waves per CU
            "-mllvm", "-disable-machine-licm",
+           # every atomic here is either per-lane on different LDS counters or issued by one elected lane; the optimizer's
+           # wave-reduction scaffolding (mbcnt / readlane loops) around them is pure overhead (BC7 11.45 -> 11.15 us)
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
            "-o", LIB, os.path.join(CSRC, "bu_hip.hip")]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
