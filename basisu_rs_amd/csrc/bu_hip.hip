@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             for (int j = 0; j < BU_BPT; j++) pos[j] = (uint32_t)__builtin_amdgcn_readfirstlane(lead[j]) + lane;
         } else {
 #pragma unroll
-            for (int j = 0; j < BU_BPT; j++) pos[j] = mode[j] < 20u ? atomicAdd(&cnt[mode[j]], 1u) : 0u;
+            for (int j = 0; j < BU_BPT; j++) pos[j] = atomicAdd(&cnt[mode[j]], 1u);  // lanes past the end hit the dummy counter 31: no exec-mask region, the atomics issue back to back
         }
         BU_STAMP(2)
         __syncthreads();
