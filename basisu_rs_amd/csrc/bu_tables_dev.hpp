@@ -46,8 +46,10 @@ struct BuTables {
     uint8_t astc_trit[244];   // astc.rs:247-264
     uint8_t astc_quint[128];  // astc.rs:208-217
     uint16_t astc_mode13[20]; // astc.rs:333-354
-    uint8_t astc_trit_pk[1024];  // five trits packed 2 bits each -> ASTC trit byte (astc.rs:247-264 re-indexed; digit 3 never occurs)
-    uint8_t astc_quint_pk[512];  // three quints packed 3 bits each -> ASTC quint code (astc.rs:208-217 re-indexed)
+    uint16_t astc_trit_pk[1024];  // five trits packed 2 bits each -> ASTC trit byte T (astc.rs:247-264 re-indexed), its bits already spread to
+                                  // their places in a 2-bit-value group, >> 2: T01 @0, T23 @4, T4 @8, T56 @11, T7 @15
+    uint16_t astc_quint_pk[512];  // three quints packed 3 bits each -> ASTC quint code Q (astc.rs:208-217 re-indexed), spread for a
+                                  // 3-bit-value group: Q012 @3, Q34 @9, Q56 @14
     int16_t pairdiff7[256];      // BISE range 7: index tq_lo | tq_hi << 2 | eb_lo << 4 | eb_hi << 6 -> deq(hi) - deq(lo)  (astc.rs:57-66)
     // ---- ETC1 / ETC2 only ----
     alignas(16) int16_t etc1_mod[32];  // etc.rs:435-445
@@ -221,11 +223,13 @@ static inline void bu_build_tables(BuTables* t)
             id += d * mul;
             mul *= 3;
         }
-        t->astc_trit_pk[i] = okd ? BU_ASTC_TRIT_ENC[id] : 0;
+        const uint32_t tb = okd ? BU_ASTC_TRIT_ENC[id] : 0;
+        t->astc_trit_pk[i] = (uint16_t)((tb & 3u) | ((tb & 0xCu) << 2) | ((tb & 0x10u) << 4) | ((tb & 0x60u) << 6) | ((tb & 0x80u) << 8));
     }
     for (int i = 0; i < 512; i++) {
         const int d0 = i & 7, d1 = (i >> 3) & 7, d2 = i >> 6;
-        t->astc_quint_pk[i] = (d0 < 5 && d1 < 5 && d2 < 5) ? BU_ASTC_QUINT_ENC[(d2 * 5 + d1) * 5 + d0] : 0;
+        const uint32_t qb = (d0 < 5 && d1 < 5 && d2 < 5) ? BU_ASTC_QUINT_ENC[(d2 * 5 + d1) * 5 + d0] : 0;
+        t->astc_quint_pk[i] = (uint16_t)(((qb & 7u) << 3) | ((qb & 0x18u) << 6) | ((qb & 0x60u) << 9));
     }
     for (int i = 0; i < 256; i++) {
         const int tl = i & 3, th = (i >> 2) & 3, el = (i >> 4) & 3, eh = (i >> 6) & 3;

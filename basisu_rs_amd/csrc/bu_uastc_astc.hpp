@@ -64,9 +64,8 @@ BU_DEV int bu_block_astc(const BuTables& T, const BuBlk& b, uint32_t out[4])
         for (int g = 0; g < 4; g++) {
             const uint32_t dg = g < 3 ? (dlo >> (10 * g)) & 0x3FFu : (dlo >> 30) | (dhi << 2);
             const uint32_t e = g < 3 ? (elo >> (10 * g)) & 0x3FFu : (elo >> 30) | (ehi << 2);
-            const uint32_t t = T.astc_trit_pk[dg];
-            const uint32_t v = (e & 3u) | ((e & 0xCu) << 2) | ((e & 0x30u) << 4) | ((e & 0xC0u) << 5) | ((e & 0x300u) << 7) |  //
-                               ((t & 3u) << 2) | ((t & 0xCu) << 4) | ((t & 0x10u) << 6) | ((t & 0x60u) << 8) | ((t & 0x80u) << 10);
+            const uint32_t tsp = T.astc_trit_pk[dg];  // the trit byte, already spread (>> 2)
+            const uint32_t v = (e & 3u) | ((e & 0xCu) << 2) | ((e & 0x30u) << 4) | ((e & 0xC0u) << 5) | ((e & 0x300u) << 7) | (tsp << 2);
             bu_put(out, 29 + 18 * g, 18, v);
         }
         // weights (astc.rs:143-178): complemented per inverted subset, then the whole string bit-reversed into the top
@@ -111,8 +110,7 @@ BU_DEV int bu_block_astc(const BuTables& T, const BuBlk& b, uint32_t out[4])
         BU_UNROLL
         for (int g = 0; g < 4; g++) {
             const uint32_t dg = (uint32_t)(D >> (9 * g)) & 0x1FFu, e = (uint32_t)(E >> (9 * g)) & 0x1FFu;
-            const uint32_t q = T.astc_quint_pk[dg];
-            const uint32_t v = (e & 7u) | ((e & 0x38u) << 3) | ((e & 0x1C0u) << 5) | ((q & 7u) << 3) | ((q & 0x18u) << 6) | ((q & 0x60u) << 9);
+            const uint32_t v = (e & 7u) | ((e & 0x38u) << 3) | ((e & 0x1C0u) << 5) | (uint32_t)T.astc_quint_pk[dg];  // quint code already spread
             bu_put(out, 29 + 16 * g, 16, v);
         }
         uint32_t W[3];
