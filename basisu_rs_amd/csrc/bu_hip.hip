@@ -209,6 +209,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
     // which is what lets two workgroups share a CU.
     constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
+    // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
+    static_assert(!BU_ALIAS || sizeof(BuTables) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
+                  "the RGBA32 workgroup no longer fits twice per CU: shrink BuTables or stage it per target in LDS too");
     __shared__ uint4 sblk_store[BU_ALIAS ? 1 : BU_TILE];
     __shared__ uint4 sout[BU_ALIAS ? 4 * BU_TILE : 1];
     uint4* const sblk = BU_ALIAS ? sout : sblk_store;
