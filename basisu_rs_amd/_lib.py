@@ -11,6 +11,7 @@ ASTC, BC7, ETC1, ETC2, RGBA32 = 0, 1, 2, 3, 4
 BLOCK_BYTES = {ASTC: 16, BC7: 16, ETC1: 8, ETC2: 16, RGBA32: 64}
 # bu_status
 OK, ERR_INVALID_MODE, ERR_INVALID_PATTERN, ERR_LENGTH, ERR_OUTPUT_SIZE, ERR_ARGUMENT, ERR_INDEX_RANGE, ERR_NO_DEVICE, ERR_HIP = range(9)
+ERR_UNSUPPORTED, ERR_BOUNDS = 17, 19
 STATUS_WORD_CLEAR = 0xFFFFFFFFFFFFFFFF
 
 # every symbol include/basisu_hip.h declares (tests check the library exports all of them)
@@ -24,8 +25,12 @@ SYMBOLS = [
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
     "bu_basis_read_header", "bu_basis_read_slice_descs", "bu_basis_crc16", "bu_read_query", "bu_read_to", "bu_basislz_decode",
     "bu_basis_write_uastc",
-    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_streams", "bu_time_copy_launches",
+    "bu_comm_unique_id", "bu_comm_create", "bu_comm_destroy", "bu_allgather_inplace",
+    "bu_ipc_export", "bu_ipc_open", "bu_ipc_close", "bu_allgather_peer", "bu_array_transcode_sharded",
+    "bu_device_alloc", "bu_device_free", "bu_memcpy",
+    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_copy_launches",
 ]
+COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
 # bu_read_target
 READ_RGBA, READ_ETC1, READ_ETC2, READ_UASTC, READ_ASTC, READ_BC7 = range(6)
@@ -132,11 +137,38 @@ def load():
     lib.bu_basis_write_uastc.restype = c.c_int
     lib.bu_copy_ceiling_device.argtypes = [vp, vp, sz, vp, vp]
     lib.bu_copy_ceiling_device.restype = c.c_int
-    lib.bu_time_uastc_launches.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
+    lib.bu_time_uastc_launches.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches.restype = c.c_int
+    lib.bu_time_uastc_launches_each.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
+    lib.bu_time_uastc_launches_each.restype = c.c_int
+    # multi-GPU
+    lib.bu_comm_unique_id.argtypes = [vp]
+    lib.bu_comm_unique_id.restype = c.c_int
+    lib.bu_comm_create.argtypes = [vp, c.c_int, c.c_int, vp, c.POINTER(vp)]
+    lib.bu_comm_create.restype = c.c_int
+    lib.bu_comm_destroy.argtypes = [vp]
+    lib.bu_comm_destroy.restype = None
+    lib.bu_allgather_inplace.argtypes = [vp, vp, sz, vp]
+    lib.bu_allgather_inplace.restype = c.c_int
+    lib.bu_ipc_export.argtypes = [vp, vp, vp]
+    lib.bu_ipc_export.restype = c.c_int
+    lib.bu_ipc_open.argtypes = [vp, vp, c.POINTER(vp)]
+    lib.bu_ipc_open.restype = c.c_int
+    lib.bu_ipc_close.argtypes = [vp, vp]
+    lib.bu_ipc_close.restype = c.c_int
+    lib.bu_allgather_peer.argtypes = [vp, vp, c.POINTER(vp), c.c_int, c.c_int, sz, vp]
+    lib.bu_allgather_peer.restype = c.c_int
+    lib.bu_array_transcode_sharded.argtypes = [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(vp), sz, sz, c.POINTER(vp), c.c_int, u64p]
+    lib.bu_array_transcode_sharded.restype = c.c_int
+    lib.bu_device_alloc.argtypes = [vp, sz, c.POINTER(vp)]
+    lib.bu_device_alloc.restype = c.c_int
+    lib.bu_device_free.argtypes = [vp, vp]
+    lib.bu_device_free.restype = c.c_int
+    lib.bu_memcpy.argtypes = [vp, vp, vp, sz, c.c_int]
+    lib.bu_memcpy.restype = c.c_int
     lib.bu_time_uastc_launches_streams.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, c.c_int, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches_streams.restype = c.c_int
-    lib.bu_time_copy_launches.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), sz, sz, c.c_int, vp, c.POINTER(c.c_float)]
+    lib.bu_time_copy_launches.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, c.POINTER(c.c_float)]
     lib.bu_time_copy_launches.restype = c.c_int
     _lib = lib
     return lib

@@ -75,7 +75,11 @@ public:
             owner_pid = pid;
         }
         if (helpers > capacity()) helpers = capacity();
-        while (th.size() < helpers) th.emplace_back([this] { worker(); });
+        try {
+            while (th.size() < helpers) th.emplace_back([this] { worker(); });
+        } catch (...) {  // no more threads to be had (std::system_error): run with the helpers that exist -- every job
+            helpers = (unsigned)th.size();  // pulls its items from a shared counter, so fewer copies only means less overlap
+        }
         if (helpers) {
             std::lock_guard<std::mutex> lk(m);
             job = &f;

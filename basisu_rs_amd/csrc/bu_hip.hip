@@ -415,6 +415,13 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     BU_STAMP(8)
 }
 
+// status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into
+// hipGraphs, and a captured 8-byte memset node replayed as zeros on ROCm 7.2 (tests/test_gpu_round2.py, graph test).
+__global__ void bu_status_reset_kernel(unsigned long long* words, unsigned n)
+{
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) words[i] = ~0ull;
+}
+
 // uint4 -> uint4 copy with the transcoders' launch shape (measurement only)
 __global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
 {
@@ -521,6 +528,106 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
     }
 }
 
+
+// ---- whole-file ETC1S launches (bu_read_to): every slice of the file in ONE launch -----------------------------------
+// The host concatenates the per-slice index arrays (each padded to a multiple of 64 words) and describes the slices in a
+// small table; a wave owns one 64-block unit, finds its slice by a scalar binary search over the units' prefix and then
+// does exactly what the per-slice kernels do.  One status word per image, as the sequential drivers report.
+struct BuEtc1sSlice {
+    uint32_t unit0;     // first 64-block unit of this slice (the table ends with a sentinel holding the total)
+    uint32_t n_blocks;  // nbx * nby
+    uint32_t nbx;       // blocks per row (RGBA addressing)
+    uint32_t idx_ofs;   // colour indices, in words from the start of the staged index buffer
+    uint32_t aidx_ofs;  // alpha indices (RGBA with alpha pairs), 0xFFFFFFFF = none
+    uint32_t image;     // status word / image number
+    uint64_t out_ofs;   // byte offset of the image in the output buffer
+};
+static_assert(sizeof(BuEtc1sSlice) == 32, "descriptor layout is shared with the host code");
+
+template <bool RGBA>
+__global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __restrict__ idx, const BuEtc1sSlice* __restrict__ slices, uint32_t n_slices,
+                                                              uint32_t n_units, const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                              const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
+                                                              unsigned long long* status, const BuTables* __restrict__ tables)
+{
+    __shared__ int16_t mods[32];
+    if constexpr (RGBA) {
+        if (threadIdx.x < 32) mods[threadIdx.x] = tables->etc1_mod[threadIdx.x];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u, wpg = BU_WG / 64;
+    for (uint32_t unit = blockIdx.x * wpg + (threadIdx.x >> 6); unit < n_units; unit += gridDim.x * wpg) {
+        // largest s with slices[s].unit0 <= unit (unit is wave-uniform: the search runs on the scalar unit)
+        uint32_t lo = 0, hi = n_slices;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (__builtin_amdgcn_readfirstlane(slices[mid].unit0) <= unit) lo = mid;
+            else hi = mid;
+        }
+        const BuEtc1sSlice sd = slices[lo];
+        const uint32_t i = (unit - sd.unit0) * 64u + lane;
+        if (i >= sd.n_blocks) continue;
+        const uint32_t ix = __builtin_nontemporal_load(idx + sd.idx_ofs + i);
+        const uint32_t e = ix & 0xFFFFu, sl = ix >> 16;
+        bool bad = e >= n_ep || sl >= n_sel;
+        if constexpr (!RGBA) {
+            uint2 o = make_uint2(0, 0);
+            if (bad) {
+                bu_report(status + sd.image, i, BU_ERR_INDEX_RANGE);
+            } else {  // basis_lz/mod.rs:163-181
+                const uint32_t ep = endpoints[e];
+                const uint32_t inten = ep >> 24;
+                o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
+                o.y = selectors[sl].y;
+            }
+            bu_st_stream(reinterpret_cast<uint2*>(out + sd.out_ofs) + i, o);
+        } else {  // basis_lz/mod.rs:122-146
+            const bool has_a = sd.aidx_ofs != 0xFFFFFFFFu;
+            uint32_t ae = 0, as = 0;
+            if (has_a) {
+                const uint32_t ax = __builtin_nontemporal_load(idx + sd.aidx_ofs + i);
+                ae = ax & 0xFFFFu;
+                as = ax >> 16;
+                bad = bad || ae >= n_ep || as >= n_sel;
+            }
+            uint32_t px[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) px[k] = 0;
+            if (bad) {
+                bu_report(status + sd.image, i, BU_ERR_INDEX_RANGE);
+            } else {
+                const uint32_t ep = endpoints[e];
+                const uint32_t rows = selectors[sl].x;
+                uint32_t col[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) col[k] = bu_etc1s_color(mods, ep, k);
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const uint32_t sel = (rows >> (2 * t)) & 3u;
+                    px[t] = sel == 0 ? col[0] : sel == 1 ? col[1] : sel == 2 ? col[2] : col[3];
+                }
+                if (has_a) {
+                    const uint32_t aep = endpoints[ae];
+                    const uint32_t arows = selectors[as].x;
+                    uint32_t ag[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ag[k] = (bu_etc1s_color(mods, aep, k) >> 8) & 0xFFu;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const uint32_t sel = (arows >> (2 * t)) & 3u;
+                        const uint32_t a = sel == 0 ? ag[0] : sel == 1 ? ag[1] : sel == 2 ? ag[2] : ag[3];
+                        px[t] = (px[t] & 0x00FFFFFFu) | (a << 24);
+                    }
+                }
+            }
+            const uint32_t by = i / sd.nbx, bx = i - by * sd.nbx;
+            uint4* img = reinterpret_cast<uint4*>(out + sd.out_ofs);
+#pragma unroll
+            for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)(4 * by + r) * sd.nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 unsigned bu_grid_for(size_t n_blocks, int cu_count)
 {
@@ -566,6 +673,22 @@ bu_status bu_fail(bu_context* ctx, hipError_t e, const char* what)
         hipError_t e_ = (call);                                 \
         if (e_ != hipSuccess) return bu_fail(ctx, e_, #call);   \
     } while (0)
+
+// An early error return must not leave asynchronous copies in flight: they target the caller's stack frame (status
+// words), vectors about to be freed, or the context's staging buffers the next caller will reuse.  Armed while work is
+// queued; the success path disarms it after its own final synchronisation.
+struct BuDrain {
+    bu_context* ctx;
+    bool armed = true;
+    explicit BuDrain(bu_context* c) : ctx(c) {}
+    ~BuDrain()
+    {
+        if (!armed || !ctx) return;
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (hipStream_t es : ctx->extra_streams)
+            if (es) (void)hipStreamSynchronize(es);
+    }
+};
 
 bu_status bu_reserve(bu_context* ctx, void** p, size_t* cap, size_t need)
 {
@@ -707,6 +830,7 @@ bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, si
     const void* din = map_in ? zin : ctx->d_in;
     void* dout = map_out ? zout : ctx->d_out;
     uint64_t word = 0;
+    BuDrain drain(ctx);
     if (!map_in) BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
     st = bu_launch_uastc(ctx, target, din, n, dout, bpr, 0, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream,
@@ -715,6 +839,7 @@ bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, si
     BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     if (!map_out) BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;
     return bu_status_word_decode(word, first_bad);
 }
 
@@ -819,15 +944,19 @@ void bu_context_destroy(bu_context* ctx)
 bu_status bu_status_word_reset(bu_context* ctx, uint64_t* d_status, void* stream)
 {
     if (!ctx || !d_status) return BU_ERR_ARGUMENT;
-    BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+    hipLaunchKernelGGL(bu_status_reset_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long*>(d_status), 1u);
+    BU_HIP(ctx, hipGetLastError());
     return BU_OK;
 }
 
 bu_status bu_status_word_decode(uint64_t word, uint64_t* first_bad_block)
 {
     if (word == BU_STATUS_WORD_CLEAR) return BU_OK;
+    // a report is (block << 8 | status) with status 1 or 2 (6 for ETC1S): anything else was never reset or was overwritten
+    const unsigned st = (unsigned)(word & 0xFFu);
+    if (st != BU_ERR_INVALID_MODE && st != BU_ERR_INVALID_PATTERN && st != BU_ERR_INDEX_RANGE) return BU_ERR_ARGUMENT;
     if (first_bad_block) *first_bad_block = word >> 8;
-    return static_cast<bu_status>(word & 0xFFu);
+    return static_cast<bu_status>(st);
 }
 
 bu_status bu_host_alloc(bu_context* ctx, size_t bytes, void** out_ptr)
@@ -855,6 +984,8 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
     if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
     if (bu_target_block_bytes(target) == 0) return BU_ERR_ARGUMENT;
     if (target == BU_TARGET_RGBA32 && blocks_per_row == 0) return BU_ERR_ARGUMENT;
+    // the kernels store pixel rows 4*by+1..3 at the full image pitch: a ragged last block row would land past 64*n_blocks bytes
+    if (target == BU_TARGET_RGBA32 && n_blocks % blocks_per_row != 0) return BU_ERR_ARGUMENT;
     return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream));
 }
 
@@ -946,6 +1077,8 @@ static bu_status bu_etc1s_host(bu_context* ctx, bool rgba, const uint32_t* idx, 
     st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + a_bytes);
     if (st) return st;
     uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
+    uint64_t word = 0;
+    BuDrain drain(ctx);
     BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
     BU_HIP(ctx, hipMemcpyAsync(aux, endpoints, (size_t)n_ep * 4, hipMemcpyHostToDevice, ctx->stream));
     BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, selectors, (size_t)n_sel * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -961,10 +1094,10 @@ static bu_status bu_etc1s_host(bu_context* ctx, bool rgba, const uint32_t* idx, 
     else
         st = bu_etc1s_transcode_etc1_device(ctx, static_cast<const uint32_t*>(ctx->d_in), n, d_ep, n_ep, d_sel, n_sel, ctx->d_out, ds, ctx->stream);
     if (st) return st;
-    uint64_t word = 0;
     BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;
     return bu_status_word_decode(word, first_bad);
 }
 
@@ -989,8 +1122,8 @@ bu_status bu_basis_read_header(const uint8_t* file, size_t len, bu_basis_header*
     return bu_host::read_header(file, len, out);
 }
 
-bu_status bu_basis_read_slice_descs(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out, size_t max_descs,
-                                    size_t* n_descs)
+static bu_status bu_basis_read_slice_descs_impl(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out, size_t max_descs,
+                                              size_t* n_descs)
 {
     if (!file || !header) return BU_ERR_ARGUMENT;
     std::vector<bu_slice_desc> v;
@@ -1010,7 +1143,7 @@ using bu_host::BuFilePlan;
 using bu_host::bu_plan_file;
 using bu_host::bu_make_lz;
 
-bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes)
+static bu_status bu_read_query_impl(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes)
 {
     BuFilePlan p;
     bu_status st = bu_plan_file(target, file, len, p);
@@ -1020,8 +1153,8 @@ bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, 
     return BU_OK;
 }
 
-bu_status bu_basislz_decode(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out, uint8_t* selectors_out,
-                            uint32_t* idx_out)
+static bu_status bu_basislz_decode_impl(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out, uint8_t* selectors_out,
+                                       uint32_t* idx_out)
 {
     if (!file) return BU_ERR_ARGUMENT;
     bu_basis_header h;
@@ -1045,8 +1178,8 @@ bu_status bu_basislz_decode(const uint8_t* file, size_t len, uint32_t slice_inde
     return st;
 }
 
-bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
-                     size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
+static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
+                                size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
 {
     if (!ctx || !out) return BU_ERR_ARGUMENT;
     const bool trace = getenv("BU_TRACE") != nullptr;
@@ -1067,9 +1200,13 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
     {
         bu_basis_header h0;
         if (file && len >= ((size_t)1 << 20) && bu_host::read_header(file, len, &h0) == BU_OK && h0.tex_format == 1 && target != BU_READ_UASTC) {
-            crc_deferred = true;
             const uint16_t want = h0.data_crc16;
-            crc_later = std::async(std::launch::async, [file, len, want] { return bu_host::crc16(file + 77, len - 77, 0) == want; });
+            try {
+                crc_later = std::async(std::launch::async, [file, len, want] { return bu_host::crc16(file + 77, len - 77, 0) == want; });
+                crc_deferred = true;
+            } catch (...) {  // no thread to be had: the plan below checks the CRC inline, in the reference's order
+                crc_deferred = false;
+            }
         }
     }
     auto settle = [&](bu_status s) {  // the status to report once the deferred CRC is known
@@ -1163,13 +1300,40 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
     }
     std::lock_guard<std::mutex> g(ctx->lock);
     BU_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> words(n_img, 0);  // status landing area: declared before anything is queued, outlives the drain
+    std::vector<BuEtc1sSlice> descs;        // (likewise: source of an upload)
+    BuDrain drain(ctx);
     if ((st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, total_in ? total_in : 16))) return st;
     // a page-locked `out` (bu_host_alloc) receives the kernels' stores directly over PCIe: no device output buffer, no download
     void* zout = nullptr;
     const bool direct_out = bu_device_view(out, &zout);
     if (!direct_out && (st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, p.out_bytes ? p.out_bytes : 16))) return st;
     const size_t ep_bytes = p.etc1s ? align_up(lz.endpoints.size() * 4) : 0, sel_bytes = p.etc1s ? align_up(lz.selectors.size()) : 0;
-    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + 8 * n_img + 256))) return st;
+    // ETC1S: one descriptor per image (+ sentinel) behind the codebooks and the status words
+    uint32_t n_units = 0;
+    if (p.etc1s) {
+        descs.reserve(n_img + 1);
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& sl = p.slices[p.first_slice[k]];
+            const size_t nblk = (size_t)sl.num_blocks_x * sl.num_blocks_y;
+            if (p.images[k].size == 0 || nblk == 0) continue;
+            BuEtc1sSlice d;
+            d.unit0 = n_units;
+            d.n_blocks = (uint32_t)nblk;
+            d.nbx = sl.num_blocks_x;
+            d.idx_ofs = (uint32_t)(in_off[k] / 4);
+            d.aidx_ofs = (p.alpha_pairs && target == BU_READ_RGBA) ? (uint32_t)(ain_off[k] / 4) : 0xFFFFFFFFu;
+            d.image = (uint32_t)k;
+            d.out_ofs = p.images[k].offset;
+            descs.push_back(d);
+            n_units += (uint32_t)((nblk + 63) / 64);
+        }
+        BuEtc1sSlice end = {};
+        end.unit0 = n_units;
+        descs.push_back(end);
+    }
+    const size_t desc_bytes = align_up(descs.size() * sizeof(BuEtc1sSlice)), status_bytes = align_up(8 * n_img);
+    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + status_bytes + desc_bytes + 256))) return st;
     uint8_t* d_in = static_cast<uint8_t*>(ctx->d_in);
     uint8_t* d_out = direct_out ? static_cast<uint8_t*>(zout) : static_cast<uint8_t*>(ctx->d_out);
     uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
@@ -1179,8 +1343,23 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         BU_HIP(ctx, hipMemcpyAsync(d_in, idx_all.data(), total_in, hipMemcpyHostToDevice, ctx->stream));
         if (!lz.endpoints.empty()) BU_HIP(ctx, hipMemcpyAsync(aux, lz.endpoints.data(), lz.endpoints.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         if (!lz.selectors.empty()) BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, lz.selectors.data(), lz.selectors.size(), hipMemcpyHostToDevice, ctx->stream));
+        BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes + sel_bytes + status_bytes, descs.data(), descs.size() * sizeof(BuEtc1sSlice), hipMemcpyHostToDevice, ctx->stream));
+        // ONE launch for the whole file (basis.rs:42-58 / 103-123 walk the slices one by one)
+        if (n_units) {
+            const uint32_t n_cb0 = (uint32_t)lz.endpoints.size();
+            const unsigned grid = bu_grid_for((size_t)n_units * 64, ctx->cu_count);
+            const BuEtc1sSlice* d_descs = reinterpret_cast<const BuEtc1sSlice*>(aux + ep_bytes + sel_bytes + status_bytes);
+            if (target == BU_READ_RGBA)
+                hipLaunchKernelGGL(bu_etc1s_file_kernel<true>, dim3(grid), dim3(BU_WG), 0, ctx->stream, reinterpret_cast<const uint32_t*>(d_in), d_descs,
+                                   (uint32_t)(descs.size() - 1), n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                                   reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+            else
+                hipLaunchKernelGGL(bu_etc1s_file_kernel<false>, dim3(grid), dim3(BU_WG), 0, ctx->stream, reinterpret_cast<const uint32_t*>(d_in), d_descs,
+                                   (uint32_t)(descs.size() - 1), n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                                   reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+            BU_HIP(ctx, hipGetLastError());
+        }
     }
-    const uint32_t n_cb = (uint32_t)lz.endpoints.size();
     bool used_extra = false;
     size_t run_piece_bytes = (size_t)16 << 20;
     if (const char* e = getenv("BU_RUN_PIECE_MIB")) run_piece_bytes = (size_t)atoll(e) << 20;  // 0 disables the pieced pipeline
@@ -1189,15 +1368,7 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         const bu_image& im = p.images[k];
         if (im.size == 0) continue;
         if (p.etc1s) {
-            const uint32_t* di = reinterpret_cast<const uint32_t*>(d_in + in_off[k]);
-            const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y;
-            if (target == BU_READ_RGBA)
-                st = bu_etc1s_decode_rgba_device(ctx, di, p.alpha_pairs ? reinterpret_cast<const uint32_t*>(d_in + ain_off[k]) : nullptr, s.num_blocks_x,
-                                                 s.num_blocks_y, reinterpret_cast<const uint32_t*>(aux), n_cb, aux + ep_bytes, n_cb, d_out + im.offset,
-                                                 d_status + k, ctx->stream);
-            else
-                st = bu_etc1s_transcode_etc1_device(ctx, di, nblk, reinterpret_cast<const uint32_t*>(aux), n_cb, aux + ep_bytes, n_cb, d_out + im.offset,
-                                                    d_status + k, ctx->stream);
+            // (launched once for the whole file above)
         } else {
             size_t run_end = k;  // last image of the run starting at k (only evaluated for run leaders)
             bool pieced = false;
@@ -1252,11 +1423,11 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
         BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[0]));
         BU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
     }
-    std::vector<uint64_t> words(n_img, 0);
     BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
     if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (used_extra) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[0]));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;
     lap("download + synchronise");
     for (size_t k = 0; k < n_img; k++) {  // first Err (in slice order) aborts the whole call, like the `?` in the reference drivers
         st = bu_status_word_decode(words[k], nullptr);
@@ -1266,6 +1437,39 @@ bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file
     };
     return settle(rest());
 }
+
+
+// C++ exceptions must not cross the C ABI (a ctypes or Rust caller would be terminated): vectors sized from untrusted
+// file fields can throw std::bad_alloc, thread creation std::system_error.  A file that asks for more memory than
+// exists is reported like any other out-of-bounds field.
+#define BU_GUARDED(call)                 \
+    try {                                \
+        return call;                     \
+    } catch (const std::bad_alloc&) {    \
+        return BU_ERR_BOUNDS;            \
+    } catch (...) {                      \
+        return BU_ERR_HIP;               \
+    }
+bu_status bu_basis_read_slice_descs(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out, size_t max_descs,
+                                    size_t* n_descs)
+{
+    BU_GUARDED(bu_basis_read_slice_descs_impl(file, len, header, out, max_descs, n_descs))
+}
+bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes)
+{
+    BU_GUARDED(bu_read_query_impl(target, file, len, n_images, out_bytes))
+}
+bu_status bu_basislz_decode(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out, uint8_t* selectors_out,
+                            uint32_t* idx_out)
+{
+    BU_GUARDED(bu_basislz_decode_impl(file, len, slice_index, endpoints_out, selectors_out, idx_out))
+}
+bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
+                     size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
+{
+    BU_GUARDED(bu_read_to_impl(ctx, target, file, len, header_out, images, max_images, n_images, out, out_bytes))
+}
+#undef BU_GUARDED
 
 bu_status bu_basis_write_uastc(const bu_slice_desc* descs, const uint8_t* const* slice_data, const size_t* slice_bytes, size_t n_slices,
                                uint16_t header_flags, uint8_t tex_type, uint8_t* out, size_t out_cap, size_t* out_len)
@@ -1323,13 +1527,14 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
 }
 
 bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
-                                 size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream, float* out_ms)
+                                 size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream,
+                                 float* out_ms)
 {
     if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms) return BU_ERR_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
     for (int i = 0; i < launches; i++) {
-        const size_t k = (size_t)i % n_buffers;
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
         bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, stream);
         if (st) return st;
     }
@@ -1337,6 +1542,35 @@ bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* 
     BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
     BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
     return BU_OK;
+}
+
+bu_status bu_time_uastc_launches_each(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                      size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream,
+                                      float* out_us)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_us) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
+    bu_status ret = BU_OK;
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) ret = BU_ERR_HIP;
+    if (ret == BU_OK) {
+        (void)hipEventRecord(ev[0], s);
+        for (int i = 0; i < launches && ret == BU_OK; i++) {
+            const size_t k = (first_buffer + (size_t)i) % n_buffers;
+            ret = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, stream);
+            if (hipEventRecord(ev[(size_t)i + 1], s) != hipSuccess) ret = BU_ERR_HIP;
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) ret = BU_ERR_HIP;
+        for (int i = 0; i < launches && ret == BU_OK; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[(size_t)i], ev[(size_t)i + 1]) != hipSuccess) ret = BU_ERR_HIP;
+            out_us[i] = ms * 1000.0f;
+        }
+    }
+    for (auto e : ev)
+        if (e) (void)hipEventDestroy(e);
+    return ret;
 }
 
 bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
@@ -1358,14 +1592,14 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
     return BU_OK;
 }
 
-bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers, size_t n_blocks,
-                                int launches, void* stream, float* out_ms)
+bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers, size_t first_buffer,
+                                size_t n_blocks, int launches, void* stream, float* out_ms)
 {
     if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms) return BU_ERR_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
     for (int i = 0; i < launches; i++) {
-        const size_t k = (size_t)i % n_buffers;
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
         bu_status st = bu_copy_ceiling_device(ctx, d_in[k], n_blocks, d_out[k], stream);
         if (st) return st;
     }
@@ -1376,3 +1610,5 @@ bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* 
 }
 
 }  // extern "C"
+
+#include "bu_multi.hpp"

@@ -103,7 +103,10 @@ bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16]
 /* Same work as the two slice entry points above on memory already resident in HBM.
  *   d_in            n_blocks * 16 bytes, 16-byte aligned
  *   d_out           n_blocks * block_bytes, 16-byte aligned (8 for ETC1)
- *   blocks_per_row  only read for BU_TARGET_RGBA32 (image pitch); n_blocks need not be a multiple
+ *   blocks_per_row  only read for BU_TARGET_RGBA32 (image pitch).  For RGBA32 n_blocks must be a whole number of
+ *                   block rows (n_blocks % blocks_per_row == 0, else BU_ERR_ARGUMENT): the four pixel rows of a
+ *                   block row are stored at the full image pitch, so a ragged last row would be written past
+ *                   64 * n_blocks bytes (uastc.rs:95 sizes the image the same way and would panic there).
  *   d_status        optional device uint64_t initialised with bu_status_word_reset(): receives
  *                   min over failing blocks of (block_index << 8 | status); may be shared by several
  *                   launches whose block indices are disjoint (`block_index_base` is added)
@@ -229,6 +232,51 @@ bu_status bu_basis_write_uastc(const bu_slice_desc* descs, const uint8_t* const*
                                size_t n_slices, uint16_t header_flags, uint8_t tex_type, uint8_t* out, size_t out_cap,
                                size_t* out_len);
 
+/* ---- multi-GPU: shards of one texture array -----------------------------------------------------
+ * Slices of a texture array are independent contiguous byte ranges (SliceDesc.file_ofs/file_size, basis.rs:531-552;
+ * the reference walks them in the loop of read_to_bc7, basis.rs:246-257).  Rank / device g of P owns the slices
+ * [g*n/P, (g+1)*n/P): it transcodes them with bu_uastc_transcode_device straight into its copy of the full output
+ * buffer, at the range's final offset -- no data-path collective.  One all-gather then leaves the whole array on every
+ * device.  Two transports:
+ *   RCCL        ncclAllGather in place (send = own shard inside the receive buffer), one process per GPU
+ *   peer pulls  world-1 concurrent device-to-device copies per rank (xGMI is point to point: every link carries
+ *               one copy, no ring hops); between processes through HIP IPC handles, inside one process directly */
+typedef struct bu_comm bu_comm;
+#define BU_COMM_ID_BYTES 128
+#define BU_IPC_HANDLE_BYTES 64
+/* rank 0 creates the id (ncclGetUniqueId) and hands it to every rank by any out-of-band channel.
+ * BU_ERR_UNSUPPORTED when no RCCL library can be resolved in this process. */
+bu_status bu_comm_unique_id(uint8_t id[BU_COMM_ID_BYTES]);
+/* collective over all `world` ranks (ncclCommInitRank) on ctx's device */
+bu_status bu_comm_create(bu_context* ctx, int world, int rank, const uint8_t id[BU_COMM_ID_BYTES], bu_comm** out_comm);
+void bu_comm_destroy(bu_comm* comm);
+/* d_full: world * shard_bytes bytes on this rank's device, this rank's shard already at rank * shard_bytes (written by
+ * work enqueued on `stream` before this call).  Asynchronous on `stream`; afterwards every rank holds every shard. */
+bu_status bu_allgather_inplace(bu_comm* comm, void* d_full, size_t shard_bytes, void* stream);
+/* HIP IPC view of a peer process's full buffer (export on the owner, open on every other rank, close before the
+ * owner frees it) */
+bu_status bu_ipc_export(bu_context* ctx, void* d_ptr, uint8_t handle[BU_IPC_HANDLE_BYTES]);
+bu_status bu_ipc_open(bu_context* ctx, const uint8_t handle[BU_IPC_HANDLE_BYTES], void** d_peer);
+bu_status bu_ipc_close(bu_context* ctx, void* d_peer);
+/* Pull every other rank's shard out of its full buffer: copies [p*shard_bytes, (p+1)*shard_bytes) of d_peer_full[p]
+ * into d_full at the same offset for every p != rank (d_peer_full[rank] is ignored), all copies in flight together on
+ * context-owned streams that wait for `stream` and are joined back into it.  The caller orders this call after the
+ * PEERS' transcodes (a barrier across ranks); asynchronous on `stream`. */
+bu_status bu_allgather_peer(bu_context* ctx, void* d_full, void* const* d_peer_full, int world, int rank, size_t shard_bytes,
+                            void* stream);
+/* One process driving n_ctx devices (one context each; several contexts on one device are allowed and behave as
+ * virtual ranks).  d_in_shard[i]: device i's slice range only, resident on device i; d_full[i]: n_slices *
+ * blocks_per_slice * block_bytes bytes on device i.  Transcodes every range in place, then (gather != 0) every device
+ * pulls the other ranges from its peers.  Block-linear targets only.  Synchronous; on a block error returns the
+ * status and index (array-wide) of the LOWEST failing block, like the sequential loop over slices. */
+bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_target target, const void* const* d_in_shard,
+                                     size_t n_slices, size_t blocks_per_slice, void* const* d_full, int gather,
+                                     uint64_t* first_bad_block);
+/* device memory on ctx's device for callers without a HIP binding of their own (hipMalloc / hipFree / synchronous copy) */
+bu_status bu_device_alloc(bu_context* ctx, size_t bytes, void** out_ptr);
+bu_status bu_device_free(bu_context* ctx, void* ptr);
+bu_status bu_memcpy(bu_context* ctx, void* dst, const void* src, size_t bytes, int to_device);
+
 /* ---- measurement helpers (bench.py) ------------------------------------------------------------
  * uint4 -> uint4 copy kernel of the same launch shape as the 16 B -> 16 B transcoders: the practical
  * HBM ceiling the roofline fraction is reported next to. */
@@ -236,17 +284,25 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
 /* Times `launches` back-to-back launches of one transcode with hipEvents recorded on `stream`
  * around the whole batch (the stream the kernels are launched on).  d_in/d_out are arrays of
  * `n_buffers` device pointers rotated round-robin so that consecutive launches touch different
- * HBM (cold-cache protocol).  Writes the elapsed milliseconds for the whole batch. */
+ * HBM (cold-cache protocol): launch i uses buffer (first_buffer + i) % n_buffers, so a caller that carries
+ * first_buffer across calls never lets a timed launch re-touch what its warm-up just touched.
+ * Writes the elapsed milliseconds for the whole batch. */
 bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
-                                 size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches,
+                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches,
                                  uint64_t* d_status, void* stream, float* out_ms);
+/* Same launches with one hipEvent between every two of them: out_us[i] = microseconds from the event before launch i to
+ * the event after it (includes the event's own packet; the batch form above is the one the mean is taken from, this one
+ * gives the distribution: median, min, max). */
+bu_status bu_time_uastc_launches_each(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
+                                      size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches,
+                                      uint64_t* d_status, void* stream, float* out_us);
 /* Same launches spread round-robin over `n_streams` context-owned streams (independent slices in flight together);
  * wall-clock milliseconds between two device synchronisations.  Steady-state throughput row, not the roofline row. */
 bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                          size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches, int n_streams,
                                          float* out_ms);
 bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers,
-                                size_t n_blocks, int launches, void* stream, float* out_ms);
+                                size_t first_buffer, size_t n_blocks, int launches, void* stream, float* out_ms);
 
 #ifdef __cplusplus
 }

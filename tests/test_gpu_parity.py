@@ -179,7 +179,9 @@ def test_virtual_ranks_on_one_device_match_single_rank(ctx, golden):
     idx = synth.gold_indices(n_slices * bps, seed=77)
     slices = torch.from_numpy(golden["uastc"][idx].reshape(n_slices, bps, 16).copy()).cuda()
     fn = sharded.gpu_transcode_fn(ctx, _lib.BC7)
-    whole = fn(slices.reshape(-1, 16)).reshape(n_slices, bps, 16)
+    whole = torch.empty((n_slices, bps, 16), dtype=torch.uint8, device="cuda")
+    assert fn(slices.reshape(-1, 16), whole.view(-1, 16), 0) == sharded._CLEAR
+    assert torch.equal(sharded.transcode_array_sharded(slices, fn), whole)  # world size 1: the driver is a plain call
     assert (whole.cpu().numpy() == golden["bc7"][idx].reshape(n_slices, bps, 16)).all()
     for P in (2, 3, 8):
         full = torch.empty_like(whole)

@@ -52,7 +52,58 @@ def _worker(rank, world, port, n_slices, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_slices", [8, 7])
+def _worker_failing(rank, world, port, q):
+    """rank 1's shard holds an invalid block: BOTH ranks must raise the same error (lowest failing block of the whole
+    array) instead of rank 0 waiting in the all-gather until the collective times out"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basisu_rs_amd import sharded, synth
+        from oracle.pyoracle import Oracle
+
+        oracle = Oracle()
+        g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+        n_slices, bps = 4, 32
+        blocks = synth.atlas_err(g["uastc"], n_slices * bps, bad_at=[70, 100])  # both in rank 1's range (blocks 64..127)
+        slices = torch.from_numpy(blocks.reshape(n_slices, bps, 16).copy())
+
+        def fn(t, out, base):  # the product function's protocol: write `out`, return the status word
+            res, st = oracle.batch("bc7", t.numpy())
+            out.copy_(torch.from_numpy(res))
+            bad = np.nonzero(st)[0]
+            return sharded._CLEAR if bad.size == 0 else ((base + int(bad[0])) << 8) | int(st[bad[0]])
+
+        fn.block_bytes = 16
+        try:
+            sharded.transcode_array_sharded(slices, fn)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, args_of_rank, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args_of_rank) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(q.get(timeout=5) for _ in range(world))
+
+
+def test_failing_shard_raises_on_every_rank():
+    res = _spawn(_worker_failing, ())
+    assert res[0][1] == res[1][1] and "block 70 failed" in res[0][1], res
+
+
+@pytest.mark.parametrize("n_slices", [8, 7, 1])
 def test_two_rank_sharded_transcode_reassembles(n_slices):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     ctx = mp.get_context("spawn")

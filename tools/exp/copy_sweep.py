@@ -16,9 +16,9 @@ for lg in (6, 11, 14, 16, 18, 19, 20, 21, 22):
     ip, op = A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs])
     ms = ctypes.c_float(0)
     launches = 256
-    lib.bu_time_copy_launches(ctx.handle, ip, op, nbuf, N, 16, sp, ctypes.byref(ms))
+    lib.bu_time_copy_launches(ctx.handle, ip, op, nbuf, 0, N, 16, sp, ctypes.byref(ms))
     best = 1e9
     for _ in range(3):
-        lib.bu_time_copy_launches(ctx.handle, ip, op, nbuf, N, launches, sp, ctypes.byref(ms))
+        lib.bu_time_copy_launches(ctx.handle, ip, op, nbuf, 0, N, launches, sp, ctypes.byref(ms))
         best = min(best, ms.value / launches * 1e3)
     print("copy 2^%-2d blocks  %8.2f us  %7.1f GB/s" % (lg, best, 32 * N / best / 1e3), flush=True)

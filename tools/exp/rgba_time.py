@@ -17,12 +17,12 @@ sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 A = ctypes.c_void_p * NBUF
 ip, op = A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs])
 ms = ctypes.c_float(0)
-lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, ip, op, NBUF, N, 1024, 16, None, sp, ctypes.byref(ms))
+lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, ip, op, NBUF, 0, N, 1024, 16, None, sp, ctypes.byref(ms))
 torch.cuda.synchronize()
 img = outs[3].view(1024, 4, 1024, 16).permute(0, 2, 1, 3).reshape(N, 64)
 ok = bool(torch.equal(img, gr[idxs[3]]))
 best = 1e9
 for _ in range(3):
-    lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, ip, op, NBUF, N, 1024, 128, None, sp, ctypes.byref(ms))
+    lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, ip, op, NBUF, 0, N, 1024, 128, None, sp, ctypes.byref(ms))
     best = min(best, ms.value / 128 * 1e3)
 print("rgba32 %.2f us  %.0f GB/s  ok=%s" % (best, 80 * N / best / 1e3, ok))

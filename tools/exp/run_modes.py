@@ -20,10 +20,10 @@ def run(modes, launches=200):
     A = ctypes.c_void_p * NBUF
     ip, op = A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs])
     ms = ctypes.c_float(0)
-    lib.bu_time_uastc_launches(ctx.handle, int(os.environ.get("TARGET", _lib.BC7)), ip, op, NBUF, N, 1024, 32, None, sp, ctypes.byref(ms))
+    lib.bu_time_uastc_launches(ctx.handle, int(os.environ.get("TARGET", _lib.BC7)), ip, op, NBUF, 0, N, 1024, 32, None, sp, ctypes.byref(ms))
     best = 1e9
     for _ in range(3):
-        lib.bu_time_uastc_launches(ctx.handle, int(os.environ.get("TARGET", _lib.BC7)), ip, op, NBUF, N, 1024, launches, None, sp, ctypes.byref(ms))
+        lib.bu_time_uastc_launches(ctx.handle, int(os.environ.get("TARGET", _lib.BC7)), ip, op, NBUF, 0, N, 1024, launches, None, sp, ctypes.byref(ms))
         best = min(best, ms.value / launches * 1e3)
     return best
 base = None

@@ -23,10 +23,10 @@ for lg in range(int(os.environ.get("LG_LO", 11)), int(os.environ.get("LG_HI", 26
     ip, op = A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs])
     ms = ctypes.c_float(0)
     launches = max(8, min(256, (1 << 28) // N))
-    lib.bu_time_uastc_launches(ctx.handle, target, ip, op, nbuf, N, 1024, 8, None, sp, ctypes.byref(ms))
+    lib.bu_time_uastc_launches(ctx.handle, target, ip, op, nbuf, 0, N, 1024, 8, None, sp, ctypes.byref(ms))
     best = 1e9
     for _ in range(3):
-        lib.bu_time_uastc_launches(ctx.handle, target, ip, op, nbuf, N, 1024, launches, None, sp, ctypes.byref(ms))
+        lib.bu_time_uastc_launches(ctx.handle, target, ip, op, nbuf, 0, N, 1024, launches, None, sp, ctypes.byref(ms))
         best = min(best, ms.value / launches * 1e3)
     print("2^%-2d blocks  %9.2f us  %7.1f GB/s  %8.1f Mblocks/s  (nbuf %d)" % (lg, best, 32 * N / best / 1e3, N / best, nbuf), flush=True)
     del ins, outs
