@@ -54,17 +54,47 @@ __device__ __forceinline__ uint4 bu_ld_stream(const uint4* p)
     const bu_v4u r = __builtin_nontemporal_load(reinterpret_cast<const bu_v4u*>(p));
     return make_uint4(r.x, r.y, r.z, r.w);
 }
+// Output stores.  BU_ST_MODE selects the cache policy (experiment knob).  A/B inside one run (tools/exp/ab.sh), 2^20 blocks:
+//   0 nontemporal (nt)            copy 7.15  BC7 10.93  ETC1 25.1  RGBA32 21.2 us
+//   1 plain                            7.07      12.70       25.9         23.1     (results linger dirty in L2)
+//   2 write-through (sc1)              7.16      10.88       24.9         20.6
+//   3 sc0 sc1                          7.13      10.86       24.8         20.7
+//   4 sc1 nt  <- shipped               6.99      10.70       24.75        20.6
+#ifndef BU_ST_MODE
+#define BU_ST_MODE 4
+#endif
+#if BU_ST_MODE == 2
+#define BU_ST_BITS " sc1"
+#elif BU_ST_MODE == 3
+#define BU_ST_BITS " sc0 sc1"
+#elif BU_ST_MODE == 4
+#define BU_ST_BITS " sc1 nt"
+#endif
 __device__ __forceinline__ void bu_st_stream(uint4* p, const uint4 v)
 {
     bu_v4u r;
     r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+#if BU_ST_MODE == 0
     __builtin_nontemporal_store(r, reinterpret_cast<bu_v4u*>(p));
+#elif BU_ST_MODE == 1
+    *reinterpret_cast<bu_v4u*>(p) = r;
+#else
+    // hipcc does not model an asm store: the s_nop 1 keeps its next instruction from overwriting the data registers before
+    // the store has read them (two wait states behind a store of more than 8 bytes on gfx940+)
+    asm volatile("global_store_dwordx4 %0, %1, off" BU_ST_BITS "\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+#endif
 }
 __device__ __forceinline__ void bu_st_stream(uint2* p, const uint2 v)
 {
     bu_v2u r;
     r.x = v.x; r.y = v.y;
+    // 8-byte stores stay nontemporal: an sc1 store narrower than 16 bytes is one fabric write per lane
+    // (ETC1S -> ETC1 at 2^18 blocks: 4.7 -> 6.2 us with sc1 nt)
+#if BU_ST_MODE == 1
+    *reinterpret_cast<bu_v2u*>(p) = r;
+#else
     __builtin_nontemporal_store(r, reinterpret_cast<bu_v2u*>(p));
+#endif
 }
 
 // UASTC -> {ASTC, BC7, ETC1, ETC2, RGBA32}: replaces the loop of uastc.rs:157-165 / 96-107
@@ -127,7 +157,32 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr),
 // BU_RUN_PIECE_MIB (piece size of the two-stream upload pipeline, 0 = off).
 // modes by descending code-path length (BC7 VALU counts), 5 bits each: entries 0-11 / 12-19
-constexpr unsigned long long BU_COST_ORDER_LO = 0x2c8cb0b0e281123ull, BU_COST_ORDER_HI = 0x9bdb1401caull;
+constexpr unsigned long long bu_cost_pack(int from, int n)
+{
+    unsigned long long v = 0;
+    for (int i = 0; i < n; i++) v |= (unsigned long long)BU_COST_ORDER[from + i] << (5 * i);
+    return v;
+}
+constexpr unsigned long long BU_COST_ORDER_LO = bu_cost_pack(0, 12), BU_COST_ORDER_HI = bu_cost_pack(12, 8);
+static_assert(BU_COST_ORDER_LO == 0x2c8cb0b0e281123ull && BU_COST_ORDER_HI == 0x9bdb1401caull, "cost order moved");
+// mode of sort key k (scalar)
+__device__ __forceinline__ uint32_t bu_mode_of_key(uint32_t k)
+{
+    return (uint32_t)((k < 12 ? (BU_COST_ORDER_LO >> (5 * k)) : (BU_COST_ORDER_HI >> (5 * (k - 12)))) & 31u);
+}
+// inclusive add-scan over lanes 0..31 (and 32..63) with DPP row shifts: 5 VALU, no LDS round trips
+__device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    return v;
+}
+#ifndef BU_PARB
+#define BU_PARB 1
+#endif
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // The large-input configurations (>= 512 Ki blocks), per target; all A/B'd inside one run (tools/exp/ab.sh) on the
@@ -144,16 +199,31 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
 template <int TARGET>
 struct BuBigCfg {
+    static constexpr bool PREFETCH = false, DIRECT = false;
     static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
     static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
+// experiment knobs (tools/exp/build_variant.sh -DBU_X_...): shape of the BC7 large configuration
+#ifndef BU_X_WGS
+#define BU_X_WGS 512
+#define BU_X_BPT 2
+#define BU_X_PER_CU 4
+#endif
+#ifndef BU_X_PREFETCH
+#define BU_X_PREFETCH false
+#endif
+#ifndef BU_X_DIRECT
+#define BU_X_DIRECT false
+#endif
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
-    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr int WGS = BU_X_WGS, BPT = BU_X_BPT, WG_PER_CU = BU_X_PER_CU, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
+    static constexpr bool PREFETCH = BU_X_PREFETCH, DIRECT = BU_X_DIRECT;
 };
 template <>
 struct BuBigCfg<BU_TGT_ASTC> {
+    static constexpr bool PREFETCH = false, DIRECT = false;
     static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = true;
 };
@@ -201,7 +271,16 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     if constexpr (SKEW > 0) {
         if (blockIdx.x >= gridDim.x / 2 && gridDim.x > 1) __builtin_amdgcn_s_sleep(SKEW);
     }
-    constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
+#ifdef BU_X_SLOT1
+    // EXPERIMENT: stagger by residency slot (workgroups b, b + gridDim/4, ... share a CU: tools/exp/census.hip)
+    {
+        const unsigned slot = blockIdx.x / (gridDim.x / 4u > 0 ? gridDim.x / 4u : 1u);
+        if (slot == 1) __builtin_amdgcn_s_sleep(BU_X_SLOT1);
+        if (slot == 2) __builtin_amdgcn_s_sleep(BU_X_SLOT2);
+        if (slot == 3) __builtin_amdgcn_s_sleep(BU_X_SLOT3);
+    }
+#endif
+    constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ BuTables T;
     // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
     // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts).  The sorted input tile
@@ -217,8 +296,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     uint4* const sblk = BU_ALIAS ? sout : sblk_store;
     __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
     __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
-    __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks, next_chunk;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
+    // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
+    __shared__ uint32_t cnt[2][32], next_chunk[2];
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
     unsigned tile = blockIdx.x;
     uint4 v[BU_BPT];
@@ -228,78 +309,57 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         v[j] = (tile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
     bu_stage_tables_n<WGS, TARGET>(T, tables);
-    if (tid < 32) cnt[tid] = 0;
+    if (tid < 64) (&cnt[0][0])[tid] = 0;
+    if (tid < 2) next_chunk[tid] = 0;
     __syncthreads();
     BU_STAMP(1)
-    for (; tile < n_tiles; tile += gridDim.x) {
+    unsigned par = 0;
+    for (; tile < n_tiles; tile += gridDim.x, par ^= 1u) {
         const unsigned tbase = tile * BU_TILE;
-        // ---- A: mode + rank within the mode (counting sort, pass 1) ----
-        // Rank within the mode = one LDS atomic per block.  64 lanes adding to ONE counter serialise, though, and that is
+        // ---- A: sort key + rank within the key (counting sort, pass 1) ----
+        // key = position of the block's mode in BU_COST_ORDER (runs are laid out heaviest code path first).
+        // Rank within the key = one LDS atomic per block.  64 lanes adding to ONE counter serialise, though, and that is
         // exactly what coherent textures produce (flat regions: long runs of one mode).  A wave whose loads are each of a
         // single mode therefore takes an aggregated path -- one atomic of 64 by lane 0 per load, rank = lane id -- chosen
         // by a wave-uniform branch; every other wave runs the plain per-lane atomics unchanged.
-        uint32_t mode[BU_BPT], pos[BU_BPT];
+        uint32_t key[BU_BPT], pos[BU_BPT];
         bool uniform = true;
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             const bool valid = tbase + j * BU_WG + tid < n_blocks;
-            mode[j] = valid ? T.mode_lut[v[j].x & 127u] : 31u;
-            uniform = uniform && (__ballot(mode[j] == (uint32_t)__builtin_amdgcn_readfirstlane(mode[j])) == ~0ull) && mode[j] < 20u;
+            key[j] = valid ? T.key_lut[v[j].x & 127u] : 31u;
+            uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && key[j] < 20u;
         }
         if (uniform) {
             uint32_t lead[BU_BPT];
 #pragma unroll
-            for (int j = 0; j < BU_BPT; j++) lead[j] = lane == 0 ? atomicAdd(&cnt[mode[j]], 64u) : 0u;
+            for (int j = 0; j < BU_BPT; j++) lead[j] = lane == 0 ? atomicAdd(&cnt[par][key[j]], 64u) : 0u;
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) pos[j] = (uint32_t)__builtin_amdgcn_readfirstlane(lead[j]) + lane;
         } else {
 #pragma unroll
-            for (int j = 0; j < BU_BPT; j++) pos[j] = atomicAdd(&cnt[mode[j]], 1u);  // lanes past the end hit the dummy counter 31: no exec-mask region, the atomics issue back to back
+            for (int j = 0; j < BU_BPT; j++) pos[j] = atomicAdd(&cnt[par][key[j]], 1u);  // lanes past the end hit the dummy counter 31: no exec-mask region, the atomics issue back to back
         }
         BU_STAMP(2)
-        __syncthreads();
+        __syncthreads();  // (1) every rank is final
         BU_STAMP(3)
-        // ---- B: run starts and the chunk list (one wave) ----
-        if (wave == 0) {
-            // lane l owns mode BU_COST_ORDER[l]: runs are laid out heaviest code path first, so the dynamically
-            // scheduled chunk loop below ends with the cheap chunks (longest-processing-time-first balancing)
-            const uint32_t mo = (uint32_t)((lane < 12 ? (BU_COST_ORDER_LO >> (5 * lane)) : (BU_COST_ORDER_HI >> (5 * (lane - 12)))) & 31u);
-            const uint32_t c = lane < 20 ? cnt[mo] : 0u;
-            uint32_t incl = c, nch = (c + 63u) >> 6, cincl = nch;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const uint32_t a = __shfl_up(incl, d), b2 = __shfl_up(cincl, d);
-                if (lane >= (unsigned)d) {
-                    incl += a;
-                    cincl += b2;
-                }
-            }
-            const uint32_t st = incl - c, cst = cincl - nch;
-            if (lane < 20) start[mo] = st;
-            // chunk list: lanes l, l+20, l+40 share run l (k = 0,3,6.. / 1,4,7.. / 2,5,8..), so a tile made of one single
-            // mode (64 chunks in one run) costs 22 loop trips here instead of 64 while 15 other waves wait at the barrier
-            {
-                const int src = (int)(lane % 20u);
-                const uint32_t r_c = __shfl(c, src), r_st = __shfl(st, src), r_cst = __shfl(cst, src), r_mo = __shfl(mo, src);
-                const uint32_t r_nch = (r_c + 63u) >> 6;
-                if (lane < 60)
-                    for (uint32_t k = lane / 20u; k < r_nch; k += 3u) {
-                        const uint32_t left = r_c - 64u * k;
-                        chunk[r_cst + k] = r_mo | ((r_st + 64u * k) << 8) | ((left < 64u ? left : 64u) << 24);
-                    }
-            }
-            if (lane == 19) n_chunks = cincl;
-            if (lane < 32) cnt[lane] = 0;
-            if (lane == 0) next_chunk = 0;
-        }
-        __syncthreads();
-        BU_STAMP(4)
+        // ---- B: run starts and the chunk map, derived by EVERY wave for itself ----
+        // Lane k < 20 holds run k: blocks in the low half, 64-block chunks in the high half of one word; a DPP scan gives
+        // every run's first slot and first chunk number.  No wave waits for another one here (the round-1 kernel had one
+        // wave build a chunk list in LDS while seven stood at a barrier).
+        const uint32_t run_c = lane < 20u ? cnt[par][lane] : 0u;
+        const uint32_t run_pk = run_c | (((run_c + 63u) >> 6) << 16);
+        const uint32_t run_incl = bu_scan32(run_pk), run_excl = run_incl - run_pk;  // lanes 20..31 carry the totals
+        const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)run_incl, 31) >> 16;
+        if (tid < 32) cnt[par ^ 1u][tid] = 0;  // the other parity: last read in B of the previous tile, next written in A of the next one
+        if (tid == 0) next_chunk[par ^ 1u] = 0;
         // ---- scatter into sorted order (counting sort, pass 2) ----
         uint32_t dest[BU_BPT];
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
-            dest[j] = mode[j] < 20u ? start[mode[j]] + pos[j] : 0u;
-            if (mode[j] < 20u) {
+            const uint32_t st = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key[j] << 2), (int)run_excl) & 0xFFFFu;
+            dest[j] = key[j] < 20u ? st + pos[j] : 0u;
+            if (key[j] < 20u) {
                 sblk[dest[j]] = v[j];
                 if constexpr (DIRECT) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
             }
@@ -314,22 +374,23 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                 vn[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
-        __syncthreads();
+        BU_STAMP(4)
+        __syncthreads();  // (2) the sorted tile is complete
         BU_STAMP(5)
         // ---- C: whole chunks, wave-uniform mode ----
-        // dynamic chunk scheduling: waves take the next chunk as they free up.  The claim for the FOLLOWING chunk is issued
-        // before the current one is transcoded, so its LDS round trip hides under the transcode (12.65 -> 12.58 us).
-        // (Tried: static serpentine assignment, 13.0 us; claims two ahead with the chunk list in registers and the next
-        // chunk's blocks prefetched, 13.1 us -- a wave sitting on two claimed chunks unbalances the tail.)
-        const uint32_t nc = n_chunks;
+        // dynamic chunk scheduling: waves take the next chunk as they free up (one LDS atomic per chunk).  The claim for the
+        // FOLLOWING chunk is issued before the current one is transcoded, so its LDS round trip hides under the transcode.
         uint32_t c_next = 0;
-        if (lane == 0) c_next = atomicAdd(&next_chunk, 1u);
+        if (lane == 0) c_next = atomicAdd(&next_chunk[par], 1u);
         for (;;) {
             const uint32_t c = __builtin_amdgcn_readfirstlane(c_next);
             if (c >= nc) break;
-            if (lane == 0) c_next = atomicAdd(&next_chunk, 1u);
-            const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk[c]);
-            const uint32_t m = desc & 31u, s0 = (desc >> 8) & 0xFFFFu, count = desc >> 24;
+            if (lane == 0) c_next = atomicAdd(&next_chunk[par], 1u);
+            // chunk c belongs to the first run whose inclusive chunk count exceeds c
+            const uint32_t r = (uint32_t)__builtin_ctzll(__ballot((run_incl >> 16) > c));
+            const uint32_t r_pk = (uint32_t)__builtin_amdgcn_readlane((int)run_pk, (int)r), r_ex = (uint32_t)__builtin_amdgcn_readlane((int)run_excl, (int)r);
+            const uint32_t k64 = (c - (r_ex >> 16)) << 6;
+            const uint32_t m = bu_mode_of_key(r), s0 = (r_ex & 0xFFFFu) + k64, left = (r_pk & 0xFFFFu) - k64, count = left < 64u ? left : 64u;
             const bool active = lane < count;
             const uint32_t slot = s0 + (active ? lane : 0u);
             const uint4 bv = sblk[slot];
@@ -360,7 +421,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                         const unsigned by = idx / bpr, bx = idx - by * bpr;
                         uint4* img = reinterpret_cast<uint4*>(out);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) img[(size_t)((4 * by + r) * bpr + bx)] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+                        for (int r2 = 0; r2 < 4; r2++) img[(size_t)((4 * by + r2) * bpr + bx)] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
                     } else if constexpr (TARGET == BU_TGT_ETC1) {
                         reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
                     } else {
@@ -368,7 +429,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                     }
                 } else if constexpr (TARGET == BU_TGT_RGBA) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) sout[r * BU_TILE + slot] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+                    for (int r2 = 0; r2 < 4; r2++) sout[r2 * BU_TILE + slot] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
                     sst[slot] = (uint8_t)st;
                 } else {
                     sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -377,13 +438,13 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             }
         }
         BU_STAMP(6)
-        __syncthreads();
+        __syncthreads();  // (3) every result is in LDS
         BU_STAMP(7)
         // ---- D: results leave in original order ----
         if constexpr (!DIRECT) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                if (mode[j] < 20u) {
+                if (key[j] < 20u) {
                     const unsigned idx = tbase + j * BU_WG + tid;
                     const uint32_t st = sst[dest[j]];
                     if (st) bu_report(status, base + idx, (int)st);
@@ -410,7 +471,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                 v[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
-        __syncthreads();
+        // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only
+        // after its reads of this tile's results have completed
     }
     BU_STAMP(8)
 }
@@ -736,7 +798,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         using C = BuBigCfg<T>;                                                                                                          \
         const size_t btiles = (nb + (size_t)C::WGS * C::BPT - 1) / ((size_t)C::WGS * C::BPT);                                           \
         const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
                            dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);      \
     } else if (grid_cap == 0) {                                                                                                         \
         /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \

@@ -24,6 +24,10 @@ static_assert(sizeof(BuPart) == 16, "BuPart must be 16 bytes");
 // (bu_table_range below): every workgroup copies its tables from L2 into LDS, and with four workgroups per CU on
 // 1024-block tiles the whole 9.3 KiB blob would be more than half of the 16 KiB of payload the workgroup moves.
 //   [BC7 only][common front-end][texel unpack: RGBA32, ETC][ASTC only][ETC only]
+// Modes by descending length of their code path (BC7 VALU counts, tools/exp/mode_isa.py): the mode-sorted kernel lays the
+// runs out in this order so that dynamically scheduled chunks end with the cheap ones.  Entry 19 = invalid mode code.
+constexpr uint8_t BU_COST_ORDER[20] = {3, 9, 4, 16, 2, 7, 12, 1, 11, 6, 18, 5, 10, 14, 0, 8, 17, 13, 15, 19};
+
 struct BuTables {
     // ---- BC7 only ----
     alignas(16) uint8_t deq5[56];  // (deq*31+127)/255 for ranges 7 (ofs 0) and 12 (ofs 16): BC7 mode 2 endpoints (bc7.rs:262-264)
@@ -38,6 +42,7 @@ struct BuTables {
     uint16_t quint3[128];  // 7-bit group -> 3 quints, digit i in bits [3i,3i+3)  (uastc.rs:629-655)
     uint8_t deq[504];      // endpoint dequantisation, ranges 7,8,11,12,13,18,19  (uastc.rs:585-614)
     uint8_t mode_lut[128];    // uastc.rs:560-577
+    uint8_t key_lut[128];     // sort key of the mode-sorted kernel: position of the block's mode in BU_COST_ORDER (19 = invalid code)
     BuPart part[61];       // partition records
     // ---- texel unpack (RGBA32, ETC1, ETC2) ----
     alignas(16) uint32_t wpack[64];  // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
@@ -171,6 +176,11 @@ static inline void bu_build_tables(BuTables* t)
     for (int i = 0; i < 32; i++) t->etc1_mod[i] = BU_ETC1_MOD[i];
     for (int i = 0; i < 128; i++) t->etc2_amod[i] = BU_ETC2_ALPHA_MOD[i];
     for (int i = 0; i < 128; i++) t->mode_lut[i] = BU_MODE_LUT[i];
+    for (int i = 0; i < 128; i++) {
+        t->key_lut[i] = 19;
+        for (int k = 0; k < 20; k++)
+            if (BU_COST_ORDER[k] == BU_MODE_LUT[i]) t->key_lut[i] = (uint8_t)k;
+    }
     for (int i = 0; i < 30; i++) {
         uint64_t m = 0;
         for (int tx = 0; tx < 16; tx++)

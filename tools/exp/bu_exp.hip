@@ -8,6 +8,11 @@
         unsigned long long t_;                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
         stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = t_;        \
+        if ((k) == 0 || (k) == 8) {                                                                   \
+            unsigned long long r_;                                                                    \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_)::"memory");            \
+            stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + 9 + (k) / 8] = r_; \
+        }                                                                                             \
     }
 #define BU_CHUNK_DECL unsigned chunk_no_ = 0;
 // per-chunk stamps: slot k of chunk record n of this wave: [time, value]

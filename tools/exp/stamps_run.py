@@ -37,7 +37,13 @@ lib.bu_exp_set_stamps(vp(buf.data_ptr()))
 lib.bu_exp_time(h, variant, ip, op, NBUF, N, 5, sp, ctypes.byref(ms))
 torch.cuda.synchronize()
 lib.bu_exp_set_stamps(None)
-s = buf.cpu().numpy()[: nw * 16].reshape(nw, 16)[:, :9].astype(np.float64)
+raw = buf.cpu().numpy()[: nw * 16].reshape(nw, 16)
+s = raw[:, :9].astype(np.float64)
+rt = (raw[:, 10] - raw[:, 9]).astype(np.float64)  # s_memrealtime ticks (100 MHz) over the wave's life
+ok = rt > 0
+print("shader clock from s_memtime / s_memrealtime over a wave's life: %.0f MHz (median), wave life %.2f us (median), %.2f us (max)" % (
+    np.median((s[ok, 8] - s[ok, 0]) / rt[ok]) * 100, np.median(rt[ok]) / 100, rt[ok].max() / 100))
+print("kernel span by s_memrealtime: %.2f us" % ((raw[:, 10].max() - raw[:, 9].min()) / 100))
 names = ["start", "tables+loads", "A done", "bar1", "B done(bar2)", "scatter(bar3)", "C done", "bar4", "end"]
 t0 = s[:, 0].min()
 print("shader clocks since the first wave started: mean / min / p50 / max   (per-wave delta mean)")
@@ -46,3 +52,29 @@ for k in range(9):
     d = (s[:, k] - s[:, k - 1]).mean() if k else 0
     print("  %-14s %8.0f %8.0f %8.0f %8.0f   (%6.0f)" % (names[k], a.mean(), a.min(), np.median(a), a.max(), d))
 print("kernel span first start -> last end: %.0f clocks" % (s[:, 8].max() - t0))
+
+st_us = (raw[:, 9] - raw[:, 9].min()) / 100.0
+en_us = (raw[:, 10] - raw[:, 9].min()) / 100.0
+print("wave START times (us after the first wave): p1 %.2f p10 %.2f p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(st_us, [1, 10, 25, 50, 75, 90, 99, 100])))
+print("wave END   times (us after the first wave): p1 %.2f p10 %.2f p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(en_us, [1, 10, 25, 50, 75, 90, 99, 100])))
+wg = np.arange(nw) // wpw
+for q in range(4):
+    sel = (wg // 256) == q
+    if sel.any():
+        print("  CU slot %d (blockIdx %4d..%4d): start p50 %.2f max %.2f | end p50 %.2f max %.2f | life p50 %.2f us" % (
+            q, q * 256, q * 256 + 255, np.median(st_us[sel]), st_us[sel].max(), np.median(en_us[sel]), en_us[sel].max(), np.median(en_us[sel] - st_us[sel])))
+# phase boundaries in real time for the median wave: scale shader clocks by the measured clock
+
+# per-slot Gantt: median real time (us after the first wave) at which waves of each CU slot pass each stamp
+mhz = np.median((s[ok, 8] - s[ok, 0]) / rt[ok]) * 100
+x11 = (raw[:, 11].astype(np.float64) - s[:, 1]) / mhz
+x12 = (raw[:, 12].astype(np.float64) - raw[:, 11].astype(np.float64)) / mhz
+x2 = (s[:, 2] - raw[:, 12].astype(np.float64)) / mhz
+for nm, x in (("stamp1 -> stamp11 (back to back: cost of one stamp)", x11), ("stamp11 -> keys known", x12), ("keys known -> A done (atomics returned)", x2)):
+    print("%-55s p10 %.3f p50 %.3f p90 %.3f us" % (nm, np.percentile(x, 10), np.median(x), np.percentile(x, 90)))
+t_us = st_us[:, None] + (s - s[:, :1]) / mhz
+print("median time (us) at each stamp, per CU slot:   " + "  ".join("%-6s" % n[:6] for n in names))
+for q in range(4):
+    sel = (wg // 256) == q
+    if sel.any():
+        print("  slot %d                                       " % q + "  ".join("%6.2f" % np.median(t_us[sel, k]) for k in range(9)))
