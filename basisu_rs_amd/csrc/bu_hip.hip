@@ -197,11 +197,19 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 //   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
 // ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp); ETC1/ETC2 (81)
 // do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
+// experiment knobs for the ETC1 / ETC2 large configuration
+#ifndef BU_E_BPT
+#define BU_E_BPT 4
+#define BU_E_PER_CU 2
+#define BU_E_MINW 1
+#define BU_E_SKEW 40
+#define BU_E_ALL false
+#endif
 template <int TARGET>
 struct BuBigCfg {
     static constexpr bool PREFETCH = false, DIRECT = false;
-    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
-    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
+    static constexpr int WGS = 512, BPT = BU_E_BPT, WG_PER_CU = BU_E_PER_CU, SKEW = BU_E_SKEW, MINW = BU_E_MINW;
+    static constexpr bool ALL_SIZES = BU_E_ALL;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
 // experiment knobs (tools/exp/build_variant.sh -DBU_X_...): shape of the BC7 large configuration
 #ifndef BU_X_WGS

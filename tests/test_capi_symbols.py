@@ -59,3 +59,28 @@ def test_pure_host_helpers_of_the_abi(oracle):
 
     rows = np.random.default_rng(0).integers(0, 256, size=(500, 4), dtype=np.uint8)
     assert (etc1s_selector_from_rows(rows) == oracle.selectors_from_rows(rows)).all()
+
+
+def test_rust_facade_declarations_match_the_header():
+    """rust/src/ffi.rs (source only, no toolchain here): every extern fn it declares must be a symbol of the header with the
+    same number of parameters -- the cheapest check that the uncompiled binding has not drifted from the C ABI"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "basisu_hip.h")).read(), flags=re.S)
+    c_arity = {}
+    for m in re.finditer(r"\b(bu_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        c_arity[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    rs = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    rs = re.sub(r"//.*", "", rs)
+    seen = 0
+    for m in re.finditer(r"pub fn (bu_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", rs, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if not args else args.count(":")
+        assert name in c_arity, name
+        assert n == c_arity[name], (name, n, c_arity[name])
+        seen += 1
+    assert seen >= 35
+    # the eleven public functions of the reference crate (lib.rs:20-53) exist in the facade
+    lib_rs = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    for fn in ("read_to_rgba", "read_to_etc1", "read_to_etc2", "read_to_uastc", "read_to_astc", "read_to_bc7", "unpack_uastc_block_to_rgba",
+               "transcode_uastc_block_to_astc", "transcode_uastc_block_to_bc7", "transcode_uastc_block_to_etc1", "transcode_uastc_block_to_etc2"):
+        assert re.search(r"pub fn %s\(" % fn, lib_rs), fn
