@@ -273,21 +273,23 @@ __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables*
 template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                                const BuTables* __restrict__ tables BU_STAMP_ARG)
+                                                                const BuTables* __restrict__ tables, unsigned cus BU_STAMP_ARG)
 {
     BU_STAMP(0)
     if constexpr (SKEW > 0) {
         if (blockIdx.x >= gridDim.x / 2 && gridDim.x > 1) __builtin_amdgcn_s_sleep(SKEW);
     }
-#ifdef BU_X_SLOT1
-    // EXPERIMENT: stagger by residency slot (workgroups b, b + gridDim/4, ... share a CU: tools/exp/census.hip)
+    // Static priority by residency generation.  Workgroups are dealt breadth-first (b, b + CUs, b + 2 CUs, ... share a CU:
+    // tools/exp/census.hip), and the instruction arbiter serves the OLDEST wave first, so the four tiles of a CU finish
+    // 1.5 us apart and the last one runs its latency-bound chain with the vector units nearly idle (phase stamps,
+    // profiles/r02_*stamps*).  Raising the later generations' priority makes them catch up while the older ones fill
+    // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
     {
-        const unsigned slot = blockIdx.x / (gridDim.x / 4u > 0 ? gridDim.x / 4u : 1u);
-        if (slot == 1) __builtin_amdgcn_s_sleep(BU_X_SLOT1);
-        if (slot == 2) __builtin_amdgcn_s_sleep(BU_X_SLOT2);
-        if (slot == 3) __builtin_amdgcn_s_sleep(BU_X_SLOT3);
+        const unsigned gen = blockIdx.x / (cus ? cus : 1u);
+        if (gen == 1) __builtin_amdgcn_s_setprio(1);
+        if (gen == 2) __builtin_amdgcn_s_setprio(2);
+        if (gen >= 3) __builtin_amdgcn_s_setprio(3);
     }
-#endif
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ BuTables T;
     // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
@@ -807,14 +809,14 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         const size_t btiles = (nb + (size_t)C::WGS * C::BPT - 1) / ((size_t)C::WGS * C::BPT);                                           \
         const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
-                           dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);      \
+                           dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);      \
     } else if (grid_cap == 0) {                                                                                                         \
         /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(512), 0, stream, pin, pout, \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);                                         \
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);                                         \
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);
             const bool many = nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
             switch (target) {
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
@@ -828,7 +830,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
                 const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * BU_RGBA_WG_PER_CU;
                 const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
                 hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_RGBA_WGS, BU_RGBA_BPT, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(BU_RGBA_WGS), 0, stream, pin,
-                                   pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables BU_STAMP_PASS);
+                                   pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);
             } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }
