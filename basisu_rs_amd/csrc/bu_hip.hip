@@ -1611,7 +1611,14 @@ bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* 
         if (st) return st;
     }
     BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
-    BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    // poll instead of a blocking wait: the caller's wall clock around this call (bench.py's `value`) should not carry the
+    // tens of microseconds a sleeping host thread needs to be woken up -- they are as long as several steps
+    for (;;) {
+        const hipError_t q = hipEventQuery(ctx->ev1);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
+    }
+    (void)hipGetLastError();
     BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
     return BU_OK;
 }

@@ -163,6 +163,7 @@ def main():
     from basisu_rs_amd import Context, _lib, synth
 
     env = Env()
+    env.json_fd = json_fd
     env.args, env.torch, env.dist = args, torch, dist
     env.rank, env.world, env.local_rank, env.use_dist = rank, world, local_rank, use_dist
     env.ctx = Context(local_rank)
@@ -187,6 +188,29 @@ def main():
 
 class Env:
     pass
+
+
+class GatherWatchdog:
+    """The gather rows are secondary: if a transport hangs (a collective one rank never entered, an IPC mapping the driver
+    refuses), the headline line must still come out.  After `seconds` rank 0 writes the line it has, with the time-out
+    recorded under "allgather", and every rank leaves the process without waiting for the stuck call."""
+
+    def __init__(self, env, line, seconds=240):
+        import threading
+
+        self.env, self.line = env, line
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def fire(self):
+        if self.env.rank == 0:
+            self.line["allgather"] = {"error": "timed out: no transport finished; the transcode numbers above are unaffected"}
+            os.write(self.env.json_fd, (json.dumps(self.line) + "\n").encode())
+        os._exit(0)
+
+    def cancel(self):
+        self.t.cancel()
 
 
 def check(env, st, what):
@@ -237,6 +261,13 @@ def measure_gather(env, full_buf, shard_bytes, verify=None, reps=10):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
+    def all_ok(ok_here):
+        """every rank learns whether every rank got through its local setup: a rank that failed must not leave the others
+        waiting inside a collective it never enters"""
+        f = torch.tensor([1 if ok_here else 0], dtype=torch.int32, device=env.dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
     def scrub():  # zero the other ranks' slots so that a transport that does nothing cannot pass the check
         t = full_buf.tensor()
         if rank > 0:
@@ -248,15 +279,20 @@ def measure_gather(env, full_buf, shard_bytes, verify=None, reps=10):
     # ---- RCCL, in place ----
     try:
         ident = torch.zeros(env._lib.COMM_ID_BYTES, dtype=torch.uint8)
+        id_ok = True
         if rank == 0:
             buf = (ctypes.c_uint8 * env._lib.COMM_ID_BYTES)()
-            check(env, lib.bu_comm_unique_id(buf), "bu_comm_unique_id")
+            id_ok = lib.bu_comm_unique_id(buf) == 0
             ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if not all_ok(id_ok):
+            raise RuntimeError("bu_comm_unique_id failed (no RCCL library could be resolved)")
         ident = ident.to(env.dev)
         dist.broadcast(ident, 0)
         idb = (ctypes.c_uint8 * env._lib.COMM_ID_BYTES)(*ident.cpu().tolist())
         comm = ctypes.c_void_p(0)
-        check(env, lib.bu_comm_create(ctx.handle, world, rank, idb, ctypes.byref(comm)), "bu_comm_create")
+        st_c = lib.bu_comm_create(ctx.handle, world, rank, idb, ctypes.byref(comm))  # collective: every rank calls it
+        if not all_ok(st_c == 0):
+            raise RuntimeError("bu_comm_create: " + lib.bu_status_string(st_c).decode())
         scrub()
         s = timed(lambda: check(env, lib.bu_allgather_inplace(comm, ctypes.c_void_p(full_buf.ptr), shard_bytes, env.sp), "bu_allgather_inplace"))
         ok = bool(verify(full_buf.tensor())) if verify else None
@@ -268,20 +304,25 @@ def measure_gather(env, full_buf, shard_bytes, verify=None, reps=10):
     # ---- direct peer pulls over HIP IPC ----
     try:
         hb = (ctypes.c_uint8 * env._lib.IPC_HANDLE_BYTES)()
-        check(env, lib.bu_ipc_export(ctx.handle, ctypes.c_void_p(full_buf.ptr), hb), "bu_ipc_export")
+        st_e = lib.bu_ipc_export(ctx.handle, ctypes.c_void_p(full_buf.ptr), hb)
+        if not all_ok(st_e == 0):
+            raise RuntimeError("bu_ipc_export: " + lib.bu_last_error(ctx.handle).decode())
         mine = torch.tensor(list(hb), dtype=torch.uint8, device=env.dev)
         allh = torch.empty(world * env._lib.IPC_HANDLE_BYTES, dtype=torch.uint8, device=env.dev)
         dist.all_gather_into_tensor(allh, mine)
         allh = allh.cpu().view(world, -1)
         peers = (ctypes.c_void_p * world)()
+        open_ok = True
         for p_ in range(world):
             if p_ == rank:
                 peers[p_] = full_buf.ptr
                 continue
             hp = (ctypes.c_uint8 * env._lib.IPC_HANDLE_BYTES)(*allh[p_].tolist())
             pp = ctypes.c_void_p(0)
-            check(env, lib.bu_ipc_open(ctx.handle, hp, ctypes.byref(pp)), "bu_ipc_open")
+            open_ok = open_ok and lib.bu_ipc_open(ctx.handle, hp, ctypes.byref(pp)) == 0
             peers[p_] = pp.value
+        if not all_ok(open_ok):
+            raise RuntimeError("bu_ipc_open: " + lib.bu_last_error(ctx.handle).decode())
         scrub()
         dist.barrier()
 
@@ -375,6 +416,21 @@ def run_array512(env):
     kern_s = ev_max / args.steps
     achieved = BYTES_PER_BLOCK * nb / kern_s / 1e9  # per GPU: this rank's shard (the even split makes all ranks alike)
 
+    line = {
+        "metric": "M 4x4 blocks/s UASTC->BC7 texture array 512 x (1024x1024)",
+        "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt_max / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "UASTC->BC7, texture array of 512 slices x 65 536 blocks (512 MiB in, 512 MiB out) per step; rank r owns "
+                               "slices [r*512/N, (r+1)*512/N), one launch over its contiguous range; A-gold blocks; %d rotated "
+                               "input shards / full output buffers per rank" % nrot,
+                   "blocks_per_step": total, "slices_per_gpu": hi - lo, "gb_s_in": round(value * 16 / 1e3, 1)},
+        "transcode_only": {"mblocks_s": round(total / kern_s / 1e6, 1), "us_per_step_kernel_max_over_ranks": round(kern_s * 1e6, 3),
+                           "note": "all blocks / slowest rank's kernel time (hipEvents on the launch stream)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
+                     "bytes_per_launch": BYTES_PER_BLOCK * nb, "note": "per GPU, on its shard"},
+    }
     gather = None
     if env.use_dist:
         # shard of rotation slot 0 is verified above; re-run it so that slot 0 holds this rank's result, then gather slot 0
@@ -392,24 +448,11 @@ def run_array512(env):
                     ok = ok and bool(torch.equal(v[r_][(s - a) * bps: (s - a + 1) * bps], expect(s)))
             return ok
 
+        dog = GatherWatchdog(env, line)
         gather = measure_gather(env, fulls[0], shard_bytes, verify)
+        dog.cancel()
     for f in fulls:
         f.free()
-    line = {
-        "metric": "M 4x4 blocks/s UASTC->BC7 texture array 512 x (1024x1024)",
-        "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt_max / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "UASTC->BC7, texture array of 512 slices x 65 536 blocks (512 MiB in, 512 MiB out) per step; rank r owns "
-                               "slices [r*512/N, (r+1)*512/N), one launch over its contiguous range; A-gold blocks; %d rotated "
-                               "input shards / full output buffers per rank" % nrot,
-                   "blocks_per_step": total, "slices_per_gpu": hi - lo, "gb_s_in": round(value * 16 / 1e3, 1)},
-        "transcode_only": {"mblocks_s": round(total / kern_s / 1e6, 1), "us_per_step_kernel_max_over_ranks": round(kern_s * 1e6, 3),
-                           "note": "all blocks / slowest rank's kernel time (hipEvents on the launch stream)"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
-                     "bytes_per_launch": BYTES_PER_BLOCK * nb, "note": "per GPU, on its shard"},
-    }
     if gather:
         line["allgather"] = gather
         best = min([g["ms"] for g in gather.values() if isinstance(g, dict) and "ms" in g] or [None]) if gather else None
@@ -664,25 +707,6 @@ def run_atlas4096(env):
         del rg_out
 
 
-    allgather = None
-    if use_dist:
-        # reassembly of the texture array: every rank's 16 MiB BC7 result at rank*16 MiB of a world*16 MiB buffer on every rank
-        shard_bytes = N_BLOCKS * 16
-        full = RawDeviceBuffer(env, world * shard_bytes)
-        full.tensor()[rank * shard_bytes:(rank + 1) * shard_bytes].copy_(outs[0].view(-1))
-        torch.cuda.synchronize()
-        mine_ref = outs[0].view(-1)
-
-        def verify(ft):  # own slot intact; every other slot non-zero (each rank's atlas differs, so no reference is held here)
-            v = ft.view(world, shard_bytes)
-            ok = bool(torch.equal(v[rank], mine_ref))
-            for r_ in range(world):
-                ok = ok and bool(v[r_].any())
-            return ok
-
-        allgather = measure_gather(env, full, shard_bytes, verify)
-        full.free()
-
     line = {
         "metric": "M 4x4 blocks/s UASTC->BC7 4096x4096",
         "value": round(value, 1),
@@ -709,9 +733,30 @@ def run_atlas4096(env):
     if tr:
         line["roofline"]["traffic"] = tr[0]
         line["roofline"]["traffic_source"] = tr[1] + " (committed rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this kernel; not measured in this run)"
+    line["extra"] = extra
+    allgather = None
+    if use_dist:
+        # reassembly of the texture array: every rank's 16 MiB BC7 result at rank*16 MiB of a world*16 MiB buffer on every rank
+        shard_bytes = N_BLOCKS * 16
+        full = RawDeviceBuffer(env, world * shard_bytes)
+        full.tensor()[rank * shard_bytes:(rank + 1) * shard_bytes].copy_(outs[0].view(-1))
+        torch.cuda.synchronize()
+        mine_ref = outs[0].view(-1)
+
+        def verify(ft):  # own slot intact; every other slot non-zero (each rank's atlas differs, so no reference is held here)
+            v = ft.view(world, shard_bytes)
+            ok = bool(torch.equal(v[rank], mine_ref))
+            for r_ in range(world):
+                ok = ok and bool(v[r_].any())
+            return ok
+
+        dog = GatherWatchdog(env, line)
+        allgather = measure_gather(env, full, shard_bytes, verify)
+        dog.cancel()
+        full.free()
+
     if allgather:
         line["allgather"] = allgather
-    line["extra"] = extra
     if world == 1 and rank == 0 and not args.no_cpu and not args.headline_only:
         line["cpu_baseline"] = cpu_baseline(golden, idx0)
     return line
