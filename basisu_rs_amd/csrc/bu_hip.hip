@@ -286,9 +286,16 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
     {
         const unsigned gen = blockIdx.x / (cus ? cus : 1u);
-        if (gen == 1) __builtin_amdgcn_s_setprio(1);
-        if (gen == 2) __builtin_amdgcn_s_setprio(2);
-        if (gen >= 3) __builtin_amdgcn_s_setprio(3);
+#ifndef BU_X_P0
+#define BU_X_P0 0
+#define BU_X_P1 1
+#define BU_X_P2 2
+#define BU_X_P3 3
+#endif
+        if (gen == 0) __builtin_amdgcn_s_setprio(BU_X_P0);
+        if (gen == 1) __builtin_amdgcn_s_setprio(BU_X_P1);
+        if (gen == 2) __builtin_amdgcn_s_setprio(BU_X_P2);
+        if (gen >= 3) __builtin_amdgcn_s_setprio(BU_X_P3);
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ BuTables T;

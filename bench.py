@@ -59,7 +59,7 @@ def pmc_traffic():
         return None
     try:
         d = json.load(open(files[-1]))
-        return int(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+        return int(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT), d.get("SQ_INSTS_VALU")
     except Exception:
         return None
 
@@ -733,6 +733,15 @@ def run_atlas4096(env):
     if tr:
         line["roofline"]["traffic"] = tr[0]
         line["roofline"]["traffic_source"] = tr[1] + " (committed rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this kernel; not measured in this run)"
+        if tr[2]:
+            # the limiter DESIGN.md section 6 measures: vector-ALU instruction issue.  Peak = SIMDs x shader clock / 4.2 clk per
+            # wave64 instruction (the issue cost of the slow instruction forms, tools/exp/opbench.hip; the clock is the 2.35 GHz
+            # measured in-kernel from s_memtime / s_memrealtime)
+            simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+            peak = simds * 2.35e9 / 4.2 / 1e9
+            rate = tr[2] / kern_s / 1e9
+            extra["valu_issue"] = {"wave_instructions_per_launch": int(tr[2]), "achieved_g_per_s": round(rate, 1), "peak_g_per_s": round(peak, 1),
+                                   "frac": round(rate / peak, 3), "source": tr[1] + " (SQ_INSTS_VALU, committed pass; not measured in this run)"}
     line["extra"] = extra
     allgather = None
     if use_dist:
