@@ -316,6 +316,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
     // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
     __shared__ uint32_t cnt[2][32], next_chunk[2];
+#ifdef BU_X_LDSPAD
+    __shared__ uint32_t lds_pad_[BU_X_LDSPAD / 4];  // EXPERIMENT: limits resident workgroups per CU
+    if (n_blocks == 0xFFFFFFFFu) lds_pad_[threadIdx.x] = 1;
+#endif
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
     unsigned tile = blockIdx.x;
