@@ -202,3 +202,40 @@ def test_concurrent_slice_decode_is_race_free(tmp_path):
     r = subprocess.run([os.path.join(he, "bu_hostlogic_tsan"), str(path), "300"], capture_output=True, text=True)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
     assert "fuzz done" in r.stdout
+
+
+def test_allocation_failure_inside_the_abi_is_a_status_not_a_terminate(tmp_path):
+    """C++ exceptions must not cross the C ABI: a file whose slice table needs more memory than the process may have
+    (address-space limit set just above the current footprint) makes std::vector throw std::bad_alloc inside
+    bu_read_query / bu_basis_read_slice_descs -- the entry points return BU_ERR_BOUNDS, the process lives on"""
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 400_000  # slice descriptors: 9.2 MB of file, > 9 MB for the parsed table and as much again for the image list
+    blocks = [np.zeros((1, 16), dtype=np.uint8)] * n
+    f = bb.uastc_file(blocks, [(1, 1)] * n)
+    path = tmp_path / "many_slices.basis"
+    path.write_bytes(f)
+    code = textwrap.dedent("""
+        import ctypes, resource, sys
+        sys.path.insert(0, %r)
+        from basisu_rs_amd import _lib
+        lib = _lib.load()
+        data = open(%r, "rb").read()
+        buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
+        n, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert lib.bu_read_query(_lib.READ_BC7, buf, len(data), ctypes.byref(n), ctypes.byref(nb)) == 0 and n.value == %d
+        vm = [int(l.split()[1]) * 1024 for l in open("/proc/self/status") if l.startswith("VmSize")][0]
+        resource.setrlimit(resource.RLIMIT_AS, (vm + (4 << 20), vm + (4 << 20)))
+        st = lib.bu_read_query(_lib.READ_BC7, buf, len(data), ctypes.byref(n), ctypes.byref(nb))
+        h = _lib.BasisHeader()
+        assert lib.bu_basis_read_header(buf, len(data), ctypes.byref(h)) == 0
+        cnt = ctypes.c_size_t(0)
+        st2 = lib.bu_basis_read_slice_descs(buf, len(data), ctypes.byref(h), None, 0, ctypes.byref(cnt))
+        print("status", st, st2)
+    """) % (root, str(path), n)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert "status %d %d" % (_lib.ERR_BOUNDS, _lib.ERR_BOUNDS) in r.stdout, r.stdout + r.stderr[-2000:]
