@@ -180,9 +180,7 @@ __device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
     return v;
 }
-#ifndef BU_PARB
-#define BU_PARB 1
-#endif
+
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
 constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // The large-input configurations (>= 512 Ki blocks), per target; all A/B'd inside one run (tools/exp/ab.sh) on the
@@ -197,37 +195,20 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 //   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
 // ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp); ETC1/ETC2 (81)
 // do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
-// experiment knobs for the ETC1 / ETC2 large configuration
-#ifndef BU_E_BPT
-#define BU_E_BPT 4
-#define BU_E_PER_CU 2
-#define BU_E_MINW 1
-#define BU_E_SKEW 40
-#define BU_E_ALL false
-#endif
+// ETC1 / ETC2 (72-78 VGPRs): 2048-block tiles, two workgroups per CU.  Tried in round 2 (tools/exp/ab.sh): 1024-block
+// tiles with three workgroups per CU 25.7 us, with four (64 VGPRs, 7 spilled) 27.4, against 24.9 -- the ALUs are saturated
+// at 16 waves per CU, more waves only add sort overhead.
 template <int TARGET>
 struct BuBigCfg {
     static constexpr bool PREFETCH = false, DIRECT = false;
-    static constexpr int WGS = 512, BPT = BU_E_BPT, WG_PER_CU = BU_E_PER_CU, SKEW = BU_E_SKEW, MINW = BU_E_MINW;
-    static constexpr bool ALL_SIZES = BU_E_ALL;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
+    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
+    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
-// experiment knobs (tools/exp/build_variant.sh -DBU_X_...): shape of the BC7 large configuration
-#ifndef BU_X_WGS
-#define BU_X_WGS 512
-#define BU_X_BPT 2
-#define BU_X_PER_CU 4
-#endif
-#ifndef BU_X_PREFETCH
-#define BU_X_PREFETCH false
-#endif
-#ifndef BU_X_DIRECT
-#define BU_X_DIRECT false
-#endif
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
-    static constexpr int WGS = BU_X_WGS, BPT = BU_X_BPT, WG_PER_CU = BU_X_PER_CU, SKEW = 0, MINW = 1;
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
-    static constexpr bool PREFETCH = BU_X_PREFETCH, DIRECT = BU_X_DIRECT;
+    static constexpr bool PREFETCH = false, DIRECT = false;
 };
 template <>
 struct BuBigCfg<BU_TGT_ASTC> {
@@ -286,16 +267,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
     {
         const unsigned gen = blockIdx.x / (cus ? cus : 1u);
-#ifndef BU_X_P0
-#define BU_X_P0 0
-#define BU_X_P1 1
-#define BU_X_P2 2
-#define BU_X_P3 3
-#endif
-        if (gen == 0) __builtin_amdgcn_s_setprio(BU_X_P0);
-        if (gen == 1) __builtin_amdgcn_s_setprio(BU_X_P1);
-        if (gen == 2) __builtin_amdgcn_s_setprio(BU_X_P2);
-        if (gen >= 3) __builtin_amdgcn_s_setprio(BU_X_P3);
+        if (gen == 1) __builtin_amdgcn_s_setprio(1);
+        if (gen == 2) __builtin_amdgcn_s_setprio(2);
+        if (gen >= 3) __builtin_amdgcn_s_setprio(3);
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ BuTables T;
@@ -316,10 +290,6 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
     // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
     __shared__ uint32_t cnt[2][32], next_chunk[2];
-#ifdef BU_X_LDSPAD
-    __shared__ uint32_t lds_pad_[BU_X_LDSPAD / 4];  // EXPERIMENT: limits resident workgroups per CU
-    if (n_blocks == 0xFFFFFFFFu) lds_pad_[threadIdx.x] = 1;
-#endif
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
     unsigned tile = blockIdx.x;

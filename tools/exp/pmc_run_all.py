@@ -9,6 +9,7 @@ ctx = Context(0); lib = _lib.load()
 g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
 dev = torch.device("cuda", 0); N = 1 << 20; NBUF = int(os.environ.get("PMC_NBUF", 24))
 only = sys.argv[1:]  # optional subset: bc7 astc etc1 etc2 rgba etc1s copy
+REPS = int(os.environ.get("PMC_REPS", 1))  # the kernel-trace pass repeats every kernel's rotation (steady-state durations)
 gu = torch.from_numpy(g["uastc"]).to(dev)
 ins = []
 for k in range(NBUF):
@@ -19,17 +20,17 @@ sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 for name, t in (("bc7", _lib.BC7), ("astc", _lib.ASTC), ("etc1", _lib.ETC1), ("etc2", _lib.ETC2)):
     if only and name not in only: continue
-    for k in range(NBUF):
-        ctx.transcode_device(t, ins[k], N, outs[k], blocks_per_row=1024)
+    for k in range(NBUF * REPS):
+        ctx.transcode_device(t, ins[k % NBUF], N, outs[k % NBUF], blocks_per_row=1024)
     torch.cuda.synchronize()
 if not only or "rgba" in only:
     ro = [torch.empty((N, 64), dtype=torch.uint8, device=dev) for _ in range(8)]
-    for k in range(NBUF):
-        ctx.transcode_device(_lib.RGBA32, ins[k], N, ro[k % 8], blocks_per_row=1024)
+    for k in range(NBUF * REPS):
+        ctx.transcode_device(_lib.RGBA32, ins[k % NBUF], N, ro[k % 8], blocks_per_row=1024)
     torch.cuda.synchronize(); del ro
 if not only or "copy" in only:
-    for k in range(NBUF):
-        lib.bu_copy_ceiling_device(ctx.handle, ins[k].data_ptr(), N, outs[k].data_ptr(), sp)
+    for k in range(NBUF * REPS):
+        lib.bu_copy_ceiling_device(ctx.handle, ins[k % NBUF].data_ptr(), N, outs[k % NBUF].data_ptr(), sp)
     torch.cuda.synchronize()
 if not only or "etc1s" in only:
     ep, rows = synth.etc1s_codebooks(4096, 8192, seed=2)
@@ -39,9 +40,9 @@ if not only or "etc1s" in only:
     d_idx = [torch.from_numpy(synth.etc1s_indices(nbl, 4096, 8192, seed=100 + k).view(np.int32)).to(dev) for k in range(NBUF)]
     o8 = [torch.empty((nbl, 8), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
     o64 = [torch.empty((nbl, 64), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-    for k in range(NBUF):
-        lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx[k].data_ptr(), nbl, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o8[k].data_ptr(), None, sp)
-    for k in range(NBUF):
-        lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx[k].data_ptr(), None, 512, 512, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o64[k].data_ptr(), None, sp)
+    for k in range(NBUF * REPS):
+        lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx[k % NBUF].data_ptr(), nbl, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o8[k % NBUF].data_ptr(), None, sp)
+    for k in range(NBUF * REPS):
+        lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx[k % NBUF].data_ptr(), None, 512, 512, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o64[k % NBUF].data_ptr(), None, sp)
     torch.cuda.synchronize()
 print("done")

@@ -6,7 +6,9 @@ set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
 rm -rf gpurun_out/pmc/trace
+export PMC_REPS=16   # 384 launches per kernel in the kernel-trace pass: steady-state durations (the counter passes below use one rotation)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc/trace -- python3 tools/exp/pmc_run_all.py "$@" > gpurun_out/pmc/trace.log 2>&1
+export PMC_REPS=1
 find gpurun_out/pmc/trace -name "*kernel_stats*.csv" | head -1 | while read f; do cp "$f" gpurun_out/pmc/kernel_stats.csv; done
 run() { name=$1; shift; rm -rf gpurun_out/pmc/$name; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$name -- python3 tools/exp/pmc_run_all.py ${TARGETS:-} > gpurun_out/pmc/$name.log 2>&1; }
 run lds SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
