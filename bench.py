@@ -105,7 +105,8 @@ def self_launch(n):
     import torch
 
     have = torch.cuda.device_count()
-    if have < n:
+    dry = os.environ.get("BENCH_SELF_LAUNCH_DRYRUN") == "1"  # tests: print the child command instead of running it
+    if have < n and not dry:
         raise SystemExit("bench: --gpus %d but only %d GPU(s) are visible" % (n, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -115,6 +116,9 @@ def self_launch(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and HIP IPC handles need it on this driver
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if dry:
+        print(json.dumps({"self_launch": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}))
+        raise SystemExit(0)
     r = subprocess.run(cmd, env=env)
     raise SystemExit(r.returncode)
 

@@ -129,3 +129,23 @@ def test_partition_covers_everything_once():
             assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus N` without a launcher must spawn torch.distributed.run as a CHILD (never re-exec) before it
+    touches a GPU, with the rendezvous on 127.0.0.1 and its own arguments passed through; under a launcher (WORLD_SIZE
+    set) it must not spawn anything.  Dry run: the command is printed instead of executed."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, BENCH_SELF_LAUNCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "3", "--config", "array512"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = d["self_launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-8:] == ["--gpus", "8", "--steps", "7", "--warmup", "3", "--config", "array512"] and cmd[-9].endswith("bench.py")
+    assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") not in (None, "0")

@@ -20,17 +20,22 @@ sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 for name, t in (("bc7", _lib.BC7), ("astc", _lib.ASTC), ("etc1", _lib.ETC1), ("etc2", _lib.ETC2)):
     if only and name not in only: continue
-    for k in range(NBUF * REPS):
-        ctx.transcode_device(t, ins[k % NBUF], N, outs[k % NBUF], blocks_per_row=1024)
+    # back-to-back launches from the C timing helper (a Python call per launch leaves the GPU idle between kernels and the
+    # traced durations come out ~15 % long)
+    A = ctypes.c_void_p * NBUF
+    ms = ctypes.c_float(0)
+    assert lib.bu_time_uastc_launches(ctx.handle, t, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), NBUF, 0, N, 1024, NBUF * REPS, None, sp, ctypes.byref(ms)) == 0
     torch.cuda.synchronize()
 if not only or "rgba" in only:
     ro = [torch.empty((N, 64), dtype=torch.uint8, device=dev) for _ in range(8)]
-    for k in range(NBUF * REPS):
-        ctx.transcode_device(_lib.RGBA32, ins[k % NBUF], N, ro[k % 8], blocks_per_row=1024)
+    A8 = ctypes.c_void_p * 8
+    ms = ctypes.c_float(0)
+    assert lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, A8(*[x.data_ptr() for x in ins[:8]]), A8(*[x.data_ptr() for x in ro]), 8, 0, N, 1024, NBUF * REPS, None, sp, ctypes.byref(ms)) == 0
     torch.cuda.synchronize(); del ro
 if not only or "copy" in only:
-    for k in range(NBUF * REPS):
-        lib.bu_copy_ceiling_device(ctx.handle, ins[k % NBUF].data_ptr(), N, outs[k % NBUF].data_ptr(), sp)
+    A = ctypes.c_void_p * NBUF
+    ms = ctypes.c_float(0)
+    assert lib.bu_time_copy_launches(ctx.handle, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), NBUF, 0, N, NBUF * REPS, sp, ctypes.byref(ms)) == 0
     torch.cuda.synchronize()
 if not only or "etc1s" in only:
     ep, rows = synth.etc1s_codebooks(4096, 8192, seed=2)
