@@ -1,0 +1,408 @@
+// C ABI, whole-file level: the crate's public read_to_* API (src/lib.rs:20-22, src/basis.rs) -- container parse, CRC and BasisLZ
+// decode on the host (bu_basis.hpp), block work through the kernels; the UASTC file writer.
+// Part of the single translation unit bu_hip.hip.
+#pragma once
+extern "C" {
+
+// ---- whole-file level (basis.rs) --------------------------------------------------------------------
+bu_status bu_basis_read_header(const uint8_t* file, size_t len, bu_basis_header* out)
+{
+    if (!file || !out) return BU_ERR_ARGUMENT;
+    return bu_host::read_header(file, len, out);
+}
+
+static bu_status bu_basis_read_slice_descs_impl(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out, size_t max_descs,
+                                              size_t* n_descs)
+{
+    if (!file || !header) return BU_ERR_ARGUMENT;
+    std::vector<bu_slice_desc> v;
+    bu_status st = bu_host::read_slice_descs(file, len, header, v);
+    if (st) return st;
+    if (n_descs) *n_descs = v.size();
+    if (out) {
+        if (v.size() > max_descs) return BU_ERR_OUTPUT_SIZE;
+        for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+    }
+    return BU_OK;
+}
+
+uint16_t bu_basis_crc16(const uint8_t* data, size_t len, uint16_t crc) { return bu_host::crc16(data, len, crc); }
+
+using bu_host::BuFilePlan;
+using bu_host::bu_plan_file;
+using bu_host::bu_make_lz;
+
+static bu_status bu_read_query_impl(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes)
+{
+    BuFilePlan p;
+    bu_status st = bu_plan_file(target, file, len, p);
+    if (st) return st;
+    if (n_images) *n_images = p.images.size();
+    if (out_bytes) *out_bytes = p.out_bytes;
+    return BU_OK;
+}
+
+static bu_status bu_basislz_decode_impl(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out, uint8_t* selectors_out,
+                                       uint32_t* idx_out)
+{
+    if (!file) return BU_ERR_ARGUMENT;
+    bu_basis_header h;
+    bu_status st = bu_host::read_header(file, len, &h);
+    if (st) return st;
+    if (h.tex_format != 0) return BU_ERR_UNSUPPORTED;
+    std::vector<bu_slice_desc> slices;
+    st = bu_host::read_slice_descs(file, len, &h, slices);
+    if (st) return st;
+    bu_host::BasisLz lz;
+    st = bu_make_lz(file, len, h, lz);
+    if (st) return st;
+    if (endpoints_out) memcpy(endpoints_out, lz.endpoints.data(), lz.endpoints.size() * 4);
+    if (selectors_out) memcpy(selectors_out, lz.selectors.data(), lz.selectors.size());
+    if (idx_out) {
+        if (slice_index >= slices.size()) return BU_ERR_ARGUMENT;
+        const bu_slice_desc& s = slices[slice_index];
+        if (!bu_host::in_file(len, s.file_ofs, s.file_size)) return BU_ERR_BOUNDS;
+        st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, file + s.file_ofs, s.file_size, idx_out);
+    }
+    return st;
+}
+
+static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
+                                size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
+{
+    if (!ctx || !out) return BU_ERR_ARGUMENT;
+    const bool trace = getenv("BU_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t = now();
+        fprintf(stderr, "[bu_read_to] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    BuFilePlan p;
+    // Large UASTC files: the payload CRC (0.3 ms per 16 MiB on the host cores) runs beside the upload instead of before
+    // it.  The reference checks it before anything else behind the header (basis.rs:338-341), so a CRC failure takes
+    // precedence over every later error, and nothing is reported as success before it is known.
+    std::future<bool> crc_later;
+    bool crc_deferred = false;
+    {
+        bu_basis_header h0;
+        if (file && len >= ((size_t)1 << 20) && bu_host::read_header(file, len, &h0) == BU_OK && h0.tex_format == 1 && target != BU_READ_UASTC) {
+            const uint16_t want = h0.data_crc16;
+            try {
+                crc_later = std::async(std::launch::async, [file, len, want] { return bu_host::crc16(file + 77, len - 77, 0) == want; });
+                crc_deferred = true;
+            } catch (...) {  // no thread to be had: the plan below checks the CRC inline, in the reference's order
+                crc_deferred = false;
+            }
+        }
+    }
+    auto settle = [&](bu_status s) {  // the status to report once the deferred CRC is known
+        if (crc_deferred) {
+            crc_deferred = false;
+            if (!crc_later.get()) return BU_ERR_DATA_CRC;
+        }
+        return s;
+    };
+    bu_status st = bu_plan_file(target, file, len, p, !crc_deferred);
+    lap("plan (parse + CRCs)");
+    if (st) return settle(st);
+    const auto rest = [&]() -> bu_status {
+    if (header_out) *header_out = p.h;
+    if (n_images) *n_images = p.images.size();
+    if (out_bytes < p.out_bytes) return BU_ERR_OUTPUT_SIZE;
+    if (images) {
+        if (p.images.size() > max_images) return BU_ERR_OUTPUT_SIZE;
+        for (size_t i = 0; i < p.images.size(); i++) images[i] = p.images[i];
+    }
+    if (p.images.empty()) return BU_OK;
+    if (!p.etc1s && target == BU_READ_UASTC) {  // uastc.rs:85-87: plain copies, no device work
+        for (size_t k = 0; k < p.images.size(); k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
+            if (s.file_size) memcpy(out + p.images[k].offset, file + s.file_ofs, s.file_size);
+        }
+        return BU_OK;
+    }
+    // Batched front door: every slice's input is staged at an aligned offset of one device buffer, the device output
+    // buffer mirrors `out`, all launches go to the context stream back to back (one status word per image) and a
+    // single synchronisation ends the call.  The host-side BasisLZ decode of all slices happens before any upload.
+    bu_host::BasisLz lz;
+    const size_t n_img = p.images.size();
+    std::vector<size_t> in_off(n_img, 0), ain_off(n_img, 0), run_of(n_img, 0);  // run_of[k]: first image of k's run
+    std::vector<uint32_t> idx_all;
+    size_t total_in = 0;
+    auto align_up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    if (p.etc1s) {
+        st = bu_make_lz(file, len, p.h, lz);
+        if (st) return st;
+        lap("codebooks + tables");
+        size_t words = 0;
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
+            const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y;
+            in_off[k] = words * 4;
+            words += (nblk + 63) & ~(size_t)63;
+            if (p.alpha_pairs) {
+                ain_off[k] = words * 4;
+                words += (nblk + 63) & ~(size_t)63;
+            }
+        }
+        idx_all.assign(words ? words : 1, 0);
+        std::vector<bu_host::SliceJob> jobs;  // file order: colour slice, then its alpha slice
+        jobs.reserve(n_img * (p.alpha_pairs ? 2 : 1));
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
+            jobs.push_back({s.num_blocks_x, s.num_blocks_y, file + s.file_ofs, s.file_size, idx_all.data() + in_off[k] / 4, BU_OK});
+            if (p.alpha_pairs) {
+                const bu_slice_desc& a = p.slices[p.first_slice[k] + 1];
+                jobs.push_back({a.num_blocks_x, a.num_blocks_y, file + a.file_ofs, a.file_size, idx_all.data() + ain_off[k] / 4, BU_OK});
+            }
+        }
+        st = bu_host::decode_slices(lz, jobs);  // host cores in parallel; the symbol stream is serial only within a slice
+        if (st) return st;
+        lap("slice symbol streams");
+        total_in = words * 4;
+    } else {
+        // Runs: consecutive slices that sit back to back in the file (the usual layout of a mip chain or a texture array)
+        // are staged back to back with ONE upload, and -- for the block-linear targets, whose outputs are then contiguous
+        // too -- transcoded with ONE launch over the whole run: 512 slices of 65 536 blocks are one 33 M-block launch
+        // (0.3 ms) instead of 512 latency-bound ones (3.9 ms).  The lowest failing block of a run lies in its first
+        // failing slice, so the reported error is the sequential loop's.
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k]];
+            const bool joins = k > 0 && run_of[k - 1] != SIZE_MAX && s.file_size % 16 == 0 && s.file_size != 0 &&
+                               p.slices[p.first_slice[k - 1]].file_size % 16 == 0 && p.slices[p.first_slice[k - 1]].file_size != 0 &&
+                               (size_t)p.slices[p.first_slice[k - 1]].file_ofs + p.slices[p.first_slice[k - 1]].file_size == s.file_ofs;
+            if (joins) {
+                run_of[k] = run_of[k - 1];
+                in_off[k] = in_off[k - 1] + p.slices[p.first_slice[k - 1]].file_size;
+                total_in = in_off[k] + s.file_size;
+            } else {
+                total_in = align_up(total_in);
+                run_of[k] = k;
+                in_off[k] = total_in;
+                total_in += s.file_size;
+            }
+        }
+        total_in = align_up(total_in);
+    }
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> words(n_img, 0);  // status landing area: declared before anything is queued, outlives the drain
+    std::vector<BuEtc1sSlice> descs;        // (likewise: source of an upload)
+    BuDrain drain(ctx);
+    if ((st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, total_in ? total_in : 16))) return st;
+    // a page-locked `out` (bu_host_alloc) receives the kernels' stores directly over PCIe: no device output buffer, no download
+    void* zout = nullptr;
+    const bool direct_out = bu_device_view(out, &zout);
+    if (!direct_out && (st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, p.out_bytes ? p.out_bytes : 16))) return st;
+    const size_t ep_bytes = p.etc1s ? align_up(lz.endpoints.size() * 4) : 0, sel_bytes = p.etc1s ? align_up(lz.selectors.size()) : 0;
+    // ETC1S: one descriptor per image (+ sentinel) behind the codebooks and the status words
+    uint32_t n_units = 0;
+    if (p.etc1s) {
+        descs.reserve(n_img + 1);
+        for (size_t k = 0; k < n_img; k++) {
+            const bu_slice_desc& sl = p.slices[p.first_slice[k]];
+            const size_t nblk = (size_t)sl.num_blocks_x * sl.num_blocks_y;
+            if (p.images[k].size == 0 || nblk == 0) continue;
+            BuEtc1sSlice d;
+            d.unit0 = n_units;
+            d.n_blocks = (uint32_t)nblk;
+            d.nbx = sl.num_blocks_x;
+            d.idx_ofs = (uint32_t)(in_off[k] / 4);
+            d.aidx_ofs = (p.alpha_pairs && target == BU_READ_RGBA) ? (uint32_t)(ain_off[k] / 4) : 0xFFFFFFFFu;
+            d.image = (uint32_t)k;
+            d.out_ofs = p.images[k].offset;
+            descs.push_back(d);
+            n_units += (uint32_t)((nblk + 63) / 64);
+        }
+        BuEtc1sSlice end = {};
+        end.unit0 = n_units;
+        descs.push_back(end);
+    }
+    const size_t desc_bytes = align_up(descs.size() * sizeof(BuEtc1sSlice)), status_bytes = align_up(8 * n_img);
+    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + status_bytes + desc_bytes + 256))) return st;
+    uint8_t* d_in = static_cast<uint8_t*>(ctx->d_in);
+    uint8_t* d_out = direct_out ? static_cast<uint8_t*>(zout) : static_cast<uint8_t*>(ctx->d_out);
+    uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
+    uint64_t* d_status = reinterpret_cast<uint64_t*>(aux + ep_bytes + sel_bytes);
+    BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, 8 * n_img, ctx->stream));
+    if (p.etc1s) {
+        BU_HIP(ctx, hipMemcpyAsync(d_in, idx_all.data(), total_in, hipMemcpyHostToDevice, ctx->stream));
+        if (!lz.endpoints.empty()) BU_HIP(ctx, hipMemcpyAsync(aux, lz.endpoints.data(), lz.endpoints.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!lz.selectors.empty()) BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, lz.selectors.data(), lz.selectors.size(), hipMemcpyHostToDevice, ctx->stream));
+        BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes + sel_bytes + status_bytes, descs.data(), descs.size() * sizeof(BuEtc1sSlice), hipMemcpyHostToDevice, ctx->stream));
+        // ONE launch for the whole file (basis.rs:42-58 / 103-123 walk the slices one by one)
+        if (n_units) {
+            const uint32_t n_cb0 = (uint32_t)lz.endpoints.size();
+            const unsigned grid = bu_grid_for((size_t)n_units * 64, ctx->cu_count);
+            const BuEtc1sSlice* d_descs = reinterpret_cast<const BuEtc1sSlice*>(aux + ep_bytes + sel_bytes + status_bytes);
+            if (target == BU_READ_RGBA)
+                hipLaunchKernelGGL(bu_etc1s_file_kernel<true>, dim3(grid), dim3(BU_WG), 0, ctx->stream, reinterpret_cast<const uint32_t*>(d_in), d_descs,
+                                   (uint32_t)(descs.size() - 1), n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                                   reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+            else
+                hipLaunchKernelGGL(bu_etc1s_file_kernel<false>, dim3(grid), dim3(BU_WG), 0, ctx->stream, reinterpret_cast<const uint32_t*>(d_in), d_descs,
+                                   (uint32_t)(descs.size() - 1), n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                                   reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+            BU_HIP(ctx, hipGetLastError());
+        }
+    }
+    bool used_extra = false;
+    size_t run_piece_bytes = (size_t)16 << 20;
+    if (const char* e = getenv("BU_RUN_PIECE_MIB")) run_piece_bytes = (size_t)atoll(e) << 20;  // 0 disables the pieced pipeline
+    for (size_t k = 0; k < n_img; k++) {
+        const bu_slice_desc& s = p.slices[p.first_slice[k]];
+        const bu_image& im = p.images[k];
+        if (im.size == 0) continue;
+        if (p.etc1s) {
+            // (launched once for the whole file above)
+        } else {
+            size_t run_end = k;  // last image of the run starting at k (only evaluated for run leaders)
+            bool pieced = false;
+            if (run_of[k] == k) {
+                while (run_end + 1 < n_img && run_of[run_end + 1] == k) run_end++;
+                const size_t run_bytes = in_off[run_end] + p.slices[p.first_slice[run_end]].file_size - in_off[k];
+                // A large block-linear run with a mapped (page-locked) output: upload and transcode in pieces on two
+                // streams, so that piece i's results cross PCIe upstream while piece i+1 comes down.
+                const size_t piece_bytes = run_piece_bytes;
+                if (target != BU_READ_RGBA && direct_out && piece_bytes && run_bytes >= 2 * piece_bytes) {
+                    pieced = true;
+                    if (!ctx->extra_streams[0]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[0], hipStreamNonBlocking));
+                    if (!used_extra) {
+                        BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));  // the status words are reset on the context stream
+                        BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[0], ctx->ev0, 0));
+                        used_extra = true;
+                    }
+                    const bu_target pbt = target == BU_READ_ASTC ? BU_TARGET_ASTC : target == BU_READ_BC7 ? BU_TARGET_BC7
+                                          : target == BU_READ_ETC1 ? BU_TARGET_ETC1 : BU_TARGET_ETC2;
+                    const size_t obytes = bu_target_block_bytes(pbt);
+                    size_t piece_no = 0;
+                    for (size_t done = 0; done < run_bytes; done += piece_bytes, piece_no++) {
+                        const size_t nbytes = run_bytes - done < piece_bytes ? run_bytes - done : piece_bytes;
+                        hipStream_t ps = (piece_no & 1) ? ctx->extra_streams[0] : ctx->stream;
+                        BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k] + done, file + s.file_ofs + done, nbytes, hipMemcpyHostToDevice, ps));
+                        st = bu_launch_uastc(ctx, pbt, d_in + in_off[k] + done, nbytes / 16, d_out + im.offset + (done / 16) * obytes, 1, done / 16, d_status + k, ps,
+                                             BU_ZEROCOPY_GRID);
+                        if (st) return st;
+                    }
+                } else {
+                    BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k], file + s.file_ofs, run_bytes, hipMemcpyHostToDevice, ctx->stream));
+                }
+            }
+            const bu_target bt = target == BU_READ_RGBA ? BU_TARGET_RGBA32
+                                 : target == BU_READ_ASTC ? BU_TARGET_ASTC
+                                 : target == BU_READ_BC7  ? BU_TARGET_BC7
+                                 : target == BU_READ_ETC1 ? BU_TARGET_ETC1
+                                                          : BU_TARGET_ETC2;
+            if (target == BU_READ_RGBA) {  // image geometry differs per slice: one launch each
+                st = bu_launch_uastc(ctx, bt, d_in + in_off[k], s.file_size / 16, d_out + im.offset, s.num_blocks_x ? s.num_blocks_x : 1, 0, d_status + k,
+                                     ctx->stream, direct_out ? BU_ZEROCOPY_GRID : 0);
+            } else if (run_of[k] == k && !pieced) {  // block-linear: the run's outputs are contiguous from im.offset on
+                const size_t run_bytes = in_off[run_end] + p.slices[p.first_slice[run_end]].file_size - in_off[k];
+                st = bu_launch_uastc(ctx, bt, d_in + in_off[k], run_bytes / 16, d_out + im.offset, 1, 0, d_status + k, ctx->stream,
+                                     direct_out ? BU_ZEROCOPY_GRID : 0);
+            }
+        }
+        if (st) return st;
+    }
+    lap("reserve + enqueue");
+    if (used_extra) {  // the status words are read on the context stream: it must see the second stream's kernels
+        BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[0]));
+        BU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
+    }
+    BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
+    if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (used_extra) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[0]));
+    BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;
+    lap("download + synchronise");
+    for (size_t k = 0; k < n_img; k++) {  // first Err (in slice order) aborts the whole call, like the `?` in the reference drivers
+        st = bu_status_word_decode(words[k], nullptr);
+        if (st) return st;
+    }
+    return BU_OK;
+    };
+    return settle(rest());
+}
+
+
+// C++ exceptions must not cross the C ABI (a ctypes or Rust caller would be terminated): vectors sized from untrusted
+// file fields can throw std::bad_alloc, thread creation std::system_error.  A file that asks for more memory than
+// exists is reported like any other out-of-bounds field.
+#define BU_GUARDED(call)                 \
+    try {                                \
+        return call;                     \
+    } catch (const std::bad_alloc&) {    \
+        return BU_ERR_BOUNDS;            \
+    } catch (...) {                      \
+        return BU_ERR_HIP;               \
+    }
+bu_status bu_basis_read_slice_descs(const uint8_t* file, size_t len, const bu_basis_header* header, bu_slice_desc* out, size_t max_descs,
+                                    size_t* n_descs)
+{
+    BU_GUARDED(bu_basis_read_slice_descs_impl(file, len, header, out, max_descs, n_descs))
+}
+bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, size_t* n_images, size_t* out_bytes)
+{
+    BU_GUARDED(bu_read_query_impl(target, file, len, n_images, out_bytes))
+}
+bu_status bu_basislz_decode(const uint8_t* file, size_t len, uint32_t slice_index, uint32_t* endpoints_out, uint8_t* selectors_out,
+                            uint32_t* idx_out)
+{
+    BU_GUARDED(bu_basislz_decode_impl(file, len, slice_index, endpoints_out, selectors_out, idx_out))
+}
+bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
+                     size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
+{
+    BU_GUARDED(bu_read_to_impl(ctx, target, file, len, header_out, images, max_images, n_images, out, out_bytes))
+}
+#undef BU_GUARDED
+
+bu_status bu_basis_write_uastc(const bu_slice_desc* descs, const uint8_t* const* slice_data, const size_t* slice_bytes, size_t n_slices,
+                               uint16_t header_flags, uint8_t tex_type, uint8_t* out, size_t out_cap, size_t* out_len)
+{
+    if ((n_slices && (!descs || !slice_data || !slice_bytes)) || n_slices >= (1u << 24)) return BU_ERR_ARGUMENT;
+    size_t total = 77 + 23 * n_slices;
+    for (size_t i = 0; i < n_slices; i++) total += slice_bytes[i];
+    if (out_len) *out_len = total;
+    if (!out) return BU_OK;
+    if (out_cap < total || total > 0xFFFFFFFFull) return BU_ERR_OUTPUT_SIZE;
+    auto put = [&](size_t pos, uint32_t v, int n) { for (int k = 0; k < n; k++) out[pos + k] = (uint8_t)(v >> (8 * k)); };
+    memset(out, 0, 77 + 23 * n_slices);
+    size_t ofs = 77 + 23 * n_slices;
+    uint32_t n_images = 0;
+    for (size_t i = 0; i < n_slices; i++) {
+        const size_t d = 77 + 23 * i;
+        put(d, descs[i].image_index, 3);
+        out[d + 3] = descs[i].level_index;
+        out[d + 4] = descs[i].flags;
+        put(d + 5, descs[i].orig_width, 2);
+        put(d + 7, descs[i].orig_height, 2);
+        put(d + 9, descs[i].num_blocks_x, 2);
+        put(d + 11, descs[i].num_blocks_y, 2);
+        put(d + 13, (uint32_t)ofs, 4);
+        put(d + 17, (uint32_t)slice_bytes[i], 4);
+        put(d + 21, bu_host::crc16(slice_data[i], slice_bytes[i], 0), 2);
+        if (slice_bytes[i]) memcpy(out + ofs, slice_data[i], slice_bytes[i]);
+        ofs += slice_bytes[i];
+        if (descs[i].image_index + 1 > n_images) n_images = descs[i].image_index + 1;
+    }
+    put(0, 0x4273, 2);   // sig
+    put(2, 0x13, 2);     // ver
+    put(4, 77, 2);       // header_size
+    put(8, (uint32_t)(total - 77), 4);
+    put(12, bu_host::crc16(out + 77, total - 77, 0), 2);
+    put(14, (uint32_t)n_slices, 3);
+    put(17, n_images, 3);
+    out[20] = 1;         // UASTC4x4
+    put(21, header_flags, 2);
+    out[23] = tex_type;
+    put(65, 77, 4);      // slice_desc_file_ofs
+    put(6, bu_host::crc16(out + 8, 77 - 8, 0), 2);
+    return BU_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// C ABI, measurement helpers of bench.py: copy ceiling and back-to-back timed launches (hipEvents on the launch stream).
+// Part of the single translation unit bu_hip.hip.
+#pragma once
+extern "C" {
+
+// ---- measurement helpers ---------------------------------------------------------------------------
+bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blocks, void* d_out, void* stream)
+{
+    if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
+    if (n_blocks == 0) return BU_OK;
+    hipLaunchKernelGGL(bu_copy_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), n_blocks);
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                 size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream,
+                                 float* out_ms)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
+        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, stream);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    // poll instead of a blocking wait: the caller's wall clock around this call (bench.py's `value`) should not carry the
+    // tens of microseconds a sleeping host thread needs to be woken up -- they are as long as several steps
+    for (;;) {
+        const hipError_t q = hipEventQuery(ctx->ev1);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
+    }
+    (void)hipGetLastError();
+    BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
+
+bu_status bu_time_uastc_launches_each(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                      size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream,
+                                      float* out_us)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_us) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<hipEvent_t> ev((size_t)launches + 1, nullptr);
+    bu_status ret = BU_OK;
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) ret = BU_ERR_HIP;
+    if (ret == BU_OK) {
+        (void)hipEventRecord(ev[0], s);
+        for (int i = 0; i < launches && ret == BU_OK; i++) {
+            const size_t k = (first_buffer + (size_t)i) % n_buffers;
+            ret = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, stream);
+            if (hipEventRecord(ev[(size_t)i + 1], s) != hipSuccess) ret = BU_ERR_HIP;
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) ret = BU_ERR_HIP;
+        for (int i = 0; i < launches && ret == BU_OK; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[(size_t)i], ev[(size_t)i + 1]) != hipSuccess) ret = BU_ERR_HIP;
+            out_us[i] = ms * 1000.0f;
+        }
+    }
+    for (auto e : ev)
+        if (e) (void)hipEventDestroy(e);
+    return ret;
+}
+
+bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                         size_t n_blocks, size_t blocks_per_row, int launches, int n_streams, float* out_ms)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_streams; i++)
+        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
+    BU_HIP(ctx, hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (size_t)i % n_buffers;
+        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, nullptr, ctx->extra_streams[i % n_streams]);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipDeviceSynchronize());
+    *out_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return BU_OK;
+}
+
+bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers, size_t first_buffer,
+                                size_t n_blocks, int launches, void* stream, float* out_ms)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < launches; i++) {
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
+        bu_status st = bu_copy_ceiling_device(ctx, d_in[k], n_blocks, d_out[k], stream);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    BU_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
+
+}  // extern "C"

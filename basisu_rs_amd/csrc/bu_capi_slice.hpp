@@ -1,0 +1,275 @@
+// C ABI, slice level: context, status strings, UASTC slice / per-block entry points (host and device pointers), page-locked
+// buffers, the ETC1S back-end entry points.  Part of the single translation unit bu_hip.hip.
+#pragma once
+extern "C" {
+
+size_t bu_target_block_bytes(bu_target target)
+{
+    switch (target) {
+    case BU_TARGET_ASTC:
+    case BU_TARGET_BC7:
+    case BU_TARGET_ETC2: return 16;
+    case BU_TARGET_ETC1: return 8;
+    case BU_TARGET_RGBA32: return 64;
+    default: return 0;
+    }
+}
+
+const char* bu_status_string(bu_status st)
+{
+    switch (st) {
+    case BU_OK: return "ok";
+    case BU_ERR_INVALID_MODE: return "invalid mode index";                                        // uastc.rs:336
+    case BU_ERR_INVALID_PATTERN: return "block pattern is not valid";                             // uastc.rs:364
+    case BU_ERR_LENGTH: return "data length is not divisible by UASTC block size (16)";           // uastc.rs:56
+    case BU_ERR_OUTPUT_SIZE: return "output buffer too small";
+    case BU_ERR_ARGUMENT: return "invalid argument";
+    case BU_ERR_INDEX_RANGE: return "ETC1S endpoint or selector index out of range";
+    case BU_ERR_NO_DEVICE: return "no usable gfx950 HIP device";
+    case BU_ERR_HIP: return "HIP runtime error";
+    case BU_ERR_SIG: return "Sig mismatch, not a Basis Universal file";                                  // basis.rs:309
+    case BU_ERR_HEADER_TRUNCATED: return "Expected at least 77 byte header";                              // basis.rs:313
+    case BU_ERR_HEADER_SIZE: return "File specified unexpected header size, expected 77";                 // basis.rs:323
+    case BU_ERR_HEADER_CRC: return "Header CRC16 failed";                                                 // basis.rs:332
+    case BU_ERR_DATA_CRC: return "Data CRC16 failed";                                                     // basis.rs:12
+    case BU_ERR_TEX_FORMAT: return "Unknown texture format";                                              // basis.rs:404
+    case BU_ERR_SLICE_DESC: return "Expected 23 byte slice desc";                                         // basis.rs:350
+    case BU_ERR_ALPHA_SLICES: return "alpha slice layout is invalid (odd slice count, missing alpha flag or size mismatch)";  // basis.rs:19,29,34
+    case BU_ERR_UNSUPPORTED: return "not implemented for this texture format";                            // unimplemented!()
+    case BU_ERR_BASISLZ: return "BasisLZ stream is invalid";
+    case BU_ERR_BOUNDS: return "offset outside the file or invalid stream state";
+    default: return "unknown status";
+    }
+}
+
+const char* bu_last_error(const bu_context* ctx) { return ctx ? ctx->err : "no context"; }
+
+bu_status bu_context_create(int device, bu_context** out_ctx)
+{
+    if (!out_ctx) return BU_ERR_ARGUMENT;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BU_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BU_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BU_ERR_NO_DEVICE;  // the code object is gfx950-only
+    bu_context* ctx = new (std::nothrow) bu_context();
+    if (!ctx) return BU_ERR_HIP;
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    bu_status st = BU_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { st = BU_ERR_NO_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTables)) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { st = BU_ERR_HIP; break; }
+        BuTables* h = new (std::nothrow) BuTables();
+        if (!h) { st = BU_ERR_HIP; break; }
+        bu_build_tables(h);
+        hipError_t e = hipMemcpy(ctx->d_tables, h, sizeof(BuTables), hipMemcpyHostToDevice);
+        delete h;
+        if (e != hipSuccess) { st = BU_ERR_HIP; break; }
+    } while (0);
+    if (st != BU_OK) {
+        bu_context_destroy(ctx);
+        return st;
+    }
+    *out_ctx = ctx;
+    return BU_OK;
+}
+
+void bu_context_destroy(bu_context* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t es : ctx->extra_streams)
+        if (es) (void)hipStreamDestroy(es);
+    delete ctx;
+}
+
+bu_status bu_status_word_reset(bu_context* ctx, uint64_t* d_status, void* stream)
+{
+    if (!ctx || !d_status) return BU_ERR_ARGUMENT;
+    hipLaunchKernelGGL(bu_status_reset_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long*>(d_status), 1u);
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+bu_status bu_status_word_decode(uint64_t word, uint64_t* first_bad_block)
+{
+    if (word == BU_STATUS_WORD_CLEAR) return BU_OK;
+    // a report is (block << 8 | status) with status 1 or 2 (6 for ETC1S): anything else was never reset or was overwritten
+    const unsigned st = (unsigned)(word & 0xFFu);
+    if (st != BU_ERR_INVALID_MODE && st != BU_ERR_INVALID_PATTERN && st != BU_ERR_INDEX_RANGE) return BU_ERR_ARGUMENT;
+    if (first_bad_block) *first_bad_block = word >> 8;
+    return static_cast<bu_status>(st);
+}
+
+bu_status bu_host_alloc(bu_context* ctx, size_t bytes, void** out_ptr)
+{
+    if (!ctx || !out_ptr) return BU_ERR_ARGUMENT;
+    *out_ptr = nullptr;
+    if (bytes == 0) return BU_OK;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    BU_HIP(ctx, hipHostMalloc(out_ptr, bytes, hipHostMallocDefault));
+    return BU_OK;
+}
+
+bu_status bu_host_free(bu_context* ctx, void* ptr)
+{
+    if (!ctx) return BU_ERR_ARGUMENT;
+    if (!ptr) return BU_OK;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    BU_HIP(ctx, hipHostFree(ptr));
+    return BU_OK;
+}
+
+bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
+                                    size_t blocks_per_row, uint64_t block_index_base, uint64_t* d_status, void* stream)
+{
+    if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
+    if (bu_target_block_bytes(target) == 0) return BU_ERR_ARGUMENT;
+    if (target == BU_TARGET_RGBA32 && blocks_per_row == 0) return BU_ERR_ARGUMENT;
+    // the kernels store pixel rows 4*by+1..3 at the full image pitch: a ragged last block row would land past 64*n_blocks bytes
+    if (target == BU_TARGET_RGBA32 && n_blocks % blocks_per_row != 0) return BU_ERR_ARGUMENT;
+    return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream));
+}
+
+bu_status bu_uastc_transcode(bu_context* ctx, bu_target target, const uint8_t* in, size_t in_bytes, uint8_t* out,
+                             size_t out_bytes, uint64_t* first_bad_block)
+{
+    if (target == BU_TARGET_RGBA32) return BU_ERR_ARGUMENT;  // uastc.rs:41-47 has no RGBA member; use bu_uastc_decode_to_rgba
+    return bu_uastc_host(ctx, target, in, in_bytes, 1, out, out_bytes, first_bad_block);
+}
+
+bu_status bu_uastc_decode_to_rgba(bu_context* ctx, const uint8_t* in, size_t in_bytes, size_t blocks_per_row, uint8_t* out,
+                                  size_t out_bytes, uint64_t* first_bad_block)
+{
+    if (blocks_per_row == 0) return BU_ERR_ARGUMENT;
+    // the reference's image has exactly 64*n bytes (uastc.rs:95); a ragged last row would index past it
+    // (Rust panics there), so require whole block rows
+    if (in_bytes % 16 == 0 && (in_bytes / 16) % blocks_per_row != 0) return BU_ERR_ARGUMENT;
+    return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, in_bytes, blocks_per_row, out, out_bytes, first_bad_block);
+}
+
+bu_status bu_unpack_uastc_block_to_rgba(bu_context* ctx, const uint8_t in[16], uint32_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, 16, 1, reinterpret_cast<uint8_t*>(out), 64, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_astc(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_ASTC, in, 16, 1, out, 16, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_bc7(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_BC7, in, 16, 1, out, 16, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_etc1(bu_context* ctx, const uint8_t in[16], uint8_t out[8])
+{
+    return bu_uastc_host(ctx, BU_TARGET_ETC1, in, 16, 1, out, 8, nullptr);
+}
+bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
+{
+    return bu_uastc_host(ctx, BU_TARGET_ETC2, in, 16, 1, out, 16, nullptr);
+}
+
+// ---- ETC1S ---------------------------------------------------------------------------------------
+void bu_etc1s_selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8]) { bu_host::selector_from_rows(rows, out_entry); }
+
+bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx, size_t n_blocks, const uint32_t* d_endpoints,
+                                         uint32_t n_endpoints, const void* d_selectors, uint32_t n_selectors, void* d_out,
+                                         uint64_t* d_status, void* stream)
+{
+    if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
+    if (n_blocks == 0) return BU_OK;
+    hipLaunchKernelGGL(bu_etc1s_etc1_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream), d_idx,
+                       n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors, static_cast<uint2*>(d_out),
+                       reinterpret_cast<unsigned long long*>(d_status));
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+bu_status bu_etc1s_decode_rgba_device(bu_context* ctx, const uint32_t* d_idx, const uint32_t* d_alpha_idx, size_t nbx, size_t nby,
+                                      const uint32_t* d_endpoints, uint32_t n_endpoints, const void* d_selectors,
+                                      uint32_t n_selectors, void* d_out, uint64_t* d_status, void* stream)
+{
+    const size_t n_blocks = nbx * nby;
+    if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
+    if (n_blocks == 0) return BU_OK;
+    hipLaunchKernelGGL(bu_etc1s_rgba_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream), d_idx,
+                       d_alpha_idx, (unsigned)nbx, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
+                       static_cast<uint4*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
+
+static bu_status bu_etc1s_host(bu_context* ctx, bool rgba, const uint32_t* idx, const uint32_t* alpha_idx, size_t nbx, size_t nby,
+                               const uint32_t* endpoints, uint32_t n_ep, const uint8_t* selectors, uint32_t n_sel, uint8_t* out,
+                               size_t out_bytes, uint64_t* first_bad)
+{
+    const size_t n = nbx * nby;
+    if (!ctx || !out || (n && (!idx || !endpoints || !selectors))) return BU_ERR_ARGUMENT;
+    const size_t bb = rgba ? 64 : 8;
+    if (out_bytes < n * bb) return BU_ERR_OUTPUT_SIZE;
+    if (n == 0) return BU_OK;
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    bu_status st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, n * 4);
+    if (st) return st;
+    st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, n * bb);
+    if (st) return st;
+    const size_t ep_bytes = ((size_t)n_ep * 4 + 15) & ~(size_t)15, sel_bytes = ((size_t)n_sel * 8 + 15) & ~(size_t)15;
+    const size_t a_bytes = alpha_idx ? n * 4 : 0;
+    st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + a_bytes);
+    if (st) return st;
+    uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
+    uint64_t word = 0;
+    BuDrain drain(ctx);
+    BU_HIP(ctx, hipMemcpyAsync(ctx->d_in, idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(aux, endpoints, (size_t)n_ep * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, selectors, (size_t)n_sel * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (alpha_idx) BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes + sel_bytes, alpha_idx, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
+    uint64_t* ds = reinterpret_cast<uint64_t*>(ctx->d_status);
+    const uint32_t* d_ep = reinterpret_cast<const uint32_t*>(aux);
+    const void* d_sel = aux + ep_bytes;
+    if (rgba)
+        st = bu_etc1s_decode_rgba_device(ctx, static_cast<const uint32_t*>(ctx->d_in),
+                                         alpha_idx ? reinterpret_cast<const uint32_t*>(aux + ep_bytes + sel_bytes) : nullptr, nbx, nby, d_ep,
+                                         n_ep, d_sel, n_sel, ctx->d_out, ds, ctx->stream);
+    else
+        st = bu_etc1s_transcode_etc1_device(ctx, static_cast<const uint32_t*>(ctx->d_in), n, d_ep, n_ep, d_sel, n_sel, ctx->d_out, ds, ctx->stream);
+    if (st) return st;
+    BU_HIP(ctx, hipMemcpyAsync(&word, ctx->d_status, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(out, ctx->d_out, n * bb, hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;
+    return bu_status_word_decode(word, first_bad);
+}
+
+bu_status bu_etc1s_transcode_etc1(bu_context* ctx, const uint32_t* idx, size_t n_blocks, const uint32_t* endpoints, uint32_t n_endpoints,
+                                  const uint8_t* selectors, uint32_t n_selectors, uint8_t* out, size_t out_bytes, uint64_t* first_bad_block)
+{
+    return bu_etc1s_host(ctx, false, idx, nullptr, n_blocks, 1, endpoints, n_endpoints, selectors, n_selectors, out, out_bytes, first_bad_block);
+}
+
+bu_status bu_etc1s_decode_rgba(bu_context* ctx, const uint32_t* idx, const uint32_t* alpha_idx, size_t nbx, size_t nby,
+                               const uint32_t* endpoints, uint32_t n_endpoints, const uint8_t* selectors, uint32_t n_selectors, uint8_t* out,
+                               size_t out_bytes, uint64_t* first_bad_block)
+{
+    if (nbx == 0 && nby != 0) return BU_ERR_ARGUMENT;
+    return bu_etc1s_host(ctx, true, idx, alpha_idx, nbx, nby, endpoints, n_endpoints, selectors, n_selectors, out, out_bytes, first_bad_block);
+}
+
+
+}  // extern "C"

@@ -1,0 +1,675 @@
+// gfx950 kernels of the block-transcode path: the one-lane-per-block kernel, the mode-sorted kernel (every UASTC target), the
+// ETC1S codebook-lookup kernels, the status-word reset and the copy kernel of the measurement harness.
+// Part of the single translation unit bu_hip.hip (included there; not a stand-alone header).
+#pragma once
+namespace {
+
+constexpr int BU_WG = 256;            // 4 waves
+constexpr int BU_TABLE_VEC = (int)(sizeof(BuTables) / 16);
+// Below this the plain one-lane-per-block kernel is used.  It runs one mode path per DISTINCT mode present, so it only
+// wins for a handful of blocks (BC7: 1 block 2.3 vs 3.3 us, 8 blocks 4.2 vs 3.7 us, 64 blocks 7.8 vs 4.4 us,
+// 1024 blocks 16.1 vs 4.8 us; ETC1 at 128 blocks 38.6 vs 15.0 us).
+constexpr int BU_SORT_MIN_BLOCKS = 8;
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bu_stage_tables(BuTables& dst, const BuTables* __restrict__ src)
+{
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(&dst);
+    for (int i = threadIdx.x; i < BU_TABLE_VEC; i += BU_WG) d[i] = s[i];
+}
+
+__device__ __forceinline__ void bu_report(unsigned long long* status, unsigned long long block, int st)
+{
+    if (status) atomicMin(status, (block << 8) | (unsigned long long)st);
+}
+
+// Every block is read once and every result written once: non-temporal (streaming) accesses keep the 32 MiB of a 4096^2
+// atlas from being allocated in L2 / Infinity Cache with normal retention.  Measured on the BC7 headline: 14.4 -> 13.7 us.
+typedef unsigned int bu_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int bu_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 bu_ld_stream(const uint4* p)
+{
+    const bu_v4u r = __builtin_nontemporal_load(reinterpret_cast<const bu_v4u*>(p));
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+// Output stores.  BU_ST_MODE selects the cache policy (experiment knob).  A/B inside one run (tools/exp/ab.sh), 2^20 blocks:
+//   0 nontemporal (nt)            copy 7.15  BC7 10.93  ETC1 25.1  RGBA32 21.2 us
+//   1 plain                            7.07      12.70       25.9         23.1     (results linger dirty in L2)
+//   2 write-through (sc1)              7.16      10.88       24.9         20.6
+//   3 sc0 sc1                          7.13      10.86       24.8         20.7
+//   4 sc1 nt  <- shipped               6.99      10.70       24.75        20.6
+#ifndef BU_ST_MODE
+#define BU_ST_MODE 4
+#endif
+#if BU_ST_MODE == 2
+#define BU_ST_BITS " sc1"
+#elif BU_ST_MODE == 3
+#define BU_ST_BITS " sc0 sc1"
+#elif BU_ST_MODE == 4
+#define BU_ST_BITS " sc1 nt"
+#endif
+__device__ __forceinline__ void bu_st_stream(uint4* p, const uint4 v)
+{
+    bu_v4u r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+#if BU_ST_MODE == 0
+    __builtin_nontemporal_store(r, reinterpret_cast<bu_v4u*>(p));
+#elif BU_ST_MODE == 1
+    *reinterpret_cast<bu_v4u*>(p) = r;
+#else
+    // hipcc does not model an asm store: the s_nop 1 keeps its next instruction from overwriting the data registers before
+    // the store has read them (two wait states behind a store of more than 8 bytes on gfx940+)
+    asm volatile("global_store_dwordx4 %0, %1, off" BU_ST_BITS "\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+#endif
+}
+__device__ __forceinline__ void bu_st_stream(uint2* p, const uint2 v)
+{
+    bu_v2u r;
+    r.x = v.x; r.y = v.y;
+    // 8-byte stores stay nontemporal: an sc1 store narrower than 16 bytes is one fabric write per lane
+    // (ETC1S -> ETC1 at 2^18 blocks: 4.7 -> 6.2 us with sc1 nt)
+#if BU_ST_MODE == 1
+    *reinterpret_cast<bu_v2u*>(p) = r;
+#else
+    __builtin_nontemporal_store(r, reinterpret_cast<bu_v2u*>(p));
+#endif
+}
+
+// UASTC -> {ASTC, BC7, ETC1, ETC2, RGBA32}: replaces the loop of uastc.rs:157-165 / 96-107
+template <int TARGET>
+__global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
+                                                         unsigned bpr, unsigned long long base, unsigned long long* status,
+                                                         const BuTables* __restrict__ tables)
+{
+    __shared__ BuTables T;
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x;
+    // first block load is issued before the table copy so both are in flight together
+    uint4 v = idx < n_blocks ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+    bu_stage_tables(T, tables);
+    __syncthreads();
+    while (idx < n_blocks) {
+        const size_t next = idx + stride;
+        const uint4 vn = next < n_blocks ? in[next] : make_uint4(0, 0, 0, 0);
+        BuBlk b;
+        b.w[0] = v.x;
+        b.w[1] = v.y;
+        b.w[2] = v.z;
+        b.w[3] = v.w;
+        const uint32_t mode = T.mode_lut[v.x & 127u];
+        uint32_t o[TARGET == BU_TGT_RGBA ? 16 : 4];
+#pragma unroll
+        for (int i = 0; i < (TARGET == BU_TGT_RGBA ? 16 : 4); i++) o[i] = 0;
+        const int st = bu_block_any<TARGET>(T, mode, b, o);
+        if (st) {
+            bu_report(status, base + idx, st);
+#pragma unroll
+            for (int i = 0; i < (TARGET == BU_TGT_RGBA ? 16 : 4); i++) o[i] = 0;
+        }
+        if constexpr (TARGET == BU_TGT_ETC1) {
+            reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
+        } else if constexpr (TARGET == BU_TGT_RGBA) {
+            const size_t by = idx / bpr, bx = idx - by * bpr;
+            uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+            for (int r = 0; r < 4; r++) img[(4 * by + r) * (size_t)bpr + bx] = make_uint4(o[4 * r], o[4 * r + 1], o[4 * r + 2], o[4 * r + 3]);
+        } else {
+            reinterpret_cast<uint4*>(out)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        v = vn;
+        idx = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mode-sorted kernel (every target; RGBA32 returns its 64 B per block through an LDS row tile).
+//
+// The per-mode code paths are straight-line and short (100-260 VALU each for BC7) but there are 19 of
+// them: a wave whose 64 lanes hold a random mix of modes executes all 19 serially (measured: 69 us
+// per 4096x4096 atlas vs a 7 us copy).  So each workgroup first sorts its tile of BU_TILE blocks by
+// mode through LDS (counting sort: one LDS atomic per block), cuts every mode's run into chunks of
+// <= 64 blocks, and each wave then transcodes whole chunks with a wave-uniform mode (scalar branch,
+// no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
+// so global loads and stores stay fully coalesced (1 KiB per wave instruction).
+//   LDS per workgroup: tile 16 B x BU_TILE + tables 5.9 KiB + 1 B x BU_TILE status + counters and the chunk list.
+// Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr),
+// BU_RUN_PIECE_MIB (piece size of the two-stream upload pipeline, 0 = off).
+// modes by descending code-path length (BC7 VALU counts), 5 bits each: entries 0-11 / 12-19
+constexpr unsigned long long bu_cost_pack(int from, int n)
+{
+    unsigned long long v = 0;
+    for (int i = 0; i < n; i++) v |= (unsigned long long)BU_COST_ORDER[from + i] << (5 * i);
+    return v;
+}
+constexpr unsigned long long BU_COST_ORDER_LO = bu_cost_pack(0, 12), BU_COST_ORDER_HI = bu_cost_pack(12, 8);
+static_assert(BU_COST_ORDER_LO == 0x2c8cb0b0e281123ull && BU_COST_ORDER_HI == 0x9bdb1401caull, "cost order moved");
+// mode of sort key k (scalar)
+__device__ __forceinline__ uint32_t bu_mode_of_key(uint32_t k)
+{
+    return (uint32_t)((k < 12 ? (BU_COST_ORDER_LO >> (5 * k)) : (BU_COST_ORDER_HI >> (5 * (k - 12)))) & 31u);
+}
+// inclusive add-scan over lanes 0..31 (and 32..63) with DPP row shifts: 5 VALU, no LDS round trips
+__device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    return v;
+}
+
+// WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
+constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
+// The large-input configurations (>= 512 Ki blocks), per target; all A/B'd inside one run (tools/exp/ab.sh) on the
+// BC7 headline, a 4096^2 atlas = 4096 blocks per CU:
+//   1024 x 4 (4096-block tile), one workgroup per CU                          13.65 us
+//   512 x 4 (2048), two per CU (16 waves)                                     12.80    -- half-size workgroups overlap each
+//   + second half of the grid started ~1 us late (s_sleep 40)                 12.65       other's barrier-bound sort phases
+//   256x4 13.8, 512x8 16.2, 1024x2 15.9, 256x8 15.7 at the same register count
+// The kernels are built with machine-LICM off (basisu_rs_amd/build.py): hoisting every mode path's constants out of the
+// chunk loop cost ~30 VGPRs.  BC7 then needs 62 instead of 93, which allows 32 waves per CU:
+//   1024 x 2 (2048), two per CU (32 waves)                                    11.6
+//   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
+// ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp); ETC1/ETC2 (81)
+// do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
+// ETC1 / ETC2 (72-78 VGPRs): 2048-block tiles, two workgroups per CU.  Tried in round 2 (tools/exp/ab.sh): 1024-block
+// tiles with three workgroups per CU 25.7 us, with four (64 VGPRs, 7 spilled) 27.4, against 24.9 -- the ALUs are saturated
+// at 16 waves per CU, more waves only add sort overhead.
+template <int TARGET>
+struct BuBigCfg {
+    static constexpr bool PREFETCH = false, DIRECT = false;
+    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
+    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
+};
+template <>
+struct BuBigCfg<BU_TGT_BC7> {
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
+    static constexpr bool PREFETCH = false, DIRECT = false;
+};
+template <>
+struct BuBigCfg<BU_TGT_ASTC> {
+    static constexpr bool PREFETCH = false, DIRECT = false;
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr bool ALL_SIZES = true;
+};
+// RGBA32 configuration (tile = 1024 blocks either way)
+#ifndef BU_RGBA_WGS
+#define BU_RGBA_WGS 512
+#define BU_RGBA_BPT 2
+#define BU_RGBA_WG_PER_CU 2
+#endif
+#ifndef BU_RGBA_PREFETCH
+#define BU_RGBA_PREFETCH true
+#endif
+#ifndef BU_RGBA_SKEW
+#define BU_RGBA_SKEW 20
+#endif
+
+
+// stage the parts of the table blob TARGET reads (bu_table_range), 16 bytes per thread per step
+template <int WGS, int TARGET>
+__device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
+{
+    constexpr BuTableRange R = bu_table_range(TARGET);
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(&dst);
+    for (int i = R.lo / 16 + threadIdx.x; i < (int)(R.hi / 16); i += WGS) d[i] = s[i];
+    if constexpr (R.lo2 < R.hi2) {
+        for (int i = R.lo2 / 16 + threadIdx.x; i < (int)(R.hi2 / 16); i += WGS) d[i] = s[i];
+    }
+}
+
+#ifndef BU_STAMP
+#define BU_STAMP(k)
+#define BU_STAMP_ARG
+#define BU_STAMP_PASS
+#endif
+// DIRECT: results are stored to global memory straight from the chunk loop at the block's original
+// index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
+// RGBA32 (64 B per block do not fit a second LDS tile; `bpr` = blocks per image row).
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0>
+__global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
+                                                                unsigned bpr, unsigned long long base, unsigned long long* status,
+                                                                const BuTables* __restrict__ tables, unsigned cus BU_STAMP_ARG)
+{
+    BU_STAMP(0)
+    if constexpr (SKEW > 0) {
+        if (blockIdx.x >= gridDim.x / 2 && gridDim.x > 1) __builtin_amdgcn_s_sleep(SKEW);
+    }
+    // Static priority by residency generation.  Workgroups are dealt breadth-first (b, b + CUs, b + 2 CUs, ... share a CU:
+    // tools/exp/census.hip), and the instruction arbiter serves the OLDEST wave first, so the four tiles of a CU finish
+    // 1.5 us apart and the last one runs its latency-bound chain with the vector units nearly idle (phase stamps,
+    // profiles/r02_*stamps*).  Raising the later generations' priority makes them catch up while the older ones fill
+    // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
+    {
+        const unsigned gen = blockIdx.x / (cus ? cus : 1u);
+        if (gen == 1) __builtin_amdgcn_s_setprio(1);
+        if (gen == 2) __builtin_amdgcn_s_setprio(2);
+        if (gen >= 3) __builtin_amdgcn_s_setprio(3);
+    }
+    constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
+    __shared__ BuTables T;
+    // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
+    // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts).  The sorted input tile
+    // lives IN row 0 of that output tile: a lane reads its block from slot s and later overwrites exactly slot s with
+    // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
+    // which is what lets two workgroups share a CU.
+    constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
+    // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
+    static_assert(!BU_ALIAS || sizeof(BuTables) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
+                  "the RGBA32 workgroup no longer fits twice per CU: shrink BuTables or stage it per target in LDS too");
+    __shared__ uint4 sblk_store[BU_ALIAS ? 1 : BU_TILE];
+    __shared__ uint4 sout[BU_ALIAS ? 4 * BU_TILE : 1];
+    uint4* const sblk = BU_ALIAS ? sout : sblk_store;
+    __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
+    __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
+    // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
+    // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
+    __shared__ uint32_t cnt[2][32], next_chunk[2];
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
+    unsigned tile = blockIdx.x;
+    uint4 v[BU_BPT];
+#pragma unroll
+    for (int j = 0; j < BU_BPT; j++) {
+        const unsigned idx = tile * BU_TILE + j * BU_WG + tid;
+        v[j] = (tile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+    }
+    bu_stage_tables_n<WGS, TARGET>(T, tables);
+    if (tid < 64) (&cnt[0][0])[tid] = 0;
+    if (tid < 2) next_chunk[tid] = 0;
+    __syncthreads();
+    BU_STAMP(1)
+    unsigned par = 0;
+    for (; tile < n_tiles; tile += gridDim.x, par ^= 1u) {
+        const unsigned tbase = tile * BU_TILE;
+        // ---- A: sort key + rank within the key (counting sort, pass 1) ----
+        // key = position of the block's mode in BU_COST_ORDER (runs are laid out heaviest code path first).
+        // Rank within the key = one LDS atomic per block.  64 lanes adding to ONE counter serialise, though, and that is
+        // exactly what coherent textures produce (flat regions: long runs of one mode).  A wave whose loads are each of a
+        // single mode therefore takes an aggregated path -- one atomic of 64 by lane 0 per load, rank = lane id -- chosen
+        // by a wave-uniform branch; every other wave runs the plain per-lane atomics unchanged.
+        uint32_t key[BU_BPT], pos[BU_BPT];
+        bool uniform = true;
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            const bool valid = tbase + j * BU_WG + tid < n_blocks;
+            key[j] = valid ? T.key_lut[v[j].x & 127u] : 31u;
+            uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && key[j] < 20u;
+        }
+        if (uniform) {
+            uint32_t lead[BU_BPT];
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) lead[j] = lane == 0 ? atomicAdd(&cnt[par][key[j]], 64u) : 0u;
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) pos[j] = (uint32_t)__builtin_amdgcn_readfirstlane(lead[j]) + lane;
+        } else {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) pos[j] = atomicAdd(&cnt[par][key[j]], 1u);  // lanes past the end hit the dummy counter 31: no exec-mask region, the atomics issue back to back
+        }
+        BU_STAMP(2)
+        __syncthreads();  // (1) every rank is final
+        BU_STAMP(3)
+        // ---- B: run starts and the chunk map, derived by EVERY wave for itself ----
+        // Lane k < 20 holds run k: blocks in the low half, 64-block chunks in the high half of one word; a DPP scan gives
+        // every run's first slot and first chunk number.  No wave waits for another one here (the round-1 kernel had one
+        // wave build a chunk list in LDS while seven stood at a barrier).
+        const uint32_t run_c = lane < 20u ? cnt[par][lane] : 0u;
+        const uint32_t run_pk = run_c | (((run_c + 63u) >> 6) << 16);
+        const uint32_t run_incl = bu_scan32(run_pk), run_excl = run_incl - run_pk;  // lanes 20..31 carry the totals
+        const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)run_incl, 31) >> 16;
+        if (tid < 32) cnt[par ^ 1u][tid] = 0;  // the other parity: last read in B of the previous tile, next written in A of the next one
+        if (tid == 0) next_chunk[par ^ 1u] = 0;
+        // ---- scatter into sorted order (counting sort, pass 2) ----
+        uint32_t dest[BU_BPT];
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++) {
+            const uint32_t st = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key[j] << 2), (int)run_excl) & 0xFFFFu;
+            dest[j] = key[j] < 20u ? st + pos[j] : 0u;
+            if (key[j] < 20u) {
+                sblk[dest[j]] = v[j];
+                if constexpr (DIRECT) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
+            }
+        }
+        // prefetch the next tile while this one is transcoded
+        const unsigned ntile = tile + gridDim.x;
+        uint4 vn[BU_BPT];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) {
+                const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
+                vn[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        BU_STAMP(4)
+        __syncthreads();  // (2) the sorted tile is complete
+        BU_STAMP(5)
+        // ---- C: whole chunks, wave-uniform mode ----
+        // dynamic chunk scheduling: waves take the next chunk as they free up (one LDS atomic per chunk).  The claim for the
+        // FOLLOWING chunk is issued before the current one is transcoded, so its LDS round trip hides under the transcode.
+        uint32_t c_next = 0;
+        if (lane == 0) c_next = atomicAdd(&next_chunk[par], 1u);
+        for (;;) {
+            const uint32_t c = __builtin_amdgcn_readfirstlane(c_next);
+            if (c >= nc) break;
+            if (lane == 0) c_next = atomicAdd(&next_chunk[par], 1u);
+            // chunk c belongs to the first run whose inclusive chunk count exceeds c
+            const uint32_t r = (uint32_t)__builtin_ctzll(__ballot((run_incl >> 16) > c));
+            const uint32_t r_pk = (uint32_t)__builtin_amdgcn_readlane((int)run_pk, (int)r), r_ex = (uint32_t)__builtin_amdgcn_readlane((int)run_excl, (int)r);
+            const uint32_t k64 = (c - (r_ex >> 16)) << 6;
+            const uint32_t m = bu_mode_of_key(r), s0 = (r_ex & 0xFFFFu) + k64, left = (r_pk & 0xFFFFu) - k64, count = left < 64u ? left : 64u;
+            const bool active = lane < count;
+            const uint32_t slot = s0 + (active ? lane : 0u);
+            const uint4 bv = sblk[slot];
+            BuBlk b;
+            b.w[0] = bv.x;
+            b.w[1] = bv.y;
+            b.w[2] = bv.z;
+            b.w[3] = bv.w;
+            constexpr int NO = TARGET == BU_TGT_RGBA ? 16 : 4;
+            uint32_t o[NO];
+#pragma unroll
+            for (int i = 0; i < NO; i++) o[i] = 0;
+            int st = BU_ST_BAD_MODE;
+            if (active) {
+                switch (m) {
+#define BU_CASE(k) \
+    case k: st = bu_block_mode<TARGET, k>(T, b, o); break;
+                    BU_CASE(0) BU_CASE(1) BU_CASE(2) BU_CASE(3) BU_CASE(4) BU_CASE(5) BU_CASE(6) BU_CASE(7) BU_CASE(8) BU_CASE(9)
+                    BU_CASE(10) BU_CASE(11) BU_CASE(12) BU_CASE(13) BU_CASE(14) BU_CASE(15) BU_CASE(16) BU_CASE(17) BU_CASE(18)
+#undef BU_CASE
+                default: break;
+                }
+                // (a failing block leaves o[] at the zeros it was initialised with: every path checks before it writes)
+                if constexpr (DIRECT) {
+                    const unsigned idx = tbase + sorig[slot];
+                    if (st) bu_report(status, base + idx, st);
+                    if constexpr (TARGET == BU_TGT_RGBA) {
+                        const unsigned by = idx / bpr, bx = idx - by * bpr;
+                        uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; r2++) img[(size_t)((4 * by + r2) * bpr + bx)] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
+                    } else if constexpr (TARGET == BU_TGT_ETC1) {
+                        reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
+                    } else {
+                        reinterpret_cast<uint4*>(out)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                } else if constexpr (TARGET == BU_TGT_RGBA) {
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2++) sout[r2 * BU_TILE + slot] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
+                    sst[slot] = (uint8_t)st;
+                } else {
+                    sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
+                    sst[slot] = (uint8_t)st;
+                }
+            }
+        }
+        BU_STAMP(6)
+        __syncthreads();  // (3) every result is in LDS
+        BU_STAMP(7)
+        // ---- D: results leave in original order ----
+        if constexpr (!DIRECT) {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) {
+                if (key[j] < 20u) {
+                    const unsigned idx = tbase + j * BU_WG + tid;
+                    const uint32_t st = sst[dest[j]];
+                    if (st) bu_report(status, base + idx, (int)st);
+                    if constexpr (TARGET == BU_TGT_RGBA) {
+                        const unsigned by = idx / bpr, bx = idx - by * bpr;
+                        uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)((4 * by + r) * bpr + bx), sout[r * BU_TILE + dest[j]]);
+                    } else {
+                        const uint4 r = sblk[dest[j]];
+                        if constexpr (TARGET == BU_TGT_ETC1) bu_st_stream(reinterpret_cast<uint2*>(out) + idx, make_uint2(r.x, r.y));
+                        else bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
+                    }
+                }
+            }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) {
+                const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
+                v[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only
+        // after its reads of this tile's results have completed
+    }
+    BU_STAMP(8)
+}
+
+// status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into
+// hipGraphs, and a captured 8-byte memset node replayed as zeros on ROCm 7.2 (tests/test_gpu_round2.py, graph test).
+__global__ void bu_status_reset_kernel(unsigned long long* words, unsigned n)
+{
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) words[i] = ~0ull;
+}
+
+// uint4 -> uint4 copy with the transcoders' launch shape (measurement only)
+__global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    for (size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x; idx < n; idx += stride) bu_st_stream(out + idx, bu_ld_stream(in + idx));  // same streaming hints as the transcoders
+
+}
+
+// ---- ETC1S back-end ----------------------------------------------------------------------------
+// etc.rs:396-431 for one base colour: colour k = clamp(extend5(c5) + modifier[inten][k])
+__device__ __forceinline__ uint32_t bu_etc1s_color(const int16_t* mods, uint32_t ep, int k)
+{
+    const int md = mods[((ep >> 24) & 7u) * 4 + k];
+    uint32_t c = 0xFF000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const uint32_t c5 = (ep >> (8 * ch)) & 0xFFu;
+        const int base = (int)(((c5 << 3) | (c5 >> 2)) & 0xFFu);
+        const int v = base + md;
+        c |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * ch);
+    }
+    return c;
+}
+
+// basis_lz/mod.rs:163-181
+__global__ __launch_bounds__(BU_WG) void bu_etc1s_etc1_kernel(const uint32_t* __restrict__ idx, size_t n_blocks,
+                                                              const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                              const uint2* __restrict__ selectors, uint32_t n_sel,
+                                                              uint2* __restrict__ out, unsigned long long* status)
+{
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
+        const uint32_t ix = __builtin_nontemporal_load(idx + i);  // streamed once; the codebook gathers below stay cached
+        const uint32_t e = ix & 0xFFFFu, s = ix >> 16;
+        uint2 o = make_uint2(0, 0);
+        if (e >= n_ep || s >= n_sel) {
+            bu_report(status, i, BU_ERR_INDEX_RANGE);
+        } else {
+            const uint32_t ep = endpoints[e];
+            const uint32_t inten = ep >> 24;
+            // bytes: r5<<3, g5<<3, b5<<3, inten<<5 | inten<<2 | 0b11 (u8 arithmetic)
+            o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
+            o.y = selectors[s].y;
+        }
+        bu_st_stream(out + i, o);
+    }
+}
+
+// basis_lz/mod.rs:122-146 (+ the alpha pass :139-143 fused)
+__global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ aidx,
+                                                              unsigned nbx, size_t n_blocks, const uint32_t* __restrict__ endpoints,
+                                                              uint32_t n_ep, const uint2* __restrict__ selectors, uint32_t n_sel,
+                                                              uint4* __restrict__ out, unsigned long long* status,
+                                                              const BuTables* __restrict__ tables)
+{
+    __shared__ int16_t mods[32];
+    if (threadIdx.x < 32) mods[threadIdx.x] = tables->etc1_mod[threadIdx.x];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * BU_WG;
+    for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
+        const uint32_t ix = __builtin_nontemporal_load(idx + i);
+        const uint32_t e = ix & 0xFFFFu, s = ix >> 16;
+        uint32_t ae = 0, as = 0;
+        bool bad = e >= n_ep || s >= n_sel;
+        if (aidx) {
+            const uint32_t ax = __builtin_nontemporal_load(aidx + i);
+            ae = ax & 0xFFFFu;
+            as = ax >> 16;
+            bad = bad || ae >= n_ep || as >= n_sel;
+        }
+        uint32_t px[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) px[k] = 0;
+        if (bad) {
+            bu_report(status, i, BU_ERR_INDEX_RANGE);
+        } else {
+            const uint32_t ep = endpoints[e];
+            const uint32_t rows = selectors[s].x;
+            uint32_t col[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) col[k] = bu_etc1s_color(mods, ep, k);
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const uint32_t sel = (rows >> (2 * t)) & 3u;  // row y in byte y, x = 0 in the low bits (etc.rs:354-361)
+                px[t] = sel == 0 ? col[0] : sel == 1 ? col[1] : sel == 2 ? col[2] : col[3];
+            }
+            if (aidx) {
+                const uint32_t aep = endpoints[ae];
+                const uint32_t arows = selectors[as].x;
+                uint32_t ag[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) ag[k] = (bu_etc1s_color(mods, aep, k) >> 8) & 0xFFu;  // .a = colors[sel].g
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const uint32_t sel = (arows >> (2 * t)) & 3u;
+                    const uint32_t a = sel == 0 ? ag[0] : sel == 1 ? ag[1] : sel == 2 ? ag[2] : ag[3];
+                    px[t] = (px[t] & 0x00FFFFFFu) | (a << 24);
+                }
+            }
+        }
+        const size_t by = i / nbx, bx = i - by * nbx;
+#pragma unroll
+        for (int r = 0; r < 4; r++) bu_st_stream(out + (4 * by + r) * (size_t)nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
+    }
+}
+
+
+// ---- whole-file ETC1S launches (bu_read_to): every slice of the file in ONE launch -----------------------------------
+// The host concatenates the per-slice index arrays (each padded to a multiple of 64 words) and describes the slices in a
+// small table; a wave owns one 64-block unit, finds its slice by a scalar binary search over the units' prefix and then
+// does exactly what the per-slice kernels do.  One status word per image, as the sequential drivers report.
+struct BuEtc1sSlice {
+    uint32_t unit0;     // first 64-block unit of this slice (the table ends with a sentinel holding the total)
+    uint32_t n_blocks;  // nbx * nby
+    uint32_t nbx;       // blocks per row (RGBA addressing)
+    uint32_t idx_ofs;   // colour indices, in words from the start of the staged index buffer
+    uint32_t aidx_ofs;  // alpha indices (RGBA with alpha pairs), 0xFFFFFFFF = none
+    uint32_t image;     // status word / image number
+    uint64_t out_ofs;   // byte offset of the image in the output buffer
+};
+static_assert(sizeof(BuEtc1sSlice) == 32, "descriptor layout is shared with the host code");
+
+template <bool RGBA>
+__global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __restrict__ idx, const BuEtc1sSlice* __restrict__ slices, uint32_t n_slices,
+                                                              uint32_t n_units, const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                              const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
+                                                              unsigned long long* status, const BuTables* __restrict__ tables)
+{
+    __shared__ int16_t mods[32];
+    if constexpr (RGBA) {
+        if (threadIdx.x < 32) mods[threadIdx.x] = tables->etc1_mod[threadIdx.x];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u, wpg = BU_WG / 64;
+    for (uint32_t unit = blockIdx.x * wpg + (threadIdx.x >> 6); unit < n_units; unit += gridDim.x * wpg) {
+        // largest s with slices[s].unit0 <= unit (unit is wave-uniform: the search runs on the scalar unit)
+        uint32_t lo = 0, hi = n_slices;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (__builtin_amdgcn_readfirstlane(slices[mid].unit0) <= unit) lo = mid;
+            else hi = mid;
+        }
+        const BuEtc1sSlice sd = slices[lo];
+        const uint32_t i = (unit - sd.unit0) * 64u + lane;
+        if (i >= sd.n_blocks) continue;
+        const uint32_t ix = __builtin_nontemporal_load(idx + sd.idx_ofs + i);
+        const uint32_t e = ix & 0xFFFFu, sl = ix >> 16;
+        bool bad = e >= n_ep || sl >= n_sel;
+        if constexpr (!RGBA) {
+            uint2 o = make_uint2(0, 0);
+            if (bad) {
+                bu_report(status + sd.image, i, BU_ERR_INDEX_RANGE);
+            } else {  // basis_lz/mod.rs:163-181
+                const uint32_t ep = endpoints[e];
+                const uint32_t inten = ep >> 24;
+                o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
+                o.y = selectors[sl].y;
+            }
+            bu_st_stream(reinterpret_cast<uint2*>(out + sd.out_ofs) + i, o);
+        } else {  // basis_lz/mod.rs:122-146
+            const bool has_a = sd.aidx_ofs != 0xFFFFFFFFu;
+            uint32_t ae = 0, as = 0;
+            if (has_a) {
+                const uint32_t ax = __builtin_nontemporal_load(idx + sd.aidx_ofs + i);
+                ae = ax & 0xFFFFu;
+                as = ax >> 16;
+                bad = bad || ae >= n_ep || as >= n_sel;
+            }
+            uint32_t px[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) px[k] = 0;
+            if (bad) {
+                bu_report(status + sd.image, i, BU_ERR_INDEX_RANGE);
+            } else {
+                const uint32_t ep = endpoints[e];
+                const uint32_t rows = selectors[sl].x;
+                uint32_t col[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) col[k] = bu_etc1s_color(mods, ep, k);
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const uint32_t sel = (rows >> (2 * t)) & 3u;
+                    px[t] = sel == 0 ? col[0] : sel == 1 ? col[1] : sel == 2 ? col[2] : col[3];
+                }
+                if (has_a) {
+                    const uint32_t aep = endpoints[ae];
+                    const uint32_t arows = selectors[as].x;
+                    uint32_t ag[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ag[k] = (bu_etc1s_color(mods, aep, k) >> 8) & 0xFFu;
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const uint32_t sel = (arows >> (2 * t)) & 3u;
+                        const uint32_t a = sel == 0 ? ag[0] : sel == 1 ? ag[1] : sel == 2 ? ag[2] : ag[3];
+                        px[t] = (px[t] & 0x00FFFFFFu) | (a << 24);
+                    }
+                }
+            }
+            const uint32_t by = i / sd.nbx, bx = i - by * sd.nbx;
+            uint4* img = reinterpret_cast<uint4*>(out + sd.out_ofs);
+#pragma unroll
+            for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)(4 * by + r) * sd.nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+unsigned bu_grid_for(size_t n_blocks, int cu_count)
+{
+    // enough workgroups to fill the chip several times over, capped so every workgroup amortises its
+    // table copy over >= 2 batches on large inputs (guide: grid ~ CUs x 8 for memory-bound kernels)
+    size_t wgs = (n_blocks + BU_WG - 1) / BU_WG;
+    const size_t cap = (size_t)cu_count * 8;
+    if (wgs > cap) wgs = cap;
+    if (wgs == 0) wgs = 1;
+    return (unsigned)wgs;
+}
+
+}  // namespace
