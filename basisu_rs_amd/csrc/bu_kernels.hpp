@@ -226,6 +226,8 @@ __device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables*
 #define BU_STAMP(k)
 #define BU_STAMP_ARG
 #define BU_STAMP_PASS
+#define BU_STAMP_DECL
+#define BU_STAMP_NEXT
 #endif
 // DIRECT: results are stored to global memory straight from the chunk loop at the block's original
 // index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTables* __restrict__ tables, unsigned cus BU_STAMP_ARG)
 {
+    BU_STAMP_DECL
     BU_STAMP(0)
     if constexpr (SKEW > 0) {
         if (blockIdx.x >= gridDim.x / 2 && gridDim.x > 1) __builtin_amdgcn_s_sleep(SKEW);
@@ -443,8 +446,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         }
         // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only
         // after its reads of this tile's results have completed
+        BU_STAMP(8)
+        BU_STAMP_NEXT
     }
-    BU_STAMP(8)
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into

@@ -7,14 +7,16 @@
     if (stamps && (threadIdx.x & 63u) == 0) {                                                         \
         unsigned long long t_;                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-        stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = t_;        \
+        stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + ((k) >= 2 ? 16 * bu_stamp_it_ : 0) + (k)] = t_;        \
         if ((k) == 0 || (k) == 8) {                                                                   \
             unsigned long long r_;                                                                    \
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_)::"memory");            \
-            stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + 9 + (k) / 8] = r_; \
+            stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + ((k) >= 2 ? 16 * bu_stamp_it_ : 0) + 9 + (k) / 8] = r_; \
         }                                                                                             \
     }
 #define BU_CHUNK_DECL unsigned chunk_no_ = 0;
+#define BU_STAMP_DECL unsigned bu_stamp_it_ = 0;
+#define BU_STAMP_NEXT bu_stamp_it_ = 1;
 // per-chunk stamps: slot k of chunk record n of this wave: [time, value]
 #define BU_CHUNK_STAMP(k, val)                                                                                     \
     if (stamps && (threadIdx.x & 63u) == 0) {                                                                      \
@@ -147,6 +149,14 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
         case 24: {
             const size_t t_ = (n_blocks + 1023) / 1024;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 2, 1, false, false, 0>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+        } break;
+        case 30: {  // 1024 x 1, two persistent workgroups per CU, prefetch: two tiles per workgroup
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 1024, 1, 1, true, false, 0>), dim3((unsigned)(2 * ctx->cu_count)), dim3(1024), 0, s, in, d_out[k],
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+        } break;
+        case 31: {  // 512 x 2, two persistent workgroups per CU, prefetch
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 2, 1, true, false, 0>), dim3((unsigned)(2 * ctx->cu_count)), dim3(512), 0, s, in, d_out[k],
                                (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
         } break;
         case 23: {
