@@ -130,6 +130,10 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--nbuf", type=int, default=64, help="distinct atlas buffers rotated through (cold cache)")
+    ap.add_argument("--prewarm-ms", type=float, default=25.0,
+                    help="untimed launches BEFORE the W warm-up steps until this many milliseconds have passed: the GPU needs ~20 ms of "
+                         "sustained work to reach its steady clocks (measured: 10.46 us per launch after --warmup 5, 9.8-9.9 after --warmup 2000 "
+                         "or more); with it --warmup 5 --steps 20 and --warmup 64 --steps 512 agree.  0 disables")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the verified, timed headline launches (no context rows, no CPU leg): the command profiled with rocprofv3, "
@@ -397,6 +401,13 @@ def run_array512(env):
         if not torch.equal(mine[k], expect(s)):
             raise SystemExit("bench: BC7 output of slice %d differs from the known-answer vectors" % s)
     rot[0] = 1 % nrot
+    prewarm_launches = 0
+    t_pre = time.perf_counter()
+    # clock ramp, untimed (see --prewarm-ms); the 1 GiB-per-launch kernel takes about four times as long to settle
+    # (0.49 of the roofline after 25 ms, 0.56 after 100 ms and in every longer run)
+    while args.prewarm_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < 4 * args.prewarm_ms:
+        run(8)
+        prewarm_launches += 8
     if args.warmup > 0:
         run(args.warmup)
     torch.cuda.synchronize()
@@ -428,7 +439,9 @@ def run_array512(env):
         "config": {"workload": "UASTC->BC7, texture array of 512 slices x 65 536 blocks (512 MiB in, 512 MiB out) per step; rank r owns "
                                "slices [r*512/N, (r+1)*512/N), one launch over its contiguous range; A-gold blocks; %d rotated "
                                "input shards / full output buffers per rank" % nrot,
-                   "blocks_per_step": total, "slices_per_gpu": hi - lo, "gb_s_in": round(value * 16 / 1e3, 1)},
+                   "blocks_per_step": total, "slices_per_gpu": hi - lo, "gb_s_in": round(value * 16 / 1e3, 1),
+                   "prewarm": {"launches": prewarm_launches, "ms": 4 * args.prewarm_ms,
+                               "note": "untimed launches ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}},
         "transcode_only": {"mblocks_s": round(total / kern_s / 1e6, 1), "us_per_step_kernel_max_over_ranks": round(kern_s * 1e6, 3),
                            "note": "all blocks / slowest rank's kernel time (hipEvents on the launch stream)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -510,7 +523,12 @@ def run_atlas4096(env):
         if not torch.equal(outs[k], g_bc7[idxs[k]]):
             raise SystemExit("bench: BC7 output of atlas %d differs from the known-answer vectors" % k)
 
-    # ---- warmup, then EXACTLY K timed steps between barrier + synchronize ----
+    # ---- clock ramp (untimed, see --prewarm-ms), W warm-up steps, then EXACTLY K timed steps between barrier + synchronize ----
+    prewarm_launches = 0
+    t_pre = time.perf_counter()
+    while args.prewarm_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        run(256)
+        prewarm_launches += 256
     if args.warmup > 0:
         run(args.warmup)
     torch.cuda.synchronize()
@@ -727,7 +745,9 @@ def run_atlas4096(env):
         "config": {"workload": "UASTC->BC7, 4096x4096 px (1 048 576 blocks) per GPU per step, A-gold atlas "
                                "(block i = reference known-answer block h(i) mod 608, uniform mix of the 19 modes), "
                                "%d distinct atlases rotated (cold cache)" % nbuf,
-                   "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1)},
+                   "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1),
+                   "prewarm": {"launches": prewarm_launches, "ms": args.prewarm_ms,
+                               "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                      "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
