@@ -81,27 +81,25 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
         t_prev = t;
     };
     BuFilePlan p;
-    // Large UASTC files: the payload CRC (0.3 ms per 16 MiB on the host cores) runs beside the upload instead of before
-    // it.  The reference checks it before anything else behind the header (basis.rs:338-341), so a CRC failure takes
-    // precedence over every later error, and nothing is reported as success before it is known.
-    std::future<bool> crc_later;
+    // Large UASTC files: the payload CRC (0.7 ms per 16 MiB on the host cores -- as long as upload, kernel and download
+    // together) is computed ON THE DEVICE over the slice bytes the call uploads anyway (bu_crc16_pieces_kernel, one
+    // register per 64 KiB piece); the host only runs the bytes the device never sees (slice table, gaps, the tail of a run
+    // behind its last whole piece) and folds everything in file order.  The reference checks the CRC before anything else
+    // behind the header (basis.rs:338-341), so a CRC failure takes precedence over every later error, and nothing is
+    // reported as success before it is known; an early error return settles it on the host.
     bool crc_deferred = false;
+    uint16_t crc_want = 0;
     {
         bu_basis_header h0;
         if (file && len >= ((size_t)1 << 20) && bu_host::read_header(file, len, &h0) == BU_OK && h0.tex_format == 1 && target != BU_READ_UASTC) {
-            const uint16_t want = h0.data_crc16;
-            try {
-                crc_later = std::async(std::launch::async, [file, len, want] { return bu_host::crc16(file + 77, len - 77, 0) == want; });
-                crc_deferred = true;
-            } catch (...) {  // no thread to be had: the plan below checks the CRC inline, in the reference's order
-                crc_deferred = false;
-            }
+            crc_deferred = true;
+            crc_want = h0.data_crc16;
         }
     }
     auto settle = [&](bu_status s) {  // the status to report once the deferred CRC is known
         if (crc_deferred) {
             crc_deferred = false;
-            if (!crc_later.get()) return BU_ERR_DATA_CRC;
+            if (bu_host::crc16(file + 77, len - 77, 0) != crc_want) return BU_ERR_DATA_CRC;
         }
         return s;
     };
@@ -191,6 +189,12 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
     BU_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<uint64_t> words(n_img, 0);  // status landing area: declared before anything is queued, outlives the drain
     std::vector<BuEtc1sSlice> descs;        // (likewise: source of an upload)
+    struct CrcSeg {
+        size_t file_ofs, len, first_piece, n_pieces;
+    };
+    std::vector<CrcSeg> crc_segs;           // uploaded file ranges whose 64 KiB pieces the device registers
+    std::vector<uint16_t> crc_parts((crc_deferred && !p.etc1s) ? total_in / BU_CRC_PIECE + 1 : 1, 0);  // (landing area too)
+    size_t crc_pieces = 0;
     BuDrain drain(ctx);
     if ((st = bu_reserve(ctx, &ctx->d_in, &ctx->in_cap, total_in ? total_in : 16))) return st;
     // a page-locked `out` (bu_host_alloc) receives the kernels' stores directly over PCIe: no device output buffer, no download
@@ -222,11 +226,21 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
         descs.push_back(end);
     }
     const size_t desc_bytes = align_up(descs.size() * sizeof(BuEtc1sSlice)), status_bytes = align_up(8 * n_img);
-    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + status_bytes + desc_bytes + 256))) return st;
+    const size_t crc_bytes = align_up(2 * crc_parts.size());
+    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + status_bytes + desc_bytes + crc_bytes + 256))) return st;
     uint8_t* d_in = static_cast<uint8_t*>(ctx->d_in);
     uint8_t* d_out = direct_out ? static_cast<uint8_t*>(zout) : static_cast<uint8_t*>(ctx->d_out);
     uint8_t* aux = static_cast<uint8_t*>(ctx->d_aux);
     uint64_t* d_status = reinterpret_cast<uint64_t*>(aux + ep_bytes + sel_bytes);
+    uint16_t* d_crc = reinterpret_cast<uint16_t*>(aux + ep_bytes + sel_bytes + status_bytes + desc_bytes);
+    // registers of the whole 64 KiB pieces of an uploaded range, on the stream that carries its upload
+    auto crc_enqueue = [&](const uint8_t* d_range, size_t file_ofs, size_t nbytes, hipStream_t ps) {
+        if (!crc_deferred) return;
+        const size_t np = nbytes / BU_CRC_PIECE;
+        if (np) hipLaunchKernelGGL(bu_crc16_pieces_kernel, dim3((unsigned)np), dim3(256), 0, ps, reinterpret_cast<const uint4*>(d_range), d_crc + crc_pieces, ctx->d_crc_tables);
+        crc_segs.push_back({file_ofs, nbytes, crc_pieces, np});
+        crc_pieces += np;
+    };
     BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, 8 * n_img, ctx->stream));
     if (p.etc1s) {
         BU_HIP(ctx, hipMemcpyAsync(d_in, idx_all.data(), total_in, hipMemcpyHostToDevice, ctx->stream));
@@ -250,8 +264,12 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
         }
     }
     bool used_extra = false;
-    size_t run_piece_bytes = (size_t)16 << 20;
-    if (const char* e = getenv("BU_RUN_PIECE_MIB")) run_piece_bytes = (size_t)atoll(e) << 20;  // 0 disables the pieced pipeline
+    size_t run_piece_bytes = (size_t)16 << 20;  // upper bound; a run is cut into >= 4 pieces of >= 4 MiB (below)
+    bool piece_fixed = false;
+    if (const char* e = getenv("BU_RUN_PIECE_MIB")) {  // 0 disables the pieced pipeline
+        run_piece_bytes = (size_t)atoll(e) << 20;
+        piece_fixed = true;
+    }
     for (size_t k = 0; k < n_img; k++) {
         const bu_slice_desc& s = p.slices[p.first_slice[k]];
         const bu_image& im = p.images[k];
@@ -266,7 +284,14 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                 const size_t run_bytes = in_off[run_end] + p.slices[p.first_slice[run_end]].file_size - in_off[k];
                 // A large block-linear run with a mapped (page-locked) output: upload and transcode in pieces on two
                 // streams, so that piece i's results cross PCIe upstream while piece i+1 comes down.
-                const size_t piece_bytes = run_piece_bytes;
+                // piece size: a quarter of the run, between 4 and 16 MiB (a 16 MiB file: 0.672 ms in one piece, 0.585 in four,
+                // 0.645 in eight -- tools/exp/file_time.py)
+                size_t piece_bytes = run_piece_bytes;
+                if (!piece_fixed) {
+                    piece_bytes = (run_bytes / 4) & ~(((size_t)1 << 20) - 1);
+                    if (piece_bytes < ((size_t)4 << 20)) piece_bytes = (size_t)4 << 20;
+                    if (piece_bytes > run_piece_bytes) piece_bytes = run_piece_bytes;
+                }
                 if (target != BU_READ_RGBA && direct_out && piece_bytes && run_bytes >= 2 * piece_bytes) {
                     pieced = true;
                     if (!ctx->extra_streams[0]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[0], hipStreamNonBlocking));
@@ -283,12 +308,14 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                         const size_t nbytes = run_bytes - done < piece_bytes ? run_bytes - done : piece_bytes;
                         hipStream_t ps = (piece_no & 1) ? ctx->extra_streams[0] : ctx->stream;
                         BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k] + done, file + s.file_ofs + done, nbytes, hipMemcpyHostToDevice, ps));
+                        crc_enqueue(d_in + in_off[k] + done, (size_t)s.file_ofs + done, nbytes, ps);
                         st = bu_launch_uastc(ctx, pbt, d_in + in_off[k] + done, nbytes / 16, d_out + im.offset + (done / 16) * obytes, 1, done / 16, d_status + k, ps,
                                              BU_ZEROCOPY_GRID);
                         if (st) return st;
                     }
                 } else {
                     BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k], file + s.file_ofs, run_bytes, hipMemcpyHostToDevice, ctx->stream));
+                    crc_enqueue(d_in + in_off[k], s.file_ofs, run_bytes, ctx->stream);
                 }
             }
             const bu_target bt = target == BU_READ_RGBA ? BU_TARGET_RGBA32
@@ -312,12 +339,43 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
         BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[0]));
         BU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
     }
+    BU_HIP(ctx, hipGetLastError());
     BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
+    if (crc_pieces) BU_HIP(ctx, hipMemcpyAsync(crc_parts.data(), d_crc, 2 * crc_pieces, hipMemcpyDeviceToHost, ctx->stream));
     if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (used_extra) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[0]));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain.armed = false;
     lap("download + synchronise");
+    if (crc_deferred) {  // fold the device's piece registers with the bytes only the host has seen, in file order
+        crc_deferred = false;
+        std::sort(crc_segs.begin(), crc_segs.end(), [](const CrcSeg& a, const CrcSeg& b) { return a.file_ofs < b.file_ofs; });
+        bool foldable = true;
+        size_t pos = 77;
+        for (const CrcSeg& g2 : crc_segs) {  // overlapping slices (a hostile slice table): the plain host CRC decides
+            if (g2.file_ofs < pos || g2.file_ofs + g2.len > len) foldable = false;
+            pos = g2.file_ofs + g2.len;
+        }
+        bool crc_ok;
+        if (!foldable) {
+            crc_ok = bu_host::crc16(file + 77, len - 77, 0) == crc_want;
+        } else {
+            const uint16_t shift_piece = bu_host::crc16_shift(1, BU_CRC_PIECE);  // x^(8 * 65536)
+            uint16_t reg = 0xFFFF;  // register of CRC-16/GENIBUS before the first payload byte
+            pos = 77;
+            for (const CrcSeg& g2 : crc_segs) {
+                reg = bu_host::crc16_raw(file + pos, g2.file_ofs - pos, reg);
+                for (size_t i = 0; i < g2.n_pieces; i++) reg = (uint16_t)(bu_host::crc16_gf_mul(reg, shift_piece) ^ crc_parts[g2.first_piece + i]);
+                const size_t covered = g2.n_pieces * BU_CRC_PIECE;
+                reg = bu_host::crc16_raw(file + g2.file_ofs + covered, g2.len - covered, reg);
+                pos = g2.file_ofs + g2.len;
+            }
+            reg = bu_host::crc16_raw(file + pos, len - pos, reg);
+            crc_ok = (uint16_t)~reg == crc_want;
+        }
+        lap("data CRC fold");
+        if (!crc_ok) return BU_ERR_DATA_CRC;
+    }
     for (size_t k = 0; k < n_img; k++) {  // first Err (in slice order) aborts the whole call, like the `?` in the reference drivers
         st = bu_status_word_decode(words[k], nullptr);
         if (st) return st;

@@ -70,6 +70,18 @@ bu_status bu_context_create(int device, bu_context** out_ctx)
         hipError_t e = hipMemcpy(ctx->d_tables, h, sizeof(BuTables), hipMemcpyHostToDevice);
         delete h;
         if (e != hipSuccess) { st = BU_ERR_HIP; break; }
+        // CRC tables of the device-side data CRC: registers after (byte, k zero bytes), and x^(2048 k) for the in-piece fold
+        BuCrcTables ct;
+        for (int b = 0; b < 256; b++)
+            for (int k = 0; k < 4; k++) {
+                const uint8_t msg[4] = {(uint8_t)b, 0, 0, 0};
+                ct.t[k][b] = bu_host::crc16_raw(msg, (size_t)k + 1, 0);
+            }
+        const uint16_t x2048 = bu_host::crc16_shift(1, 256);
+        ct.pw[0] = 1;
+        for (int k = 1; k < 256; k++) ct.pw[k] = bu_host::crc16_gf_mul(ct.pw[k - 1], x2048);
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_crc_tables), sizeof(BuCrcTables)) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMemcpy(ctx->d_crc_tables, &ct, sizeof(ct), hipMemcpyHostToDevice) != hipSuccess) { st = BU_ERR_HIP; break; }
     } while (0);
     if (st != BU_OK) {
         bu_context_destroy(ctx);
@@ -85,6 +97,7 @@ void bu_context_destroy(bu_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_crc_tables) (void)hipFree(ctx->d_crc_tables);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_out) (void)hipFree(ctx->d_out);

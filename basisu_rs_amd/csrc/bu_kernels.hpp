@@ -458,6 +458,57 @@ __global__ void bu_status_reset_kernel(unsigned long long* words, unsigned n)
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) words[i] = ~0ull;
 }
 
+// ---- CRC-16/GENIBUS of an uploaded file range (basis.rs:364-372; the data CRC of basis.rs:338-341) ----------------------------
+// The CRC is linear over GF(2): register(A || B) = register(A) * x^(8|B|) + register(B).  One workgroup covers a 64 KiB piece:
+// every thread runs the table-driven register over its own 256 bytes (slicing by four, tables in LDS), multiplies it by
+// x^(8 * bytes behind it inside the piece) and the workgroup XORs the 256 contributions.  The host folds the pieces' registers
+// (and the few bytes the device never sees: slice table, gaps, tails) in file order -- bu_read_to.
+struct BuCrcTables {
+    uint16_t t[4][256];  // t[k][b]: register after byte b followed by k zero bytes
+    uint16_t pw[256];    // pw[k] = x^(8 * 256 * k) mod P
+};
+constexpr unsigned BU_CRC_PIECE = 65536;
+
+__device__ __forceinline__ uint32_t bu_crc_gf_mul(uint32_t a, uint32_t b)  // a * b mod x^16 + x^12 + x^5 + 1
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        r <<= 1;
+        r ^= (r & 0x10000u) ? 0x11021u : 0u;
+        r ^= ((b >> i) & 1u) ? a : 0u;
+    }
+    return r & 0xFFFFu;
+}
+
+__global__ __launch_bounds__(256) void bu_crc16_pieces_kernel(const uint4* __restrict__ data, uint16_t* __restrict__ partial,
+                                                              const BuCrcTables* __restrict__ tables)
+{
+    __shared__ BuCrcTables C;
+    __shared__ uint32_t red[4];
+    static_assert(sizeof(BuCrcTables) % 16 == 0, "copied in 16-byte pieces");
+    for (unsigned i = threadIdx.x; i < sizeof(BuCrcTables) / 16; i += 256) reinterpret_cast<uint4*>(&C)[i] = reinterpret_cast<const uint4*>(tables)[i];
+    __syncthreads();
+    const uint4* p = data + (size_t)blockIdx.x * (BU_CRC_PIECE / 16) + threadIdx.x * 16;
+    uint32_t s = 0;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        const uint4 v = p[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // bytes in memory order: b0 = low byte of the little-endian word
+            const uint32_t x = w[k];
+            s = (uint32_t)C.t[3][((s >> 8) ^ x) & 255u] ^ (uint32_t)C.t[2][(s ^ (x >> 8)) & 255u] ^ (uint32_t)C.t[1][(x >> 16) & 255u] ^ (uint32_t)C.t[0][x >> 24];
+        }
+    }
+    uint32_t c = bu_crc_gf_mul(s, C.pw[255u - threadIdx.x]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (uint16_t)(red[0] ^ red[1] ^ red[2] ^ red[3]);
+}
+
 // uint4 -> uint4 copy with the transcoders' launch shape (measurement only)
 __global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
 {

@@ -481,3 +481,50 @@ def test_bench_array512_mode_on_one_gpu():
     assert line["scaling"] == "strong" and line["config"]["blocks_per_step"] == 512 * 65536
     assert line["allgather"]["rccl_inplace"].get("verified") is True, line["allgather"]
     assert line["allgather"]["peer_pull"].get("verified") is True, line["allgather"]
+
+
+def test_device_side_data_crc_folds_pieces_gaps_and_tails(ctx, golden, oracle):
+    """Large UASTC files: the data CRC (basis.rs:338-341) is computed by bu_crc16_pieces_kernel over the uploaded slice bytes,
+    one register per 64 KiB piece, and folded on the host with the bytes the device never sees.  A flipped bit in EVERY
+    position class must be caught -- slice table, first piece, a middle piece, the tail behind the last whole piece, the
+    second run of a file whose runs are separated by a gap -- and intact files of awkward sizes must pass."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    def check(f, n_expected):
+        imgs = bu.read_to_bc7(f, ctx)
+        assert len(imgs) == n_expected
+        st, _, want = oracle.read_to("bc7", f)
+        assert st == 0
+        for g_, (_, _, _, data) in zip(imgs, want):
+            assert g_.data.tobytes() == data.tobytes()
+
+    # one run: 1.5 MB + an odd tail, and an exact multiple of 64 KiB
+    for nblk in (96_000 + 37, 1 << 17):
+        blocks = golden["uastc"][synth.gold_indices(nblk, seed=nblk & 255)]
+        f = bu.write_uastc_file([dict(data=blocks, orig_w=4, orig_h=4 * nblk, nbx=1, nby=nblk)])
+        check(f, 1)
+        ofs = bu.read_slice_descs(f)[0].file_ofs
+        for pos in (80, ofs + 5, ofs + 70_000, ofs + 16 * nblk - 3, len(f) - 1):
+            g = bytearray(f)
+            g[pos] ^= 0x04
+            with pytest.raises(bu.BasisuError, match="Data CRC16 failed"):
+                bu.read_to_bc7(bytes(g), ctx)
+    # several slices: back-to-back ones merge into one run; basis_builder can leave a gap between runs
+    dims = [(256, 200), (128, 100), (64, 50), (300, 250)]
+    blocks = [golden["uastc"][synth.gold_indices(x * y, seed=i + 3)] for i, (x, y) in enumerate(dims)]
+    f = bb.uastc_file(blocks, dims)
+    assert len(f) >= 1 << 20
+    check(f, 4)
+    descs = bu.read_slice_descs(f)
+    for d in descs:
+        for pos in (d.file_ofs, d.file_ofs + d.file_size - 1):
+            g = bytearray(f)
+            g[pos] ^= 0x80
+            with pytest.raises(bu.BasisuError, match="Data CRC16 failed"):
+                bu.read_to_bc7(bytes(g), ctx)
+    # the whole-file RGBA path uploads the same runs
+    st, hdr, want = oracle.read_to("rgba", f)
+    h, got = bu.read_to_rgba(f, ctx)
+    assert st == 0 and len(got) == 4 and all(a.data.tobytes() == w[3].tobytes() for a, w in zip(got, want))
