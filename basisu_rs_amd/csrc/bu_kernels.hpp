@@ -5,18 +5,23 @@
 namespace {
 
 constexpr int BU_WG = 256;            // 4 waves
-constexpr int BU_TABLE_VEC = (int)(sizeof(BuTables) / 16);
 // Below this the plain one-lane-per-block kernel is used.  It runs one mode path per DISTINCT mode present, so it only
 // wins for a handful of blocks (BC7: 1 block 2.3 vs 3.3 us, 8 blocks 4.2 vs 3.7 us, 64 blocks 7.8 vs 4.4 us,
 // 1024 blocks 16.1 vs 4.8 us; ETC1 at 128 blocks 38.6 vs 15.0 us).
 constexpr int BU_SORT_MIN_BLOCKS = 8;
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bu_stage_tables(BuTables& dst, const BuTables* __restrict__ src)
+// stage the parts of the table blob TARGET reads (bu_table_range), 16 bytes per thread per step
+template <int WGS, int TARGET>
+__device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
 {
+    constexpr BuTableRange R = bu_table_range(TARGET);
     const uint4* s = reinterpret_cast<const uint4*>(src);
     uint4* d = reinterpret_cast<uint4*>(&dst);
-    for (int i = threadIdx.x; i < BU_TABLE_VEC; i += BU_WG) d[i] = s[i];
+    for (int i = R.lo / 16 + threadIdx.x; i < (int)(R.hi / 16); i += WGS) d[i] = s[i];
+    if constexpr (R.lo2 < R.hi2) {
+        for (int i = R.lo2 / 16 + threadIdx.x; i < (int)(R.hi2 / 16); i += WGS) d[i] = s[i];
+    }
 }
 
 __device__ __forceinline__ void bu_report(unsigned long long* status, unsigned long long block, int st)
@@ -82,12 +87,13 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
                                                          unsigned bpr, unsigned long long base, unsigned long long* status,
                                                          const BuTables* __restrict__ tables)
 {
-    __shared__ BuTables T;
+    __shared__ uint4 t_store[bu_table_bytes(TARGET) / 16];  // the front of the blob, as far as TARGET reads it
+    BuTables& T = *reinterpret_cast<BuTables*>(t_store);
     const size_t stride = (size_t)gridDim.x * BU_WG;
     size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x;
     // first block load is issued before the table copy so both are in flight together
     uint4 v = idx < n_blocks ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
-    bu_stage_tables(T, tables);
+    bu_stage_tables_n<BU_WG, TARGET>(T, tables);
     __syncthreads();
     while (idx < n_blocks) {
         const size_t next = idx + stride;
@@ -177,10 +183,16 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // ETC1 / ETC2 (72-78 VGPRs): 2048-block tiles, two workgroups per CU.  Tried in round 2 (tools/exp/ab.sh): 1024-block
 // tiles with three workgroups per CU 25.7 us, with four (64 VGPRs, 7 spilled) 27.4, against 24.9 -- the ALUs are saturated
 // at 16 waves per CU, more waves only add sort overhead.
+#ifndef BU_ETC_WGS
+#define BU_ETC_WGS 512
+#define BU_ETC_BPT 4
+#define BU_ETC_WGPCU 2
+#define BU_ETC_SKEW 40
+#endif
 template <int TARGET>
 struct BuBigCfg {
     static constexpr bool PREFETCH = false, DIRECT = false;
-    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 40, MINW = 1;
+    static constexpr int WGS = BU_ETC_WGS, BPT = BU_ETC_BPT, WG_PER_CU = BU_ETC_WGPCU, SKEW = BU_ETC_SKEW, MINW = 1;
     static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
 template <>
@@ -208,19 +220,6 @@ struct BuBigCfg<BU_TGT_ASTC> {
 #define BU_RGBA_SKEW 20
 #endif
 
-
-// stage the parts of the table blob TARGET reads (bu_table_range), 16 bytes per thread per step
-template <int WGS, int TARGET>
-__device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
-{
-    constexpr BuTableRange R = bu_table_range(TARGET);
-    const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4* d = reinterpret_cast<uint4*>(&dst);
-    for (int i = R.lo / 16 + threadIdx.x; i < (int)(R.hi / 16); i += WGS) d[i] = s[i];
-    if constexpr (R.lo2 < R.hi2) {
-        for (int i = R.lo2 / 16 + threadIdx.x; i < (int)(R.hi2 / 16); i += WGS) d[i] = s[i];
-    }
-}
 
 #ifndef BU_STAMP
 #define BU_STAMP(k)
@@ -254,7 +253,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         if (gen >= 3) __builtin_amdgcn_s_setprio(3);
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
-    __shared__ BuTables T;
+    __shared__ uint4 t_store[bu_table_bytes(TARGET) / 16];  // the front of the blob, as far as TARGET reads it
+    BuTables& T = *reinterpret_cast<BuTables*>(t_store);
     // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
     // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts).  The sorted input tile
     // lives IN row 0 of that output tile: a lane reads its block from slot s and later overwrites exactly slot s with
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // which is what lets two workgroups share a CU.
     constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
-    static_assert(!BU_ALIAS || sizeof(BuTables) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
+    static_assert(!BU_ALIAS || bu_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
                   "the RGBA32 workgroup no longer fits twice per CU: shrink BuTables or stage it per target in LDS too");
     __shared__ uint4 sblk_store[BU_ALIAS ? 1 : BU_TILE];
     __shared__ uint4 sout[BU_ALIAS ? 4 * BU_TILE : 1];

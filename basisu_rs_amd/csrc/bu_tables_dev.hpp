@@ -1,8 +1,8 @@
 // Device-side lookup tables of the UASTC/ETC1S transcode kernels, and the host code that builds them.
 //
 // One `BuTables` blob is built on the host at context creation (bu_build_tables), uploaded once to
-// device memory and copied into LDS by every workgroup (it is ~7 KiB; per-lane divergent lookups are
-// LDS reads, never global gathers).  All LUTs are derived here from the format constants of
+// device memory and copied into LDS by every workgroup -- the part its target reads, 4 to 27 KiB (bu_table_range);
+// per-lane divergent lookups are LDS reads, never global gathers.  All LUTs are derived here from the format constants of
 // bu_tables.h, so the kernels never divide, never take a modulo and never run a search.
 #pragma once
 #include <stddef.h>
@@ -17,6 +17,23 @@ struct BuPart {  // one UASTC partition pattern (layout documented in bu_tables.
     uint8_t bpart, perm;
 };
 static_assert(sizeof(BuPart) == 16, "BuPart must be 16 bytes");
+struct BuU2 {
+    uint32_t x, y;
+};
+struct alignas(16) BuU4 {
+    uint32_t x, y, z, w;
+};
+// (sum * limit + 1020) / 2040 = (sum * (limit * BU_Q_M) + 1020 * BU_Q_M) >> 26 for every sum <= 2040, limit <= 31 (bu_build_tables checks)
+constexpr uint32_t BU_Q_M = 32897u;  // ceil(2^26 / 2040)
+constexpr bool bu_q_exact()
+{
+    for (uint32_t limit = 15; limit <= 31; limit += 16)
+        for (uint32_t sum = 0; sum <= 2040; sum++)
+            if ((sum * (limit * BU_Q_M) + 1020u * BU_Q_M) >> 26 != (sum * limit + 1020u) / 2040u) return false;
+    return true;
+}
+static_assert(bu_q_exact(), "multiply-shift form of the ETC1 base colour quantiser");
+static_assert(31u * BU_Q_M < (1u << 24), "the quantiser runs on v_mad_u32_u24");
 
 // offsets (bytes) into BuTables::deq of the dequantisation LUT of each BISE range UASTC uses
 // (index = trit_or_quint << bits | bits_value); filled from BU_BISE[].lut_ofs_div8
@@ -57,15 +74,26 @@ struct BuTables {
                                   // 3-bit-value group: Q012 @3, Q34 @9, Q56 @14
     int16_t pairdiff7[256];      // BISE range 7: index tq_lo | tq_hi << 2 | eb_lo << 4 | eb_hi << 6 -> deq(hi) - deq(lo)  (astc.rs:57-66)
     // ---- ETC1 / ETC2 only ----
-    alignas(16) int16_t etc1_mod[32];  // etc.rs:435-445
-    int8_t etc2_amod[128];    // etc.rs:450-468
-    uint16_t etc1_bias[32];   // apply_etc1_bias deltas (etc.rs:203-234): field (2*subblock*3 + 2*c) = delta + 2
+    alignas(16) int16_t etc1_mod[32];  // etc.rs:435-445 (the ETC1S kernels)
+    int8_t eac_mods[128];     // etc.rs:450-468, every table in ascending order of the modifier: entries 3,2,1,0,4,5,6,7
     uint32_t eac_magic[16];   // ceil(2^20 / (2*range)) per EAC modifier table (etc.rs:297-307 as integers)
     int8_t eac_mod_min[16];   // modifier[3] of each table
     uint8_t eac_range[16];    // modifier[7] - modifier[3]
-    uint8_t etc1_biasv[256];  // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value
-    uint32_t etc1_thrcol[512];  // index diff << 8 | inten << 5 | c: the channel's four modified base values clamp(base + ETC1_MODIFIERS[inten][k]),
-                                // k in byte k; base = c*17 (individual, c < 16) or c<<3 | c>>2 (differential)  (etc.rs:165-171, 396-431)
+    // the eight ETC1 flag bits as stored (flip, diff, inten0:3, inten1:3; uastc.rs:411-436) -> everything derived from them:
+    //   x = header byte 3 << 24 | (diff << 3 | inten1) << 16 | (diff << 3 | inten0) << 8   (the two fields are etc1_thr row offsets)
+    //   y = diff << 7 in bytes 0..2 (etc1_biasv index bit), z = byte offset of the diff half of etc1_hdr,
+    //   w = limit * BU_Q_M (limit = 15 or 31: the quantiser's multiplier, bu_uastc_etc.hpp)
+    alignas(16) BuU4 etc1_flags[256];
+    BuU2 etc1_bias2[32];      // apply_etc1_bias deltas (etc.rs:203-234): x = sub-block 0, y = sub-block 1; byte c = (delta + 2) << 5
+    uint8_t etc1_biasv0[256]; // apply_etc1_bias per channel (etc.rs:236-255): index diff << 7 | (delta + 2) << 5 | value -> result << 3
+    uint8_t etc1_biasv1[256]; // the same -> result << 1
+    // diff << 10 | c0 << 5 | c1 (the biased 4/5-bit base colours of one channel) -> header byte (etc.rs:113-149) | (the value the
+    // second half really decodes with: c1, or (c0 + clamped delta) & 31) << 11
+    uint16_t etc1_hdr[2048];
+    // [channel][diff << 8 | inten << 5 | c]: with v0..v3 = clamp(base + ETC1_MODIFIERS[inten][k]) (etc.rs:165-171, 396-431) and
+    // w = the channel's luma weight 54 / 183 / 19: x = -w (v0 + v1), y = w (v2 - v0) | w (v3 - v1) << 16.  Summed over the
+    // channels these are -(L0 + L1), L2 - L0 and L3 - L1, from which the three luma thresholds follow by two subtractions.
+    alignas(16) BuU2 etc1_thr[3][512];
     alignas(16) uint8_t end_marker[16];
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
@@ -83,6 +111,9 @@ constexpr BuTableRange bu_table_range(int target)
                          : BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, w3mask_u),
                                         (unsigned)offsetof(BuTables, etc1_mod), (unsigned)offsetof(BuTables, end_marker)};
 }
+
+// bytes of LDS a target's kernels reserve for the blob (its staged ranges keep their offsets: the front of the struct)
+constexpr unsigned bu_table_bytes(int target) { return bu_table_range(target).lo2 < bu_table_range(target).hi2 ? bu_table_range(target).hi2 : bu_table_range(target).hi; }
 
 // deq offsets per range, compile-time (must match tools/gen_tables.py's packing order: 7,8,11,12,13,18,19,20)
 // sizes: r7 3*4=12->16, r8 16, r11 32, r12 5*8=40, r13 3*16=48, r18 5*32=160, r19 3*64=192 = 504; r20 is the identity
@@ -174,7 +205,10 @@ static inline void bu_build_tables(BuTables* t)
     for (int i = 0; i < 125; i++) t->astc_quint[i] = BU_ASTC_QUINT_ENC[i];
     for (int i = 0; i < 20; i++) t->astc_mode13[i] = BU_ASTC_BLOCK_MODE13[i];
     for (int i = 0; i < 32; i++) t->etc1_mod[i] = BU_ETC1_MOD[i];
-    for (int i = 0; i < 128; i++) t->etc2_amod[i] = BU_ETC2_ALPHA_MOD[i];
+    for (int i = 0; i < 128; i++) {
+        static const int by_rank[8] = {3, 2, 1, 0, 4, 5, 6, 7};
+        t->eac_mods[i] = BU_ETC2_ALPHA_MOD[(i & ~7) + by_rank[i & 7]];
+    }
     for (int i = 0; i < 128; i++) t->mode_lut[i] = BU_MODE_LUT[i];
     for (int i = 0; i < 128; i++) {
         t->key_lut[i] = 19;
@@ -189,7 +223,7 @@ static inline void bu_build_tables(BuTables* t)
         t->w3mask_u[i][1] = (uint32_t)(m >> 32);
     }
     for (int bias = 0; bias < 32; bias++) {  // etc.rs:203-234 tabulated
-        uint16_t packed = 0;
+        uint32_t packed[2] = {0, 0};
         for (int sb = 0; sb < 2; sb++)
             for (int c = 0; c < 3; c++) {
                 int delta;
@@ -215,15 +249,41 @@ static inline void bu_build_tables(BuTables* t)
                 case 31: delta = sb ? 0 : 1; break;
                 default: delta = (bias / divs[c]) % 3 - 1; break;
                 }
-                packed |= (uint16_t)((delta + 2) << (2 * (sb * 3 + c)));
+                packed[sb] |= (uint32_t)((delta + 2) << 5) << (8 * c);
             }
-        t->etc1_bias[bias] = packed;
+        t->etc1_bias2[bias].x = packed[0];
+        t->etc1_bias2[bias].y = packed[1];
     }
     for (int d = 0; d < 2; d++)
         for (int dc = 0; dc < 4; dc++)
             for (int v = 0; v < 32; v++) {
                 const int limit = d ? 31 : 15;
-                t->etc1_biasv[(d << 7) | (dc << 5) | v] = v <= limit ? (uint8_t)bu_etc1_bias1_host(v, dc - 2, limit) : 0;
+                const int r = v <= limit ? bu_etc1_bias1_host(v, dc - 2, limit) : 0;
+                t->etc1_biasv0[(d << 7) | (dc << 5) | v] = (uint8_t)(r << 3);
+                t->etc1_biasv1[(d << 7) | (dc << 5) | v] = (uint8_t)(r << 1);
+            }
+    for (int raw = 0; raw < 256; raw++) {
+        const uint32_t f = raw & 1, d = (raw >> 1) & 1, i0 = (raw >> 2) & 7, i1 = (raw >> 5) & 7;
+        const uint32_t hdr3 = ((i0 << 5) | (i1 << 2) | (d << 1) | f) & 0xFFu;  // etc.rs:151-158
+        t->etc1_flags[raw].x = hdr3 << 24 | ((d << 3) | i1) << 16 | ((d << 3) | i0) << 8;
+        t->etc1_flags[raw].y = d ? 0x808080u : 0u;
+        t->etc1_flags[raw].z = d * 2048u;
+        t->etc1_flags[raw].w = (d ? 31u : 15u) * BU_Q_M;
+    }
+    for (int d = 0; d < 2; d++)
+        for (int c0 = 0; c0 < 32; c0++)
+            for (int c1 = 0; c1 < 32; c1++) {
+                uint32_t byte, cq1;
+                if (!d) {  // individual: 4 + 4 bits (etc.rs:122-129)
+                    byte = ((uint32_t)(c0 << 4) | (uint32_t)c1) & 0xFFu;
+                    cq1 = (uint32_t)c1;
+                } else {  // differential: 5 bits + clamped 3-bit delta; the second half decodes from c0 + delta (etc.rs:130-149)
+                    int dl = c1 - c0;
+                    dl = dl < -4 ? -4 : (dl > 3 ? 3 : dl);
+                    byte = ((uint32_t)(c0 << 3) | ((uint32_t)dl & 7u)) & 0xFFu;
+                    cq1 = (uint32_t)((c0 + dl) & 31);
+                }
+                t->etc1_hdr[(d << 10) | (c0 << 5) | c1] = (uint16_t)(byte | cq1 << 11);
             }
     for (int i = 0; i < 1024; i++) {
         int id = 0, mul = 1, okd = 1;
@@ -257,18 +317,21 @@ static inline void bu_build_tables(BuTables* t)
             const int w = bits == 1 ? r << 6 : bits == 2 ? r * 21 + (r >> 1) : bits == 3 ? r * 9 + (r >> 2) : bits == 4 ? r * 4 + (r >> 2) + (r >> 3) : r * 2 + ((r >> 4) << 1);
             t->wpack[(1 << bits) - 2 + r] = (uint32_t)w * 0x3FFFCu + 256u;
         }
-    for (int d = 0; d < 2; d++)
-        for (int inten = 0; inten < 8; inten++)
-            for (int c = 0; c < 32; c++) {
-                const int base = d ? ((c << 3) | (c >> 2)) : ((c & 15) * 17);
-                uint32_t v = 0;
-                for (int k = 0; k < 4; k++) {
-                    int x = base + BU_ETC1_MOD[inten * 4 + k];
-                    x = x < 0 ? 0 : (x > 255 ? 255 : x);
-                    v |= (uint32_t)x << (8 * k);
+    for (int ch = 0; ch < 3; ch++)
+        for (int d = 0; d < 2; d++)
+            for (int inten = 0; inten < 8; inten++)
+                for (int c = 0; c < 32; c++) {
+                    static const int lw[3] = {54, 183, 19};  // half the reference's luma weights 108, 366, 38 (etc.rs:165-177)
+                    const int base = d ? ((c << 3) | (c >> 2)) : ((c & 15) * 17);
+                    int v[4];
+                    for (int k = 0; k < 4; k++) {
+                        int x = base + BU_ETC1_MOD[inten * 4 + k];
+                        v[k] = x < 0 ? 0 : (x > 255 ? 255 : x);
+                    }
+                    BuU2& e = t->etc1_thr[ch][(d << 8) | (inten << 5) | c];
+                    e.x = 0u - (uint32_t)(lw[ch] * (v[0] + v[1]));
+                    e.y = (uint32_t)(lw[ch] * (v[2] - v[0])) | (uint32_t)(lw[ch] * (v[3] - v[1])) << 16;
                 }
-                t->etc1_thrcol[(d << 8) | (inten << 5) | c] = v;
-            }
     for (int i = 0; i < 16; i++) {
         int mn = BU_ETC2_ALPHA_MOD[8 * i + 3], mx = BU_ETC2_ALPHA_MOD[8 * i + 7];
         int range = mx - mn;

@@ -11,6 +11,20 @@
 #include "bu_uastc_front.hpp"
 
 BU_DEV int bu_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+BU_DEV uint32_t bu_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// a * b + c with a, b < 2^24 (v_mad_u32_u24)
+BU_DEV uint32_t bu_mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIPCC__)
+    return __umul24(a, b) + c;
+#else
+    return a * b + c;
+#endif
+}
+// table reads by byte offset: the kernels keep indices pre-multiplied by the entry size (a shift that never has to be issued)
+BU_DEV uint32_t bu_at_u8(const uint8_t* base, uint32_t off) { return base[off]; }
+BU_DEV uint32_t bu_at_u16(const uint16_t* base, uint32_t off) { return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(base) + off); }
+BU_DEV BuU2 bu_at_u2(const BuU2* base, uint32_t off) { return *reinterpret_cast<const BuU2*>(reinterpret_cast<const uint8_t*>(base) + off); }
 
 // etc.rs:261-275: {value, 0x1D, 0x92, 0x49, 0x24, 0x92, 0x49, 0x24}
 BU_DEV void bu_eac_solid(uint32_t out[2], uint32_t value)
@@ -19,16 +33,26 @@ BU_DEV void bu_eac_solid(uint32_t out[2], uint32_t value)
     out[1] = 0x24499224u;
 }
 
-// etc.rs:277-341
+// etc.rs:277-341; px[i] = texel i with its alpha in byte 3.
+// The reference takes, per texel, the first minimum of |value_k - a| over the table's eight values (min_by_key).  The values
+// are monotone in a fixed order of k -- 3,2,1,0,4,5,6,7, every EAC table has four falling negative and four rising positive
+// modifiers -- so the winner is a step function of a: rank = number of thresholds passed, threshold r = the point where
+// value[rank r] starts to beat value[rank r-1].  A tie goes to the smaller k, which is the HIGHER rank among the first four and
+// the LOWER rank from there on: thresholds 1..3 are ceil(mid), thresholds 4..7 floor(mid) + 1.  Clamped duplicates fall out
+// right (equal values at 0 give threshold 0 = always passed, at 255 threshold 256 = never); the only other source of equal
+// values is multiplier 0, where every texel takes k = 0.  k = 3 - t1 - t2 - t3 + 4 t4 + t5 + t6 + t7 is accumulated for two
+// texels at a time in 16-bit lanes: (a | 0x100) - T has bit 8 set exactly when a >= T (T <= 256), three 2-clock instructions
+// per threshold and texel pair instead of eight v_sad_u32 + four v_min3_u32 per texel.
 BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, const uint32_t px[16])
 {
-    uint32_t mn = 255, mx = 0;
+    uint32_t mn = px[0], mx = px[0];  // the alpha byte leads the comparison
     BU_UNROLL
-    for (int i = 0; i < 16; i++) {
-        const uint32_t a = px[i] >> 24;
-        mn = a < mn ? a : mn;
-        mx = a > mx ? a : mx;
+    for (int i = 1; i < 16; i++) {
+        mn = bu_umin(mn, px[i]);
+        mx = bu_umax(mx, px[i]);
     }
+    mn >>= 24;
+    mx >>= 24;
     if (etc2tm == 0) {
         bu_eac_solid(out, 255);
         return;
@@ -44,27 +68,67 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
     // every range is odd, so there are no .5 ties (tests/test_float_sites.py)
     const uint32_t num = (uint32_t)(2 * ((int)mn * (range + mm) - (int)mx * mm) + range);
     const int center = (int)((num * T.eac_magic[table]) >> 20);  // num <= 14791, 2*range <= 58: exact
-    // nearest of the 8 table values, first minimum wins (min_by_key): key = 8*|value - a| + index via v_sad_u32, an
-    // 8-way minimum as three v_min3_u32 + one v_min_u32.  The index is the low 3 bits of the winning key, and one
-    // v_alignbit_b32 per texel funnels exactly those 3 bits into the top of an accumulator -- texels are visited in
-    // descending column-major id, so id 0 ends up highest, as etc.rs:324-327 lays the 48-bit string out.
-    uint32_t values8[8];
+    uint32_t val[8];
     BU_UNROLL
-    for (int k = 0; k < 8; k++) values8[k] = 8u * (uint32_t)bu_clampi(center + T.etc2_amod[8 * table + k] * mult, 0, 255);
+    for (int r = 0; r < 8; r++) val[r] = (uint32_t)bu_clampi(center + T.eac_mods[8 * table + r] * mult, 0, 255);
+    uint32_t thr2[8];  // threshold in both 16-bit lanes
+    BU_UNROLL
+    for (int r = 1; r < 8; r++) thr2[r] = ((val[r - 1] + val[r] + (r < 4 ? 1u : 2u)) >> 1) * 0x10001u;
+    const uint32_t keep = mult == 0 ? 0u : 0xFFFFFFFFu;
     uint32_t acc[2] = {0, 0};  // acc[0]: ids 0..7 in bits 8..31 (id 0 on top), acc[1]: ids 8..15
     BU_UNROLL
-    for (int id = 15; id >= 0; id--) {
-        const int i = (id % 4) * 4 + id / 4;  // column-major id -> row-major texel (etc.rs:324-327)
-        const uint32_t a8 = (px[i] >> 21) & 0x7F8u;
-        const uint32_t k0 = bu_sad<0>(values8[0], a8), k1 = bu_sad<1>(values8[1], a8), k2 = bu_sad<2>(values8[2], a8), k3 = bu_sad<3>(values8[3], a8);
-        const uint32_t k4 = bu_sad<4>(values8[4], a8), k5 = bu_sad<5>(values8[5], a8), k6 = bu_sad<6>(values8[6], a8), k7 = bu_sad<7>(values8[7], a8);
-        const uint32_t best = bu_umin(bu_umin3(k0, k1, k2), bu_umin3(k6, k7, bu_umin3(k3, k4, k5)));
-        acc[id >> 3] = bu_alignbit(best, acc[id >> 3], 3);
+    for (int id = 14; id >= 0; id -= 2) {  // column-major ids id, id + 1 = texels (x, y), (x, y + 1)  (etc.rs:324-327)
+        const int i = (id % 4) * 4 + id / 4;
+        const uint32_t a2 = bu_perm(px[i + 4], px[i], 0x0C070C03u);  // alpha of id | alpha of id + 1 << 16
+        const uint32_t b1 = a2 | 0x01000100u, b4 = a2 | 0x04000400u;
+        uint32_t k = 0x03000300u;
+        BU_UNROLL
+        for (int r = 1; r < 4; r++) k -= (b1 - thr2[r]) & 0x01000100u;
+        k += (b4 - thr2[4]) & 0x04000400u;
+        BU_UNROLL
+        for (int r = 5; r < 8; r++) k += (b1 - thr2[r]) & 0x01000100u;
+        k &= keep;
+        // k = index of id << 8 | index of id + 1 << 24: six bits into the top of the accumulator, id first
+        acc[id >> 3] = bu_alignbit((k >> 5) | (k >> 24), acc[id >> 3], 6);
     }
     // bytes 2..7 of the block are the 48-bit string big-endian: acc[0] bytes 3,2,1 then acc[1] bytes 3,2,1
     out[0] = bu_perm(acc[0], (uint32_t)center | (etc2tm << 8), 0x06070100u);
     out[1] = bu_perm(acc[1], acc[0], 0x05060701u);
 }
+
+// the ETC sink: texels as R | G << 8 | B << 16 (| A << 24 when the EAC half needs alpha), and the per-quadrant channel
+// sums of etc.rs:97-111 on the way -- R and B in the 16-bit lanes of one word, G in another
+template <bool ALPHA>
+struct BuSinkEtc {
+    uint32_t* px;
+    uint32_t qrb[4], qg[4];
+    BU_DEVM void add(int i, uint32_t rb, uint32_t g)
+    {
+        const int q = ((i >> 3) << 1) | ((i >> 1) & 1);  // row >= 2, col >= 2
+        if ((i & 5) == 0) {  // first texel of its quadrant
+            qrb[q] = rb;
+            qg[q] = g;
+        } else {
+            qrb[q] += rb;
+            qg[q] += g;
+        }
+    }
+    BU_DEVM void word(int i, uint32_t w)
+    {
+        px[i] = w;
+        add(i, w & 0x00FF00FFu, (w >> 8) & 0xFFu);
+    }
+    template <int FMT>
+    BU_DEVM void raw(int i, const uint32_t v[4])
+    {
+        const uint32_t r = v[0], g = FMT == BU_FMT_LA ? v[0] : v[1], bl = FMT == BU_FMT_LA ? v[0] : v[2];
+        const uint32_t rb = bu_perm(bl, r, 0x0C060C02u), gg = g >> 16;
+        uint32_t w = rb | (gg << 8);
+        if constexpr (ALPHA) w = bu_perm(v[FMT == BU_FMT_LA ? 1 : 3], w, 0x06020100u);
+        px[i] = w;
+        add(i, rb, gg);
+    }
+};
 
 // out: ETC1 -> out[0..1]; ETC2 -> out[0..1] alpha, out[2..3] colour (etc.rs:19-30)
 template <int M, bool ETC2>
@@ -95,89 +159,82 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
         return BU_ST_OK;
     } else {
         using L = BuLayout<M>;
+        constexpr bool ALPHA = ETC2 && L::has_alpha;
         uint32_t px[16];
-        const int st = bu_block_rgba<M>(T, b, px);
+        BuSinkEtc<ALPHA> sink;
+        sink.px = px;
+        const int st = bu_block_unpack<M>(T, b, sink);
         if (st) return st;
-        const uint32_t f = bu_bits(b, L::pos_etc1f, 1), d = bu_bits(b, L::pos_etc1d, 1);
-        const uint32_t i0 = bu_bits(b, L::pos_etc1i0, 3), i1 = bu_bits(b, L::pos_etc1i1, 3);
         if constexpr (ETC2) {
             if constexpr (L::has_alpha) bu_eac_block(T, out, bu_bits(b, L::pos_etc2tm, 8), px);
             else bu_eac_solid(out, 255);  // etc2tm = 0 for RGB modes (uastc.rs:430-434)
         }
-        // quadrant sums: R and B in 16-bit lanes of one word, G separately
-        uint32_t qrb[4] = {0, 0, 0, 0}, qg[4] = {0, 0, 0, 0};
-        BU_UNROLL
-        for (int i = 0; i < 16; i++) {
-            const int q = ((i >> 3) << 1) | ((i >> 1) & 1);  // row>=2, col>=2
-            qrb[q] += px[i] & 0x00FF00FFu;
-            qg[q] += (px[i] >> 8) & 0xFFu;
-        }
-        // flip (etc1f) : halves are rows 0-1 / 2-3; otherwise columns 0-1 / 2-3 (etc.rs:86-95)
+        // the eight flag bits flip, diff, inten0, inten1 are adjacent in every mode: one table read gives all their uses
+        const uint32_t raw8 = bu_bits(b, L::pos_etc1f, 8);
+        const BuU4 fl = T.etc1_flags[raw8];
+        const bool f = (raw8 & 1u) != 0;
+        // flip (etc1f) : halves are rows 0-1 / 2-3; otherwise columns 0-1 / 2-3 (etc.rs:86-95).  The transpose is the choice
+        // of which off-diagonal quadrant joins which half.
+        const uint32_t* qrb = sink.qrb;
+        const uint32_t* qg = sink.qg;
         const uint32_t srb0 = qrb[0] + (f ? qrb[1] : qrb[2]), srb1 = qrb[3] + (f ? qrb[2] : qrb[1]);
         const uint32_t sg0 = qg[0] + (f ? qg[1] : qg[2]), sg1 = qg[3] + (f ? qg[2] : qg[1]);
-        const int limit = d ? 31 : 15;
-        int c[2][3];
-        {
-            const uint32_t sums[2][3] = {{srb0 & 0xFFFFu, sg0, srb0 >> 16}, {srb1 & 0xFFFFu, sg1, srb1 >> 16}};
+        // (sum*limit + 1020) / 2040  (etc.rs:109) as one multiply-add and a shift (BU_Q_M); the value stays in bits 26..30
+        const uint32_t sums[2][3] = {{srb0 & 0xFFFFu, sg0, srb0 >> 16}, {srb1 & 0xFFFFu, sg1, srb1 >> 16}};
+        uint32_t x[2][3];
+        BU_UNROLL
+        for (int sb = 0; sb < 2; sb++)
             BU_UNROLL
-            for (int sb = 0; sb < 2; sb++)
-                BU_UNROLL
-                for (int ch = 0; ch < 3; ch++) {
-                    // (sum*limit + 1020) / 2040  (etc.rs:109) = floor(floor(x/8)/255)
-                    const uint32_t y = (sums[sb][ch] * (uint32_t)limit + 1020u) >> 3;
-                    c[sb][ch] = (int)((y + 1u + (y >> 8)) >> 8);
-                }
-        }
+            for (int ch = 0; ch < 3; ch++) x[sb][ch] = bu_mad24(sums[sb][ch], fl.w, 1020u * BU_Q_M);
+        // e0 = 8 * (base colour of half 0), e1 = 2 * (half 1): the scalings the next two tables are indexed with
+        uint32_t e0[3], e1[3];
         if constexpr (!L::m1012) {
             // apply_etc1_bias (etc.rs:203-259): the six per-channel adjustments are one LUT read each
-            const uint32_t p5 = (uint32_t)T.etc1_bias[bu_bits(b, L::pos_etc1bias, 5)] << 5, dsel = d << 7;
+            const BuU2 bias = T.etc1_bias2[bu_bits(b, L::pos_etc1bias, 5)];
+            const uint32_t w0 = bias.x | fl.y, w1 = bias.y | fl.y;
             BU_UNROLL
-            for (int sb = 0; sb < 2; sb++)
-                BU_UNROLL
-                for (int ch = 0; ch < 3; ch++)
-                    c[sb][ch] = (int)T.etc1_biasv[((p5 >> (2 * (sb * 3 + ch))) & 0x60u) | dsel | (uint32_t)c[sb][ch]];
+            for (int ch = 0; ch < 3; ch++) {
+                e0[ch] = bu_at_u8(T.etc1_biasv0, ((w0 >> (8 * ch)) & 0xE0u) | (x[0][ch] >> 26));
+                e1[ch] = bu_at_u8(T.etc1_biasv1, ((w1 >> (8 * ch)) & 0xE0u) | (x[1][ch] >> 26));
+            }
+        } else {
+            BU_UNROLL
+            for (int ch = 0; ch < 3; ch++) {
+                e0[ch] = (x[0][ch] >> 23) & 0xF8u;
+                e1[ch] = (x[1][ch] >> 25) & 0x3Eu;
+            }
         }
-        // header bytes; cq[sb][ch] = the quantised base colour each half actually decodes with (etc.rs:113-158)
-        uint32_t cq[2][3];
-        uint32_t hdr = 0;
+        // header bytes, and the base colour the second half actually decodes with (etc.rs:113-158): etc1_hdr
+        uint32_t h[3];
         BU_UNROLL
-        for (int ch = 0; ch < 3; ch++) {
-            // individual: 4+4 bits (etc.rs:122-129); differential: 5 bits + clamped 3-bit delta, and the second half decodes
-            // from c0 + delta (etc.rs:130-149).  Branch-free: both forms are a few ALU ops, `d` only selects.
-            const int dl = bu_clampi(c[1][ch] - c[0][ch], -4, 3);
-            const uint32_t byte_i = (((uint32_t)c[0][ch] << 4) | (uint32_t)c[1][ch]) & 0xFFu;
-            const uint32_t byte_d = (((uint32_t)c[0][ch] << 3) | ((uint32_t)dl & 7u)) & 0xFFu;
-            hdr |= (d ? byte_d : byte_i) << (8 * ch);
-            cq[0][ch] = (uint32_t)c[0][ch];
-            cq[1][ch] = d ? (uint32_t)((c[0][ch] + dl) & 31) : (uint32_t)c[1][ch];
-        }
-        hdr |= (((i0 << 5) | (i1 << 2) | (d << 1) | f) & 0xFFu) << 24;  // etc.rs:151-158
-        col[0] = hdr;
+        for (int ch = 0; ch < 3; ch++) h[ch] = bu_at_u16(T.etc1_hdr, (e0[ch] << 3) + (fl.z + e1[ch]));
+        col[0] = bu_perm(h[1], h[0], 0x0C0C0400u) | bu_perm(fl.x, h[2], 0x07000C0Cu);
 
         // luma thresholds per half (etc.rs:165-177).  The factors (108, 366, 38) are all even, so every luma is even:
         // with lum = 2*L (L = 54r + 183g + 19b) the reference's test lum >= (lum_a + lum_b)/2 is exactly
-        // L >= (L_a + L_b + 1) >> 1.  The four modified base colours of a half come from one LUT read per channel (byte k =
-        // clamp(base + modifier k)); their lumas are three v_dot4_u32_u8 each with single-byte weight words.
-        constexpr uint32_t LW = 54u | (183u << 8) | (19u << 16);
-        uint32_t thr[2][3];
+        // L >= (L_a + L_b + 1) >> 1.  etc1_thr holds each channel's share of -(L0 + L1), L2 - L0 and L3 - L1 for the four
+        // modified base colours of a half.  Kept NEGATED: v_dot4_u32_u8 adds an accumulator for free, so
+        // dot4(texel, LW, -thr) = luma - thr in one instruction and bit 31 of the result is the comparison.
+        uint32_t nthr[2][3];
         BU_UNROLL
         for (int sb = 0; sb < 2; sb++) {
-            const uint32_t sel = (d << 8) | ((sb ? i1 : i0) << 5);
-            const uint32_t r4 = T.etc1_thrcol[sel | cq[sb][0]], g4 = T.etc1_thrcol[sel | cq[sb][1]], b4 = T.etc1_thrcol[sel | cq[sb][2]];
-            uint32_t lum[4];
+            const uint32_t row = sb ? (fl.x >> 8) & 0xF00u : fl.x & 0xF00u;
+            BuU2 t[3];
             BU_UNROLL
-            for (int k = 0; k < 4; k++) lum[k] = bu_udot4(b4, 19u << (8 * k), bu_udot4(g4, 183u << (8 * k), bu_udot4(r4, 54u << (8 * k), 0u)));
-            thr[sb][0] = (lum[0] + lum[1] + 1u) >> 1;
-            thr[sb][1] = (lum[1] + lum[2] + 1u) >> 1;
-            thr[sb][2] = (lum[2] + lum[3] + 1u) >> 1;
+            for (int ch = 0; ch < 3; ch++) t[ch] = bu_at_u2(T.etc1_thr[ch], row | (sb ? h[ch] >> 8 : e0[ch]));
+            const uint32_t n01 = t[0].x + t[1].x + t[2].x, dd = t[0].y + t[1].y + t[2].y;  // dd: two sums < 2^16, no carry between them
+            const uint32_t n12 = n01 - (dd & 0xFFFFu), n23 = n12 - (dd >> 16);
+            // -((S + 1) >> 1) = floor(-S / 2)
+            nthr[sb][0] = (uint32_t)((int32_t)n01 >> 1);
+            nthr[sb][1] = (uint32_t)((int32_t)n12 >> 1);
+            nthr[sb][2] = (uint32_t)((int32_t)n23 >> 1);
         }
         // the top-right and bottom-left 2x2 quadrants change half with the flip bit: pick their thresholds once.
-        // Kept NEGATED: v_dot4_u32_u8 adds an accumulator for free, so dot4(texel, LW, -thr) = luma - thr in one instruction
-        // and bit 31 of the result is the comparison (both operands < 2^31).
+        // Threshold 2 is kept as its distance from threshold 0: luma - thr2 = (luma - thr0) + (thr0 - thr2), an add instead of a dot4
         uint32_t nthq[4][3];
         BU_UNROLL
         for (int k = 0; k < 3; k++) {
-            const uint32_t n0 = 0u - thr[0][k], n1 = 0u - thr[1][k];
+            const uint32_t n0 = k == 2 ? nthr[0][2] - nthr[0][0] : nthr[0][k], n1 = k == 2 ? nthr[1][2] - nthr[1][0] : nthr[1][k];
             nthq[0][k] = n0;
             nthq[1][k] = f ? n0 : n1;  // x >= 2, y < 2
             nthq[2][k] = f ? n1 : n0;  // x < 2, y >= 2
@@ -186,13 +243,14 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
         // sel = #thresholds <= luma; ETC1 code [3,2,0,1][sel]: high bit = sel < 2 = (luma < thr1), low bit = sel == 0 or
         // sel == 3 = NOT (luma < thr0 xor luma < thr2) (the thresholds are monotone).  Texels are visited in descending
         // pixel id (x*4 + y, etc.rs:376-392) and one v_alignbit_b32 per plane shifts the sign bit in from the right.
+        constexpr uint32_t LW = 54u | (183u << 8) | (19u << 16);
         uint32_t msbp = 0, lsbx = 0;
         BU_UNROLL
         for (int pid = 15; pid >= 0; pid--) {
-            const int x = pid >> 2, y = pid & 3;
-            const int q = ((y >> 1) << 1) | (x >> 1);
-            const uint32_t t = px[y * 4 + x];
-            const uint32_t d0 = bu_udot4(t, LW, nthq[q][0]), d1 = bu_udot4(t, LW, nthq[q][1]), d2 = bu_udot4(t, LW, nthq[q][2]);
+            const int xx = pid >> 2, y = pid & 3;
+            const int q = ((y >> 1) << 1) | (xx >> 1);
+            const uint32_t t = px[y * 4 + xx];
+            const uint32_t d0 = bu_udot4(t, LW, nthq[q][0]), d1 = bu_udot4(t, LW, nthq[q][1]), d2 = d0 + nthq[q][2];
             msbp = bu_alignbit(msbp, d1, 31);       // (msbp << 1) | (luma < thr1)
             lsbx = bu_alignbit(lsbx, d0 ^ d2, 31);  // (lsbx << 1) | (lt0 ^ lt2)
         }

@@ -15,9 +15,11 @@
 
 #if defined(__HIPCC__)
 #define BU_DEV __device__ __forceinline__
+#define BU_DEVM __device__ __forceinline__  // member functions
 #define BU_UNROLL _Pragma("unroll")
 #else
 #define BU_DEV static inline __attribute__((always_inline))
+#define BU_DEVM inline __attribute__((always_inline))
 #define BU_UNROLL _Pragma("GCC unroll 32")
 #endif
 
@@ -319,16 +321,20 @@ BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Full unpack to 16 RGBA8 texels, row-major inside the block, little-endian R,G,B,A
-// (uastc.rs:237-327; color.rs:22-24).
-template <int M>
-BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
+// Texel unpack (uastc.rs:237-327; color.rs:22-24).  The interpolation leaves every channel in byte 2 of its own word; what
+// happens to those words is the caller's business (a "sink"): RGBA32 gathers them into R,G,B,A bytes, the ETC path wants
+// R and B in 16-bit lanes for its sums.  A sink provides
+//   raw<FMT>(i, v)   v[0..2] = R,G,B (FMT RGB, alpha is 255), v[0..3] = R,G,B,A (RGBA), v[0..1] = L,A (LA), value = byte 2, byte 3 = 0
+//   word(i, px)      an assembled texel R | G << 8 | B << 16 | A << 24 (mode 8 and the rotated dual-plane path)
+// with i = row-major texel index, compile-time after unrolling.
+template <int M, class SINK>
+BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
 {
     using L = BuLayout<M>;
     if constexpr (M == 8) {
         const uint32_t c = bu_bits(b, 5, 32);  // R,G,B,A bytes right after the 5-bit code (uastc.rs:387-394)
         BU_UNROLL
-        for (int i = 0; i < 16; i++) px[i] = c;
+        for (int i = 0; i < 16; i++) sink.word(i, c);
         return BU_ST_OK;
     } else {
         constexpr int wb = L::d.wb, planes = L::d.planes, subsets = L::d.subsets, fmt = L::d.fmt;
@@ -382,7 +388,7 @@ BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
                 const uint32_t v0 = bu_udot2(As[0], b0, 128u), v1 = bu_udot2(As[1], b0, 128u);
                 const uint32_t v2 = bu_udot2(As[2], b0, 128u), v3 = bu_udot2(As[3], b1, 128u);
                 const uint32_t q = bu_perm(v1, v0, 0x0C0C0602u) | bu_perm(v3, v2, 0x06020C0Cu);
-                px[i] = bu_perm(q, q, unrot);
+                sink.word(i, bu_perm(q, q, unrot));
             }
             return BU_ST_OK;
         }
@@ -394,7 +400,7 @@ BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
             const uint32_t b0 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i * planes)];
             uint32_t b1 = b0;
             if constexpr (planes == 2) b1 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i * planes + 1)];
-            uint32_t v[4];
+            uint32_t v[4] = {0, 0, 0, 0};
             BU_UNROLL
             for (int c = 0; c < NC; c++) {
                 uint32_t a = A[0][c];
@@ -409,11 +415,28 @@ BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
                 const uint32_t bw = (planes == 2 && c == 1) ? b1 : b0;
                 v[c] = bu_udot2(a, bw, 128u);  // result = byte 2
             }
-            // gather byte 2 of each channel word
-            if constexpr (fmt == BU_FMT_RGB) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | ((v[2] & 0x00FF0000u) | 0xFF000000u);
-            else if constexpr (fmt == BU_FMT_RGBA) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | (bu_perm(v[3], v[2], 0x06020C0Cu));
-            else px[i] = bu_perm(v[1], v[0], 0x06020202u);
+            sink.template raw<fmt>(i, v);
         }
         return BU_ST_OK;
     }
+}
+
+// the RGBA32 sink: 16 texels, row-major inside the block, little-endian R,G,B,A
+struct BuSinkRgba {
+    uint32_t* px;
+    BU_DEVM void word(int i, uint32_t w) { px[i] = w; }
+    template <int FMT>
+    BU_DEVM void raw(int i, const uint32_t v[4])
+    {
+        // gather byte 2 of each channel word
+        if constexpr (FMT == BU_FMT_RGB) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | ((v[2] & 0x00FF0000u) | 0xFF000000u);
+        else if constexpr (FMT == BU_FMT_RGBA) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | (bu_perm(v[3], v[2], 0x06020C0Cu));
+        else px[i] = bu_perm(v[1], v[0], 0x06020202u);
+    }
+};
+template <int M>
+BU_DEV int bu_block_rgba(const BuTables& T, const BuBlk& b, uint32_t px[16])
+{
+    BuSinkRgba sink{px};
+    return bu_block_unpack<M>(T, b, sink);
 }
