@@ -189,10 +189,13 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 #define BU_ETC_WGPCU 2
 #define BU_ETC_SKEW 40
 #endif
+#ifndef BU_ETC_MINW
+#define BU_ETC_MINW 1
+#endif
 template <int TARGET>
 struct BuBigCfg {
     static constexpr bool PREFETCH = false, DIRECT = false;
-    static constexpr int WGS = BU_ETC_WGS, BPT = BU_ETC_BPT, WG_PER_CU = BU_ETC_WGPCU, SKEW = BU_ETC_SKEW, MINW = 1;
+    static constexpr int WGS = BU_ETC_WGS, BPT = BU_ETC_BPT, WG_PER_CU = BU_ETC_WGPCU, SKEW = BU_ETC_SKEW, MINW = BU_ETC_MINW;
     static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
 template <>

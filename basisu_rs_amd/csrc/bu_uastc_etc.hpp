@@ -101,7 +101,7 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
 template <bool ALPHA>
 struct BuSinkEtc {
     uint32_t* px;
-    uint32_t qrb[4], qg[4];
+    uint32_t qrb[4], qg[4], qbb[4];  // qbb: B alone, only while the column form (cols) is summing
     BU_DEVM void add(int i, uint32_t rb, uint32_t g)
     {
         const int q = ((i >> 3) << 1) | ((i >> 1) & 1);  // row >= 2, col >= 2
@@ -127,6 +127,54 @@ struct BuSinkEtc {
         if constexpr (ALPHA) w = bu_perm(v[FMT == BU_FMT_LA ? 1 : 3], w, 0x06020100u);
         px[i] = w;
         add(i, rb, gg);
+    }
+    // a column of channel bytes: the sums of its upper and lower texel pair are one v_dot4 each, the texel words a byte transpose
+    template <int FMT>
+    BU_DEVM void cols(int x, const uint32_t ch[4])
+    {
+        const int qt = x >> 1, qb = 2 + (x >> 1);  // quadrants of rows 0-1 and rows 2-3
+        const bool first = (x & 1) == 0;
+        const uint32_t r = ch[0], g = FMT == BU_FMT_LA ? ch[0] : ch[1], bl = FMT == BU_FMT_LA ? ch[0] : ch[2], a = ch[FMT == BU_FMT_LA ? 1 : 3];
+        if constexpr (FMT == BU_FMT_LA) {
+            qg[qt] = bu_udot4(g, 0x00000101u, first ? 0u : qg[qt]);
+            qg[qb] = bu_udot4(g, 0x01010000u, first ? 0u : qg[qb]);
+            if (!first) {
+                qrb[qt] = qg[qt] * 0x10001u;
+                qrb[qb] = qg[qb] * 0x10001u;
+            }
+        } else {
+            // R in the low lane, B in the high lane: the weight word of B carries the 16-bit shift
+            qrb[qt] = bu_udot4(r, 0x00000101u, first ? 0u : qrb[qt]);
+            qrb[qb] = bu_udot4(r, 0x01010000u, first ? 0u : qrb[qb]);
+            qbb[qt] = bu_udot4(bl, 0x00000101u, first ? 0u : qbb[qt]);
+            qbb[qb] = bu_udot4(bl, 0x01010000u, first ? 0u : qbb[qb]);
+            qg[qt] = bu_udot4(g, 0x00000101u, first ? 0u : qg[qt]);
+            qg[qb] = bu_udot4(g, 0x01010000u, first ? 0u : qg[qb]);
+            if (!first) {
+                qrb[qt] |= qbb[qt] << 16;
+                qrb[qb] |= qbb[qb] << 16;
+            }
+        }
+        if constexpr (FMT == BU_FMT_LA) {
+            px[x] = bu_perm(a, r, ALPHA ? 0x04000000u : 0x0C000000u);
+            px[4 + x] = bu_perm(a, r, ALPHA ? 0x05010101u : 0x0C010101u);
+            px[8 + x] = bu_perm(a, r, ALPHA ? 0x06020202u : 0x0C020202u);
+            px[12 + x] = bu_perm(a, r, ALPHA ? 0x07030303u : 0x0C030303u);
+        } else {
+            const uint32_t t01 = bu_perm(g, r, 0x05010400u), t23 = bu_perm(g, r, 0x07030602u);  // R0 G0 R1 G1 / R2 G2 R3 G3
+            if constexpr (ALPHA) {
+                const uint32_t u01 = bu_perm(a, bl, 0x05010400u), u23 = bu_perm(a, bl, 0x07030602u);
+                px[x] = bu_perm(u01, t01, 0x05040100u);
+                px[4 + x] = bu_perm(u01, t01, 0x07060302u);
+                px[8 + x] = bu_perm(u23, t23, 0x05040100u);
+                px[12 + x] = bu_perm(u23, t23, 0x07060302u);
+            } else {
+                px[x] = bu_perm(bl, t01, 0x0C040100u);
+                px[4 + x] = bu_perm(bl, t01, 0x0C050302u);
+                px[8 + x] = bu_perm(bl, t23, 0x0C060100u);
+                px[12 + x] = bu_perm(bl, t23, 0x0C070302u);
+            }
+        }
     }
 };
 

@@ -303,7 +303,7 @@ BU_DEV uint32_t bu_alignbit(uint32_t hi, uint32_t lo, int sh)
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 #endif
 }
-// bytes of a:b selected into one word (v_perm_b32): sel byte k picks byte (sel>>8k)&7 of {b (0-3), a (4-7)}, 0x0C = zero
+// bytes of a:b selected into one word (v_perm_b32): sel byte k picks byte (sel>>8k)&7 of {b (0-3), a (4-7)}, 0x0C = zero, 0x0D.. = 0xFF
 BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 {
 #if defined(__HIPCC__)
@@ -313,12 +313,15 @@ BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
     uint32_t r = 0;
     for (int k = 0; k < 4; k++) {
         const uint32_t sk = (sel >> (8 * k)) & 0xFFu;
-        const uint32_t byte = sk < 8 ? (uint32_t)((v >> (8 * sk)) & 0xFFu) : 0u;
+        const uint32_t byte = sk < 8 ? (uint32_t)((v >> (8 * sk)) & 0xFFu) : (sk >= 0x0Du ? 0xFFu : 0u);  // 8..11 (sign fills) are not used
         r |= byte << (8 * k);
     }
     return r;
 #endif
 }
+
+// (a & m) | (b & ~m)  (v_bfi_b32)
+BU_DEV uint32_t bu_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 // ------------------------------------------------------------------------------------------------
 // Texel unpack (uastc.rs:237-327; color.rs:22-24).  The interpolation leaves every channel in byte 2 of its own word; what
@@ -326,7 +329,15 @@ BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 // R and B in 16-bit lanes for its sums.  A sink provides
 //   raw<FMT>(i, v)   v[0..2] = R,G,B (FMT RGB, alpha is 255), v[0..3] = R,G,B,A (RGBA), v[0..1] = L,A (LA), value = byte 2, byte 3 = 0
 //   word(i, px)      an assembled texel R | G << 8 | B << 16 | A << 24 (mode 8 and the rotated dual-plane path)
+//   cols<FMT>(x, ch) one block COLUMN: ch[c] = channel c (as in raw) of texels (x, 0..3) in bytes 0..3  (2-bit weights, below)
 // with i = row-major texel index, compile-time after unrolling.
+//
+// Two-bit weights, one plane (modes 1, 3, 4, 7, 9, 14, 16): a channel takes one of four values per subset, and the weights
+// of a column are already byte-aligned -- texel (x, y) sits at bits 8y + 2x of the weight word, so (W >> 2x) & 0x03030303 is
+// the column's four weights, one per byte.  That is exactly a v_perm_b32 selector: with the four values of a channel in the
+// bytes of one register (two subsets: eight values in a register pair, selector |= subset << 2) ONE instruction
+// interpolates the channel for four texels.  The palette costs two v_dot2 per channel and subset (the outer two entries are
+// the endpoints themselves); per texel this path issues about four instructions where the generic one issues nine to twenty.
 template <int M, class SINK>
 BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
 {
@@ -392,6 +403,40 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
             }
             return BU_ST_OK;
         }
+        if constexpr (wb == 2 && planes == 1) {
+            // weights 1 and 2 of LUT2 (21, 43) in the operand form of the interpolation; weights 0 and 3 return the endpoints
+            constexpr uint32_t BW1 = 21u * 0x3FFFCu + 256u, BW2 = 43u * 0x3FFFCu + 256u;
+            uint32_t pal[3][4];
+            BU_UNROLL
+            for (int s = 0; s < subsets; s++) {
+                BU_UNROLL
+                for (int c = 0; c < NC; c++) {
+                    const uint32_t lo = e[(2 * L::channels) * s + 2 * c], hi = e[(2 * L::channels) * s + 2 * c + 1];
+                    const uint32_t v1 = bu_udot2(A[s][c], BW1, 128u), v2 = bu_udot2(A[s][c], BW2, 128u);
+                    pal[s][c] = bu_perm(v2, v1, 0x0C06020Cu) | lo | (hi << 24);
+                }
+            }
+            BU_UNROLL
+            for (int x = 0; x < 4; x++) {
+                const uint32_t wsel = (W[0] >> (2 * x)) & 0x03030303u;
+                uint32_t ch[4] = {0, 0, 0, 0};
+                if constexpr (subsets == 1) {
+                    BU_UNROLL
+                    for (int c = 0; c < NC; c++) ch[c] = bu_perm(0u, pal[0][c], wsel);
+                } else if constexpr (subsets == 2) {
+                    const uint32_t sel = wsel | (((upat >> (2 * x)) & 0x01010101u) << 2);
+                    BU_UNROLL
+                    for (int c = 0; c < NC; c++) ch[c] = bu_perm(pal[1][c], pal[0][c], sel);
+                } else {
+                    const uint32_t sid = (upat >> (2 * x)) & 0x03030303u;
+                    const uint32_t sel = wsel | ((sid & 0x01010101u) << 2), is2 = ((sid >> 1) & 0x01010101u) * 255u;
+                    BU_UNROLL
+                    for (int c = 0; c < NC; c++) ch[c] = bu_bfi(is2, bu_perm(0u, pal[2][c], wsel), bu_perm(pal[1][c], pal[0][c], sel));
+                }
+                sink.template cols<fmt>(x, ch);
+            }
+            return BU_ST_OK;
+        }
         BU_UNROLL
         for (int i = 0; i < 16; i++) {
             uint32_t sid = 0;
@@ -432,6 +477,31 @@ struct BuSinkRgba {
         if constexpr (FMT == BU_FMT_RGB) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | ((v[2] & 0x00FF0000u) | 0xFF000000u);
         else if constexpr (FMT == BU_FMT_RGBA) px[i] = bu_perm(v[1], v[0], 0x0C0C0602u) | (bu_perm(v[3], v[2], 0x06020C0Cu));
         else px[i] = bu_perm(v[1], v[0], 0x06020202u);
+    }
+    // a column of channel bytes -> four texel words (a 4x4 byte transpose, two v_perm levels)
+    template <int FMT>
+    BU_DEVM void cols(int x, const uint32_t ch[4])
+    {
+        if constexpr (FMT == BU_FMT_LA) {
+            px[x] = bu_perm(ch[1], ch[0], 0x04000000u);
+            px[4 + x] = bu_perm(ch[1], ch[0], 0x05010101u);
+            px[8 + x] = bu_perm(ch[1], ch[0], 0x06020202u);
+            px[12 + x] = bu_perm(ch[1], ch[0], 0x07030303u);
+        } else {
+            const uint32_t t01 = bu_perm(ch[1], ch[0], 0x05010400u), t23 = bu_perm(ch[1], ch[0], 0x07030602u);  // R0 G0 R1 G1 / R2 G2 R3 G3
+            if constexpr (FMT == BU_FMT_RGB) {
+                px[x] = bu_perm(ch[2], t01, 0x0D040100u);  // R G B 255
+                px[4 + x] = bu_perm(ch[2], t01, 0x0D050302u);
+                px[8 + x] = bu_perm(ch[2], t23, 0x0D060100u);
+                px[12 + x] = bu_perm(ch[2], t23, 0x0D070302u);
+            } else {
+                const uint32_t u01 = bu_perm(ch[3], ch[2], 0x05010400u), u23 = bu_perm(ch[3], ch[2], 0x07030602u);  // B0 A0 B1 A1 / ...
+                px[x] = bu_perm(u01, t01, 0x05040100u);
+                px[4 + x] = bu_perm(u01, t01, 0x07060302u);
+                px[8 + x] = bu_perm(u23, t23, 0x05040100u);
+                px[12 + x] = bu_perm(u23, t23, 0x07060302u);
+            }
+        }
     }
 };
 template <int M>
