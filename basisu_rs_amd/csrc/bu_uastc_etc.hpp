@@ -113,11 +113,7 @@ struct BuSinkEtc {
             qg[q] += g;
         }
     }
-    BU_DEVM void word(int i, uint32_t w)
-    {
-        px[i] = w;
-        add(i, w & 0x00FF00FFu, (w >> 8) & 0xFFu);
-    }
+    BU_DEVM void word(int, uint32_t) {}  // mode 8 never comes through here (bu_block_etc)
     template <int FMT>
     BU_DEVM void raw(int i, const uint32_t v[4])
     {

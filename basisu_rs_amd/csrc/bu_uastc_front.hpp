@@ -328,11 +328,11 @@ BU_DEV uint32_t bu_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b
 // happens to those words is the caller's business (a "sink"): RGBA32 gathers them into R,G,B,A bytes, the ETC path wants
 // R and B in 16-bit lanes for its sums.  A sink provides
 //   raw<FMT>(i, v)   v[0..2] = R,G,B (FMT RGB, alpha is 255), v[0..3] = R,G,B,A (RGBA), v[0..1] = L,A (LA), value = byte 2, byte 3 = 0
-//   word(i, px)      an assembled texel R | G << 8 | B << 16 | A << 24 (mode 8 and the rotated dual-plane path)
+//   word(i, px)      an assembled texel R | G << 8 | B << 16 | A << 24 (mode 8)
 //   cols<FMT>(x, ch) one block COLUMN: ch[c] = channel c (as in raw) of texels (x, 0..3) in bytes 0..3  (2-bit weights, below)
 // with i = row-major texel index, compile-time after unrolling.
 //
-// Two-bit weights, one plane (modes 1, 3, 4, 7, 9, 14, 16): a channel takes one of four values per subset, and the weights
+// Two-bit weights (modes 1, 3, 4, 7, 9, 14, 16; with two planes 6, 11, 17, and 13 with one-bit weights): a channel takes one of four values per subset, and the weights
 // of a column are already byte-aligned -- texel (x, y) sits at bits 8y + 2x of the weight word, so (W >> 2x) & 0x03030303 is
 // the column's four weights, one per byte.  That is exactly a v_perm_b32 selector: with the four values of a channel in the
 // bytes of one register (two subsets: eight values in a register pair, selector |= subset << 2) ONE instruction
@@ -382,27 +382,46 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                 X2[c] = A[0][c] ^ A[2][c];
             }
         }
-        if constexpr (planes == 2 && fmt != BU_FMT_LA) {
-            // Dual plane, runtime component selector (uastc.rs:293-296).  Rotate the compsel channel into
-            // slot 3 once per block, interpolate slot 3 with the plane-1 weight, and undo the rotation with
-            // one byte permute per texel -- instead of one select per channel per texel.
-            const uint32_t a3 = NC == 4 ? A[0][3] : 0xFFFFFFFFu;  // RGB: alpha is the constant 255
-            uint32_t As[4];
+        if constexpr (planes == 2 && wb <= 2) {
+            // Dual plane with 1- or 2-bit weights (modes 6, 11, 13, 17): the palette form again.  The two planes' weights
+            // interleave (texel i, plane p = field 2i + p), so a column's selector is two masked shifts and -- for 2-bit
+            // weights, where a block row is 16 bits -- a v_perm that brings rows 0..3 back into byte order.  The channel
+            // named by compsel reads the plane-1 selector (uastc.rs:293-296); LA always interpolates alpha on plane 1.
+            constexpr uint32_t BW1 = 21u * 0x3FFFCu + 256u, BW2 = 43u * 0x3FFFCu + 256u;
+            uint32_t pal[4];
             BU_UNROLL
-            for (int c = 0; c < 3; c++) As[c] = compsel == (uint32_t)c ? a3 : A[0][c];
-            As[3] = compsel == 0 ? A[0][0] : compsel == 1 ? A[0][1] : compsel == 2 ? A[0][2] : a3;
-            const uint32_t unrot = compsel == 0 ? 0x00020103u : compsel == 1 ? 0x01020300u : compsel == 2 ? 0x02030100u : 0x03020100u;
+            for (int c = 0; c < NC; c++) {
+                const uint32_t lo = e[2 * c], hi = e[2 * c + 1];
+                if constexpr (wb == 1) {
+                    pal[c] = lo | (hi << 8);
+                } else {
+                    const uint32_t v1 = bu_udot2(A[0][c], BW1, 128u), v2 = bu_udot2(A[0][c], BW2, 128u);
+                    pal[c] = bu_perm(v2, v1, 0x0C06020Cu) | lo | (hi << 24);
+                }
+            }
             BU_UNROLL
-            for (int i = 0; i < 16; i++) {
-                const uint32_t b0 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, 2 * i)];
-                const uint32_t b1 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, 2 * i + 1)];
-                const uint32_t v0 = bu_udot2(As[0], b0, 128u), v1 = bu_udot2(As[1], b0, 128u);
-                const uint32_t v2 = bu_udot2(As[2], b0, 128u), v3 = bu_udot2(As[3], b1, 128u);
-                const uint32_t q = bu_perm(v1, v0, 0x0C0C0602u) | bu_perm(v3, v2, 0x06020C0Cu);
-                sink.word(i, bu_perm(q, q, unrot));
+            for (int x = 0; x < 4; x++) {
+                uint32_t sel[2];
+                BU_UNROLL
+                for (int p2 = 0; p2 < 2; p2++) {
+                    if constexpr (wb == 1) {
+                        sel[p2] = (W[0] >> (2 * x + p2)) & 0x01010101u;
+                    } else {
+                        const uint32_t t0 = (W[0] >> (4 * x + 2 * p2)) & 0x00030003u, t1 = (W[1] >> (4 * x + 2 * p2)) & 0x00030003u;  // rows 0,1 / 2,3 in bytes 0 and 2
+                        sel[p2] = bu_perm(t1, t0, 0x06040200u);
+                    }
+                }
+                uint32_t ch[4] = {0, 0, 0, 0};
+                BU_UNROLL
+                for (int c = 0; c < NC; c++) {
+                    const uint32_t sc = fmt == BU_FMT_LA ? sel[c] : (compsel == (uint32_t)c ? sel[1] : sel[0]);
+                    ch[c] = bu_perm(0u, pal[c], sc);
+                }
+                sink.template cols<fmt>(x, ch);
             }
             return BU_ST_OK;
         }
+        // (every dual-plane mode has 1- or 2-bit weights: from here on there is one plane)
         if constexpr (wb == 2 && planes == 1) {
             // weights 1 and 2 of LUT2 (21, 43) in the operand form of the interpolation; weights 0 and 3 return the endpoints
             constexpr uint32_t BW1 = 21u * 0x3FFFCu + 256u, BW2 = 43u * 0x3FFFCu + 256u;
@@ -442,9 +461,7 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
             uint32_t sid = 0;
             if constexpr (subsets > 1) sid = (upat >> (2 * i)) & 3u;
             // weights x4, packed (256-4w) | 4w << 16: one LUT read per weight (dequantisation and packing folded in)
-            const uint32_t b0 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i * planes)];
-            uint32_t b1 = b0;
-            if constexpr (planes == 2) b1 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i * planes + 1)];
+            const uint32_t b0 = T.wpack[(1 << wb) - 2 + bu_wfield<wb>(W, i)];
             uint32_t v[4] = {0, 0, 0, 0};
             BU_UNROLL
             for (int c = 0; c < NC; c++) {
@@ -456,9 +473,7 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                     const uint32_t k1 = 0u - (sid & 1u), k2 = 0u - (sid >> 1);
                     a ^= (X1[c] & k1) ^ (X2[c] & k2);
                 }
-                // LA dual plane (mode 17): the second interpolation is alpha, compsel fixed to A
-                const uint32_t bw = (planes == 2 && c == 1) ? b1 : b0;
-                v[c] = bu_udot2(a, bw, 128u);  // result = byte 2
+                v[c] = bu_udot2(a, b0, 128u);  // result = byte 2
             }
             sink.template raw<fmt>(i, v);
         }
