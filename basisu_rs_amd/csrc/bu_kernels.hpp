@@ -178,25 +178,22 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 // chunk loop cost ~30 VGPRs.  BC7 then needs 62 instead of 93, which allows 32 waves per CU:
 //   1024 x 2 (2048), two per CU (32 waves)                                    11.6
 //   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
-// ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp); ETC1/ETC2 (81)
-// do not reach 8 waves per SIMD and keep 512 x 4, two per CU.
-// ETC1 / ETC2 (72-78 VGPRs): 2048-block tiles, two workgroups per CU.  Tried in round 2 (tools/exp/ab.sh): 1024-block
-// tiles with three workgroups per CU 25.7 us, with four (64 VGPRs, 7 spilled) 27.4, against 24.9 -- the ALUs are saturated
-// at 16 waves per CU, more waves only add sort overhead.
-#ifndef BU_ETC_WGS
-#define BU_ETC_WGS 512
-#define BU_ETC_BPT 4
-#define BU_ETC_WGPCU 2
-#define BU_ETC_SKEW 40
-#endif
-#ifndef BU_ETC_MINW
-#define BU_ETC_MINW 1
-#endif
+// ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp).
+// ETC1 / ETC2 (76-93 VGPRs, 27 KiB of tables per workgroup): 2048-block tiles, two 512-thread workgroups per CU.  A/B in one run
+// (tools/exp/ab.sh), round 2 with the leaner block code: ETC1 512x4 two per CU 19.98 us, without the start skew 19.85,
+// 1024x4 one per CU 19.45 (fewer half-empty chunks: 73 per 4096 blocks against 83), 1024-block tiles three per CU 22.3;
+// ETC2 25.04 / 24.92 / 25.07 / 28.3.  More waves do not help: 1024x2 two per CU (64 VGPRs, 6 / 45 spilled) 23.0 / 36.2.
 template <int TARGET>
 struct BuBigCfg {
     static constexpr bool PREFETCH = false, DIRECT = false;
-    static constexpr int WGS = BU_ETC_WGS, BPT = BU_ETC_BPT, WG_PER_CU = BU_ETC_WGPCU, SKEW = BU_ETC_SKEW, MINW = BU_ETC_MINW;
+    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
+};
+template <>
+struct BuBigCfg<BU_TGT_ETC1> {
+    static constexpr bool PREFETCH = false, DIRECT = false;
+    static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1;
+    static constexpr bool ALL_SIZES = false;
 };
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
