@@ -43,7 +43,11 @@ BU_DEV void bu_eac_solid(uint32_t out[2], uint32_t value)
 // values is multiplier 0, where every texel takes k = 0.  k = 3 - t1 - t2 - t3 + 4 t4 + t5 + t6 + t7 is accumulated for two
 // texels at a time in 16-bit lanes: (a | 0x100) - T has bit 8 set exactly when a >= T (T <= 256), three 2-clock instructions
 // per threshold and texel pair instead of eight v_sad_u32 + four v_min3_u32 per texel.
-BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, const uint32_t px[16])
+// PAL = 0: every texel goes through the threshold count.  PAL = 4 / 8: the block's alphas come from a palette of that many
+// byte entries (the 2-bit-weight modes, bu_block_unpack): the count runs over the palette, and a texel column picks its
+// indices up with the same v_perm selector `asel[x]` that interpolated its alpha.
+template <int PAL>
+BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, const uint32_t px[16], const uint32_t apal[2], const uint32_t asel[4])
 {
     uint32_t mn = px[0], mx = px[0];  // the alpha byte leads the comparison
     BU_UNROLL
@@ -75,11 +79,8 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
     BU_UNROLL
     for (int r = 1; r < 8; r++) thr2[r] = ((val[r - 1] + val[r] + (r < 4 ? 1u : 2u)) >> 1) * 0x10001u;
     const uint32_t keep = mult == 0 ? 0u : 0xFFFFFFFFu;
-    uint32_t acc[2] = {0, 0};  // acc[0]: ids 0..7 in bits 8..31 (id 0 on top), acc[1]: ids 8..15
-    BU_UNROLL
-    for (int id = 14; id >= 0; id -= 2) {  // column-major ids id, id + 1 = texels (x, y), (x, y + 1)  (etc.rs:324-327)
-        const int i = (id % 4) * 4 + id / 4;
-        const uint32_t a2 = bu_perm(px[i + 4], px[i], 0x0C070C03u);  // alpha of id | alpha of id + 1 << 16
+    // a2 = two alphas in 16-bit lanes -> index of the first << 8 | index of the second << 24
+    auto count = [&](uint32_t a2) {
         const uint32_t b1 = a2 | 0x01000100u, b4 = a2 | 0x04000400u;
         uint32_t k = 0x03000300u;
         BU_UNROLL
@@ -87,9 +88,33 @@ BU_DEV void bu_eac_block(const BuTables& T, uint32_t out[2], uint32_t etc2tm, co
         k += (b4 - thr2[4]) & 0x04000400u;
         BU_UNROLL
         for (int r = 5; r < 8; r++) k += (b1 - thr2[r]) & 0x01000100u;
-        k &= keep;
-        // k = index of id << 8 | index of id + 1 << 24: six bits into the top of the accumulator, id first
-        acc[id >> 3] = bu_alignbit((k >> 5) | (k >> 24), acc[id >> 3], 6);
+        return k & keep;
+    };
+    uint32_t acc[2] = {0, 0};  // acc[0]: ids 0..7 in bits 8..31 (id 0 on top), acc[1]: ids 8..15
+    if constexpr (PAL == 0) {
+        BU_UNROLL
+        for (int id = 14; id >= 0; id -= 2) {  // column-major ids id, id + 1 = texels (x, y), (x, y + 1)  (etc.rs:324-327)
+            const int i = (id % 4) * 4 + id / 4;
+            const uint32_t k = count(bu_perm(px[i + 4], px[i], 0x0C070C03u));  // alpha of id | alpha of id + 1 << 16
+            // six bits into the top of the accumulator, id first
+            acc[id >> 3] = bu_alignbit((k >> 5) | (k >> 24), acc[id >> 3], 6);
+        }
+    } else {
+        uint32_t ipal[2] = {0, 0};  // the index of every palette entry, one per byte
+        BU_UNROLL
+        for (int h = 0; h < PAL / 4; h++) {
+            const uint32_t k01 = count(bu_perm(0u, apal[h], 0x0C010C00u)), k23 = count(bu_perm(0u, apal[h], 0x0C030C02u));
+            ipal[h] = bu_perm(k23, k01, 0x07050301u);
+        }
+        uint32_t c12[4];  // a column's four indices as 12 bits, row 0 on top (ids 4x .. 4x + 3)
+        BU_UNROLL
+        for (int x = 0; x < 4; x++) {
+            const uint32_t ix = bu_perm(ipal[1], ipal[0], asel[x]);
+            const uint32_t q = (ix << 3) | (ix >> 8);  // bits 0..5: row 0, row 1; bits 16..21: row 2, row 3
+            c12[x] = ((q & 0x3Fu) << 6) | ((q >> 16) & 0x3Fu);
+        }
+        acc[0] = (c12[0] << 20) | (c12[1] << 8);
+        acc[1] = (c12[2] << 20) | (c12[3] << 8);
     }
     // bytes 2..7 of the block are the 48-bit string big-endian: acc[0] bytes 3,2,1 then acc[1] bytes 3,2,1
     out[0] = bu_perm(acc[0], (uint32_t)center | (etc2tm << 8), 0x06070100u);
@@ -102,6 +127,12 @@ template <bool ALPHA>
 struct BuSinkEtc {
     uint32_t* px;
     uint32_t qrb[4], qg[4], qbb[4];  // qbb: B alone, only while the column form (cols) is summing
+    uint32_t apal[2], asel[4];       // ALPHA: the alpha palette and the columns' selectors into it (bu_eac_block)
+    BU_DEVM void alpha_palette(uint32_t lo, uint32_t hi)
+    {
+        apal[0] = lo;
+        apal[1] = hi;
+    }
     BU_DEVM void add(int i, uint32_t rb, uint32_t g)
     {
         const int q = ((i >> 3) << 1) | ((i >> 1) & 1);  // row >= 2, col >= 2
@@ -126,8 +157,9 @@ struct BuSinkEtc {
     }
     // a column of channel bytes: the sums of its upper and lower texel pair are one v_dot4 each, the texel words a byte transpose
     template <int FMT>
-    BU_DEVM void cols(int x, const uint32_t ch[4])
+    BU_DEVM void cols(int x, const uint32_t ch[4], uint32_t alpha_sel)
     {
+        if constexpr (ALPHA) asel[x] = alpha_sel;
         const int qt = x >> 1, qb = 2 + (x >> 1);  // quadrants of rows 0-1 and rows 2-3
         const bool first = (x & 1) == 0;
         const uint32_t r = ch[0], g = FMT == BU_FMT_LA ? ch[0] : ch[1], bl = FMT == BU_FMT_LA ? ch[0] : ch[2], a = ch[FMT == BU_FMT_LA ? 1 : 3];
@@ -210,7 +242,7 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
         const int st = bu_block_unpack<M>(T, b, sink);
         if (st) return st;
         if constexpr (ETC2) {
-            if constexpr (L::has_alpha) bu_eac_block(T, out, bu_bits(b, L::pos_etc2tm, 8), px);
+            if constexpr (L::has_alpha) bu_eac_block<L::alpha_palette>(T, out, bu_bits(b, L::pos_etc2tm, 8), px, sink.apal, sink.asel);
             else bu_eac_solid(out, 255);  // etc2tm = 0 for RGB modes (uastc.rs:430-434)
         }
         // the eight flag bits flip, diff, inten0, inten1 are adjacent in every mode: one table read gives all their uses

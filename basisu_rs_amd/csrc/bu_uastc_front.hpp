@@ -124,6 +124,8 @@ struct BuLayout {
     static constexpr int w_raw = w_total - n_anch;
     static constexpr int w_words = (w_total + 31) / 32;
     static_assert(M == 8 || pos_w + w_raw <= 128, "mode does not fit in 128 bits");
+    // texel unpack through byte palettes (bu_block_unpack): entries of the alpha palette, 0 = the mode takes the generic path
+    static constexpr int alpha_palette = (M != 8 && has_alpha && d.wb <= 2 && (d.planes == 2 || d.wb == 2)) ? (d.subsets == 2 ? 8 : 4) : 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -329,7 +331,8 @@ BU_DEV uint32_t bu_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b
 // R and B in 16-bit lanes for its sums.  A sink provides
 //   raw<FMT>(i, v)   v[0..2] = R,G,B (FMT RGB, alpha is 255), v[0..3] = R,G,B,A (RGBA), v[0..1] = L,A (LA), value = byte 2, byte 3 = 0
 //   word(i, px)      an assembled texel R | G << 8 | B << 16 | A << 24 (mode 8)
-//   cols<FMT>(x, ch) one block COLUMN: ch[c] = channel c (as in raw) of texels (x, 0..3) in bytes 0..3  (2-bit weights, below)
+//   cols<FMT>(x, ch, asel)  one block COLUMN: ch[c] = channel c (as in raw) of texels (x, 0..3) in bytes 0..3; asel = the v_perm
+//                    selector that read the alpha channel out of alpha_palette(lo, hi)  (2-bit weights, below)
 // with i = row-major texel index, compile-time after unrolling.
 //
 // Two-bit weights (modes 1, 3, 4, 7, 9, 14, 16; with two planes 6, 11, 17, and 13 with one-bit weights): a channel takes one of four values per subset, and the weights
@@ -399,6 +402,7 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                     pal[c] = bu_perm(v2, v1, 0x0C06020Cu) | lo | (hi << 24);
                 }
             }
+            if constexpr (L::has_alpha) sink.alpha_palette(pal[NC - 1], 0u);
             BU_UNROLL
             for (int x = 0; x < 4; x++) {
                 uint32_t sel[2];
@@ -411,13 +415,13 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                         sel[p2] = bu_perm(t1, t0, 0x06040200u);
                     }
                 }
-                uint32_t ch[4] = {0, 0, 0, 0};
+                uint32_t ch[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0};
                 BU_UNROLL
                 for (int c = 0; c < NC; c++) {
-                    const uint32_t sc = fmt == BU_FMT_LA ? sel[c] : (compsel == (uint32_t)c ? sel[1] : sel[0]);
-                    ch[c] = bu_perm(0u, pal[c], sc);
+                    sc[c] = fmt == BU_FMT_LA ? sel[c] : (compsel == (uint32_t)c ? sel[1] : sel[0]);
+                    ch[c] = bu_perm(0u, pal[c], sc[c]);
                 }
-                sink.template cols<fmt>(x, ch);
+                sink.template cols<fmt>(x, ch, sc[NC - 1]);
             }
             return BU_ST_OK;
         }
@@ -435,15 +439,17 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                     pal[s][c] = bu_perm(v2, v1, 0x0C06020Cu) | lo | (hi << 24);
                 }
             }
+            if constexpr (L::has_alpha) sink.alpha_palette(pal[0][NC - 1], subsets == 2 ? pal[1][NC - 1] : 0u);
             BU_UNROLL
             for (int x = 0; x < 4; x++) {
                 const uint32_t wsel = (W[0] >> (2 * x)) & 0x03030303u;
-                uint32_t ch[4] = {0, 0, 0, 0};
+                uint32_t ch[4] = {0, 0, 0, 0}, asel = wsel;
                 if constexpr (subsets == 1) {
                     BU_UNROLL
                     for (int c = 0; c < NC; c++) ch[c] = bu_perm(0u, pal[0][c], wsel);
                 } else if constexpr (subsets == 2) {
                     const uint32_t sel = wsel | (((upat >> (2 * x)) & 0x01010101u) << 2);
+                    asel = sel;
                     BU_UNROLL
                     for (int c = 0; c < NC; c++) ch[c] = bu_perm(pal[1][c], pal[0][c], sel);
                 } else {
@@ -452,7 +458,7 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                     BU_UNROLL
                     for (int c = 0; c < NC; c++) ch[c] = bu_bfi(is2, bu_perm(0u, pal[2][c], wsel), bu_perm(pal[1][c], pal[0][c], sel));
                 }
-                sink.template cols<fmt>(x, ch);
+                sink.template cols<fmt>(x, ch, asel);
             }
             return BU_ST_OK;
         }
@@ -494,8 +500,9 @@ struct BuSinkRgba {
         else px[i] = bu_perm(v[1], v[0], 0x06020202u);
     }
     // a column of channel bytes -> four texel words (a 4x4 byte transpose, two v_perm levels)
+    BU_DEVM void alpha_palette(uint32_t, uint32_t) {}
     template <int FMT>
-    BU_DEVM void cols(int x, const uint32_t ch[4])
+    BU_DEVM void cols(int x, const uint32_t ch[4], uint32_t)
     {
         if constexpr (FMT == BU_FMT_LA) {
             px[x] = bu_perm(ch[1], ch[0], 0x04000000u);
