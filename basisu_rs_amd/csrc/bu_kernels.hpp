@@ -281,7 +281,27 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         const unsigned idx = tile * BU_TILE + j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
-    bu_stage_tables_n<WGS, TARGET>(T, tables);
+    // Table staging in two steps.  The sort phases read only key_lut (128 B): that goes to LDS now.  Everything else is first
+    // read in the chunk phase; its loads are issued here, behind the block loads, and stay in registers until the first tile's
+    // rank atomics are out -- the copy (26.6 KiB per workgroup for ETC) leaves the path to the first sorted tile.
+    // Only where the copy is big (ETC: A/B ETC1 19.45 -> 19.0 us); with the 6-8 KiB of BC7 / ASTC the registers it holds through
+    // the rank phase cost more than the copy (BC7 10.13 -> 10.25), those stage everything up front.
+    constexpr BuTableRange TR = bu_table_range(TARGET);
+    constexpr bool SPLIT = bu_table_bytes(TARGET) > 16384;
+    constexpr int TV1 = (int)(TR.hi - TR.lo) / 16, TV2 = TR.lo2 < TR.hi2 ? (int)(TR.hi2 - TR.lo2) / 16 : 0, TVN = SPLIT ? (TV1 + TV2 + WGS - 1) / WGS : 1;
+    uint4 tv[TVN];
+    if constexpr (!SPLIT) bu_stage_tables_n<WGS, TARGET>(T, tables);
+    else {
+#pragma unroll
+    for (int k = 0; k < TVN; k++) {
+        const int i = k * WGS + (int)tid;
+        const int src = i < TV1 ? (int)(TR.lo / 16) + i : (int)(TR.lo2 / 16) + (i - TV1);
+        tv[k] = i < TV1 + TV2 ? reinterpret_cast<const uint4*>(tables)[src] : make_uint4(0, 0, 0, 0);
+    }
+    static_assert(offsetof(BuTables, key_lut) % 4 == 0 && sizeof(T.key_lut) == 128, "key_lut is staged as 32 dwords");
+    if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut)[tid] = reinterpret_cast<const uint32_t*>(tables->key_lut)[tid];
+    }
+    bool tables_staged = !SPLIT;
     if (tid < 64) (&cnt[0][0])[tid] = 0;
     if (tid < 2) next_chunk[tid] = 0;
     __syncthreads();
@@ -313,8 +333,17 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) pos[j] = atomicAdd(&cnt[par][key[j]], 1u);  // lanes past the end hit the dummy counter 31: no exec-mask region, the atomics issue back to back
         }
+        if (!tables_staged) {  // (key_lut is rewritten with the bytes it already holds)
+#pragma unroll
+            for (int k = 0; k < TVN; k++) {
+                const int i = k * WGS + (int)tid;
+                const int dst = i < TV1 ? (int)(TR.lo / 16) + i : (int)(TR.lo2 / 16) + (i - TV1);
+                if (i < TV1 + TV2) reinterpret_cast<uint4*>(&T)[dst] = tv[k];
+            }
+            tables_staged = true;
+        }
         BU_STAMP(2)
-        __syncthreads();  // (1) every rank is final
+        __syncthreads();  // (1) every rank is final; the tables are in LDS
         BU_STAMP(3)
         // ---- B: run starts and the chunk map, derived by EVERY wave for itself ----
         // Lane k < 20 holds run k: blocks in the low half, 64-block chunks in the high half of one word; a DPP scan gives

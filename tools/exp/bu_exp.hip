@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BU_WG) void bu_exp_kernel(const uint4* __restrict__
         const size_t idx = tile * BU_TILE + (size_t)j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
     }
-    if (V != 3) bu_stage_tables(T, tables);
+    if (V != 3) bu_stage_tables_n<BU_WG, BU_TGT_BC7>(T, tables);
     if (tid < 32) cnt[tid] = 0;
     __syncthreads();
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -172,6 +172,16 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
         case 21: {
             const size_t t_ = (n_blocks + 2047) / 2048;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 4, 1, false, false, 40>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+        } break;
+        case 40: {  // the shipped ETC1 shape
+            const size_t t_ = (n_blocks + 4095) / 4096;
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC1, 1024, 4, 1, false, false, 0>), dim3((unsigned)t_), dim3(1024), 0, s, in, d_out[k],
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+        } break;
+        case 41: {  // the shipped ETC2 shape
+            const size_t t_ = (n_blocks + 2047) / 2048;
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC2, 512, 4, 1, false, false, 0>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
                                (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
         } break;
 #undef SV
