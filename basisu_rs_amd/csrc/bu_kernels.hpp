@@ -179,21 +179,16 @@ constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
 //   1024 x 2 (2048), two per CU (32 waves)                                    11.6
 //   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
 // ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp).
-// ETC1 / ETC2 (76-93 VGPRs, 27 KiB of tables per workgroup): 2048-block tiles, two 512-thread workgroups per CU.  A/B in one run
-// (tools/exp/ab.sh), round 2 with the leaner block code: ETC1 512x4 two per CU 19.98 us, without the start skew 19.85,
-// 1024x4 one per CU 19.45 (fewer half-empty chunks: 73 per 4096 blocks against 83), 1024-block tiles three per CU 22.3;
-// ETC2 25.04 / 24.92 / 25.07 / 28.3.  More waves do not help: 1024x2 two per CU (64 VGPRs, 6 / 45 spilled) 23.0 / 36.2.
+// ETC1 / ETC2 (84 / 106 VGPRs, 27 KiB of tables per workgroup): ONE 1024-thread workgroup per CU on a 4096-block tile -- 73
+// chunks per 4096 blocks where two 2048-block tiles have 83.  A/B in one run (tools/exp/ab.sh), round 2 with the leaner
+// block code: ETC1 512x4 two per CU 19.98 us, without the start skew 19.85, 1024x4 one per CU 19.45, 1024-block tiles
+// three per CU 22.3; ETC2 25.04 / 24.92 / 25.07 / 28.3, and with the table copy behind the first rank phase 23.79 (512x4)
+// against 23.45 (1024x4).  More waves do not help: 1024x2 two per CU (64 VGPRs, 6 / 45 spilled) 23.0 / 36.2.
 template <int TARGET>
 struct BuBigCfg {
     static constexpr bool PREFETCH = false, DIRECT = false;
-    static constexpr int WGS = 512, BPT = 4, WG_PER_CU = 2, SKEW = 0, MINW = 1;
-    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
-};
-template <>
-struct BuBigCfg<BU_TGT_ETC1> {
-    static constexpr bool PREFETCH = false, DIRECT = false;
     static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1;
-    static constexpr bool ALL_SIZES = false;
+    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
 };
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
