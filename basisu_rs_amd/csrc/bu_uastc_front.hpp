@@ -247,17 +247,6 @@ BU_DEV uint32_t bu_wfield(const uint32_t W[3], int k)
     return v & ((1u << WB) - 1u);
 }
 
-// uastc.rs:697-719 as arithmetic (LUT1..LUT5 are reproduced exactly by these forms)
-template <int WB>
-BU_DEV uint32_t bu_wdeq(uint32_t r)
-{
-    if constexpr (WB == 1) return r << 6;
-    else if constexpr (WB == 2) return r * 21u + (r >> 1);
-    else if constexpr (WB == 3) return r * 9u + (r >> 2);
-    else if constexpr (WB == 4) return r * 4u + (r >> 2) + (r >> 3);
-    else return r * 2u + ((r >> 4) << 1);
-}
-
 // uastc.rs:218-235 as one dot product.  With lo16 = l*257, hi16 = h*257 packed in a word and the
 // weights scaled by 4, ((lo16*(64-w) + hi16*w + 32) >> 6) >> 8 is byte 2 of
 //   lo16*(256-4w) + hi16*4w + 128      (v_dot2_u32_u16, max 65535*256+128 < 2^32)
@@ -281,21 +270,7 @@ BU_DEV uint32_t bu_udot4(uint32_t a, uint32_t b, uint32_t c)
     return r;
 #endif
 }
-// |a - b| + K with K a small literal (v_sad_u32).  Inline asm: left to itself hipcc expands the absolute difference
-// into max/min/sub (3 VALU) -- 8 candidates x 16 texels of those dominate the EAC search.
-template <int K>
-BU_DEV uint32_t bu_sad(uint32_t a, uint32_t b)
-{
-#if defined(__HIPCC__)
-    uint32_t r;
-    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(K));
-    return r;
-#else
-    return (a > b ? a - b : b - a) + (uint32_t)K;
-#endif
-}
 BU_DEV uint32_t bu_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-BU_DEV uint32_t bu_umin3(uint32_t a, uint32_t b, uint32_t c) { return bu_umin(bu_umin(a, b), c); }  // -> v_min3_u32
 // ({hi, lo} >> sh) & 0xFFFFFFFF for 0 < sh < 32 (v_alignbit_b32)
 BU_DEV uint32_t bu_alignbit(uint32_t hi, uint32_t lo, int sh)
 {
