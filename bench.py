@@ -167,6 +167,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the communicator's first collectives (connection setup, tens of ms) happen here, far from the timed region
+        dist.barrier()
+        dist.barrier()
+        torch.cuda.synchronize()
 
     from basisu_rs_amd import Context, _lib, synth
 
@@ -245,6 +249,26 @@ class RawDeviceBuffer:
         if self.ptr:
             self.env.lib.bu_device_free(self.env.ctx.handle, ctypes.c_void_p(self.ptr))
             self.ptr = 0
+
+
+def busy_barrier(env, launch_async, n_launches):
+    """The barrier + synchronize that opens the timed region, without letting the GPU idle through it.  An idle gap costs
+    clocks (tools/exp/idle_gap.py: 1 ms of idleness makes the next 20 launches of the 2^25-block kernel 4 % slower, 5 ms
+    14 %, 20 ms 25 %; the first collective of a fresh communicator takes longer than that).  So: untimed launches of the
+    same kernel are queued on a side stream, the ranks meet in dist.barrier() while those run, and synchronize() then
+    waits out whatever is left of them -- the K timed steps start on a GPU that has been busy all along.  Nothing of the
+    side stream's work is in the timed region: it has completed when synchronize() returns."""
+    torch, dist = env.torch, env.dist
+    if not env.use_dist:
+        torch.cuda.synchronize()
+        return
+    if getattr(env, "side_stream", None) is None:
+        env.side_stream = torch.cuda.Stream(device=env.dev)
+    ssp = ctypes.c_void_p(env.side_stream.cuda_stream)
+    for i in range(n_launches):  # asynchronous: this only fills the queue (a few ms of GPU work)
+        launch_async(i, ssp)
+    dist.barrier()
+    torch.cuda.synchronize()
 
 
 def measure_gather(env, full_buf, shard_bytes, verify=None, reps=10):
@@ -411,9 +435,12 @@ def run_array512(env):
     if args.warmup > 0:
         run(args.warmup)
     torch.cuda.synchronize()
-    if env.use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+
+    def warm_async(i, ssp):
+        k = (rot[0] + i) % nrot
+        lib.bu_uastc_transcode_device(ctx.handle, env._lib.BC7, ctypes.c_void_p(in_ptrs[k]), nb, ctypes.c_void_p(out_ptrs[k]), 256, 0, None, ssp)
+
+    busy_barrier(env, warm_async, max(2, 12 // world))  # ~3 ms of work
     t0 = time.perf_counter()
     ev_ms = run(args.steps)
     torch.cuda.synchronize()
@@ -540,9 +567,12 @@ def run_atlas4096(env):
     if args.warmup > 0:
         run(args.warmup)
     torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+
+    def warm_async(i, ssp):  # an untimed launch on the side stream, rotating like the timed ones
+        k = (rot[0] + i) % nbuf
+        lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(in_ptrs[k]), N_BLOCKS, ctypes.c_void_p(out_ptrs[k]), NBX, 0, None, ssp)
+
+    busy_barrier(env, warm_async, 400)  # ~4 ms of work
     t0 = time.perf_counter()
     ev_ms = run(args.steps)  # K launches, hipEvents recorded on the launch stream around them
     torch.cuda.synchronize()
