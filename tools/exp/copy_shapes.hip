@@ -1,0 +1,57 @@
+// EXPERIMENT: what is the fastest any kernel shape moves 16 MiB in + 16 MiB out (cold, 64 rotated buffer pairs)?
+// hipcc --offload-arch=gfx950 -O3 -o tools/exp/copy_shapes tools/exp/copy_shapes.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+template <int EPT, bool NT>
+__global__ void copyk(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+    uint4 v[EPT];
+    const size_t base = (size_t)blockIdx.x * blockDim.x * EPT + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const size_t i = base + (size_t)k * blockDim.x;
+        if (i < n) {
+            if (NT) { v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(in + i)); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
+            else v[k] = in[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const size_t i = base + (size_t)k * blockDim.x;
+        if (i < n) {
+            if (NT) { v4u t = {v[k].x, v[k].y, v[k].z, v[k].w}; __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(out + i)); }
+            else out[i] = v[k];
+        }
+    }
+}
+template <int EPT, bool NT>
+float timeit(int wg, const std::vector<uint4*>& in, const std::vector<uint4*>& out, size_t n, int launches)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const unsigned grid = (unsigned)((n + (size_t)wg * EPT - 1) / ((size_t)wg * EPT));
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; rep++) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < launches; i++) hipLaunchKernelGGL((copyk<EPT, NT>), dim3(grid), dim3(wg), 0, 0, in[i % in.size()], out[i % out.size()], n);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep) best = ms / launches * 1e3f < best ? ms / launches * 1e3f : best;
+    }
+    return best;
+}
+int main()
+{
+    const size_t n = 1 << 20;
+    std::vector<uint4*> in(64), out(64);
+    for (int k = 0; k < 64; k++) { hipMalloc(&in[k], n * 16); hipMalloc(&out[k], n * 16); hipMemset(in[k], k, n * 16); }
+    hipDeviceSynchronize();
+    for (int wg : {256, 512, 1024}) {
+        printf("wg %4d nt : ept1 %.2f  ept2 %.2f  ept4 %.2f  ept8 %.2f us\n", wg, timeit<1, true>(wg, in, out, n, 512), timeit<2, true>(wg, in, out, n, 512),
+               timeit<4, true>(wg, in, out, n, 512), timeit<8, true>(wg, in, out, n, 512));
+        printf("wg %4d pl : ept1 %.2f  ept2 %.2f  ept4 %.2f  ept8 %.2f us\n", wg, timeit<1, false>(wg, in, out, n, 512), timeit<2, false>(wg, in, out, n, 512),
+               timeit<4, false>(wg, in, out, n, 512), timeit<8, false>(wg, in, out, n, 512));
+    }
+    return 0;
+}
