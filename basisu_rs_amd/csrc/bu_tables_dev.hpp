@@ -9,7 +9,26 @@
 #include <stdint.h>
 #include <string.h>
 
+#define BU_TABLE static constexpr
 #include "bu_tables.h"
+
+// Orderings the ETC code relies on, checked where the tables are compiled in:
+//  - every EAC modifier table is monotone in the entry order 3,2,1,0,4,5,6,7 (bu_eac_block counts thresholds instead of
+//    searching the eight values; etc.rs:450-468)
+//  - every ETC1 modifier row rises (the three luma thresholds of a sub-block are monotone; etc.rs:435-445)
+constexpr bool bu_etc_tables_ordered()
+{
+    for (int t = 0; t < 16; t++) {
+        const int by_rank[8] = {3, 2, 1, 0, 4, 5, 6, 7};
+        for (int r = 1; r < 8; r++)
+            if (BU_ETC2_ALPHA_MOD[8 * t + by_rank[r - 1]] >= BU_ETC2_ALPHA_MOD[8 * t + by_rank[r]]) return false;
+    }
+    for (int i = 0; i < 8; i++)
+        for (int k = 1; k < 4; k++)
+            if (BU_ETC1_MOD[4 * i + k - 1] >= BU_ETC1_MOD[4 * i + k]) return false;
+    return true;
+}
+static_assert(bu_etc_tables_ordered(), "EAC / ETC1 modifier tables are not in the order the threshold forms assume");
 
 struct BuPart {  // one UASTC partition pattern (layout documented in bu_tables.h / tools/gen_tables.py)
     uint32_t upat, bpat;
