@@ -13,6 +13,8 @@ ins, idxs = [], []
 for k in range(NBUF):
     gen = torch.Generator(device=dev); gen.manual_seed(k + 1)
     idx = torch.randint(0, 608, (N,), device=dev, generator=gen)
+    if os.environ.get("AB_COH"):  # mode per 8x8-block tile of a 1024-block-wide image (synth.coh_indices), texture-like
+        idx = torch.from_numpy(synth.coh_indices(1024, N // 1024, seed=synth.GOLD_SEED + k)).to(dev)
     ins.append(gu[idx].contiguous()); idxs.append(idx if k == 0 else None)
 outs = [torch.empty((N, 16), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
 routs = [torch.empty((N, 64), dtype=torch.uint8, device=dev) for _ in range(min(NBUF, 16))]
