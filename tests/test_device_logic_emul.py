@@ -65,3 +65,39 @@ def test_emul_solid_colour_blocks_cover_bc7_mode5_fallback(emul, oracle):
         _compare(emul, oracle, t, blocks)
     out, _ = emul.batch("bc7", blocks)
     assert ((out[:, 0] & 0x3F) == 0x20).any(), "BC7 mode 5 fallback not exercised"
+
+
+def test_emul_is_clean_under_ubsan(golden):
+    """the per-block code once more under -fsanitize=undefined (aborts on the first report): reference vectors, raw random
+    blocks and every mode densely, all five targets -- in a child process, so that an abort is a test failure"""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
+    subprocess.check_call(["make", "-s", "-C", here, "libbu_emul_ubsan.so"])
+    code = r"""
+import ctypes, sys, numpy as np
+sys.path.insert(0, %r)
+from basisu_rs_amd import synth
+lib = ctypes.CDLL(%r)
+lib.bu_emul_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+lib.bu_emul_batch.restype = None
+g = synth.load_golden(%r)
+rng = np.random.default_rng(21)
+raw = rng.integers(0, 256, size=(40000, 16), dtype=np.uint8)
+base = np.repeat(g["uastc"], 40, axis=0)
+noise = rng.integers(0, 256, size=base.shape, dtype=np.uint8)
+dense = noise.copy()
+dense[:, 0] = (base[:, 0] & 0x7F) | (noise[:, 0] & 0x80)
+for blocks in (g["uastc"], raw, dense):
+    b = np.ascontiguousarray(blocks)
+    for t in range(5):
+        out = np.zeros((b.shape[0], 64), dtype=np.uint8)
+        st = np.zeros(b.shape[0], dtype=np.uint8)
+        lib.bu_emul_batch(t, b.ctypes.data, b.shape[0], out.ctypes.data, st.ctypes.data)
+print("clean")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(here, "libbu_emul_ubsan.so"),
+       os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "uastc_kat.bin"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
