@@ -107,7 +107,10 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);
-            const bool many = nb >= (size_t)4096 * (size_t)ctx->cu_count / 2;
+            // ETC1 / ETC2: three 1024-block workgroups (83 / 99 VGPRs) are resident per CU; up to there every tile of the small
+            // shape runs at once and beats the 4096-block shape (2^19 blocks: 12.7 against 18.2 us, 786 432: 16.7 / 18.6),
+            // beyond it the small shape needs a second round of workgroups (917 504 blocks: 21.5 against 18.9 us)
+            const bool many = nb > (size_t)3 * 1024 * (size_t)ctx->cu_count;
             switch (target) {
             case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
             case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;

@@ -191,7 +191,7 @@ struct BuBigCfg {
     // ETC2 661 -> 613, BC7 227 -> 213 (0.63 of the HBM peak).  ASTC would cross 64 VGPRs (2^20 blocks: 9.55 -> 12.97 us).
     static constexpr bool PREFETCH = true, DIRECT = false;
     static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1;
-    static constexpr bool ALL_SIZES = false;  // below 2 Ki blocks per CU the launcher switches to 512 x 2 (1024-block tiles)
+    static constexpr bool ALL_SIZES = false;  // up to 3 Ki blocks per CU the launcher uses 512 x 2 (1024-block tiles, all resident): bu_launch_uastc
 };
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
