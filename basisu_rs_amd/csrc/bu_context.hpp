@@ -68,6 +68,17 @@ bu_status bu_reserve(bu_context* ctx, void** p, size_t* cap, size_t need)
 // walks many tiles and reads overlap writes (measured on a 4096^2 atlas: 16 -> 0.52 ms, 64 -> 0.47, 256 -> 0.54, 1024 -> 0.56)
 constexpr unsigned BU_ZEROCOPY_GRID = 64;
 
+// Blocks per tile of a launch whose kernel takes its tile size at run time (bu_uastc_sorted_kernel, DYN_TILE): the smallest
+// number of rounds the full tile allows, then equal tiles (a multiple of 64 blocks) so that every workgroup slot gets the
+// same share.  1.5 Mi blocks on 256 slots of up to 4096: two rounds of 3072 instead of 4096 + 2048.
+size_t bu_balanced_tile(size_t max_tile, size_t n_blocks, size_t slots, bool dynamic)
+{
+    if (!dynamic || slots == 0) return max_tile;
+    const size_t per_slot = (n_blocks + slots - 1) / slots, rounds = (per_slot + max_tile - 1) / max_tile;
+    size_t t = ((per_slot + rounds - 1) / rounds + 63) & ~(size_t)63;
+    return t < 64 ? 64 : (t > max_tile ? max_tile : t);
+}
+
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
                           uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0)
@@ -96,17 +107,19 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
     if (grid_cap == 0 && (many || BuBigCfg<T>::ALL_SIZES)) {                                                                           \
         using C = BuBigCfg<T>;                                                                                                          \
-        const size_t btiles = (nb + (size_t)C::WGS * C::BPT - 1) / ((size_t)C::WGS * C::BPT);                                           \
+        const size_t tile_rt = bu_balanced_tile((size_t)C::WGS * C::BPT, nb, (size_t)ctx->cu_count * C::WG_PER_CU, C::DYN_TILE);        \
+        const size_t btiles = (nb + tile_rt - 1) / tile_rt;                                                                             \
         const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
-                           dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);      \
+                           dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count,                    \
+                           (unsigned)tile_rt BU_STAMP_PASS);                                                                                                       \
     } else if (grid_cap == 0) {                                                                                                         \
         /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(512), 0, stream, pin, pout, \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);                                         \
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, 1024u BU_STAMP_PASS);                                  \
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)(BU_SORT_WGS * BU_SORT_BPT) BU_STAMP_PASS);
             // ETC1 / ETC2: three 1024-block workgroups (83 / 99 VGPRs) are resident per CU; up to there every tile of the small
             // shape runs at once and beats the 4096-block shape (2^19 blocks: 12.7 against 18.2 us, 786 432: 16.7 / 18.6),
             // beyond it the small shape needs a second round of workgroups (917 504 blocks: 21.5 against 18.9 us)
@@ -123,7 +136,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
                 const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * BU_RGBA_WG_PER_CU;
                 const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
                 hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_RGBA_WGS, BU_RGBA_BPT, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(BU_RGBA_WGS), 0, stream, pin,
-                                   pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count BU_STAMP_PASS);
+                                   pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)(BU_RGBA_WGS * BU_RGBA_BPT) BU_STAMP_PASS);
             } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }

@@ -191,6 +191,7 @@ struct BuBigCfg {
     // ETC2 661 -> 613, BC7 227 -> 213 (0.63 of the HBM peak).  ASTC would cross 64 VGPRs (2^20 blocks: 9.55 -> 12.97 us).
     static constexpr bool PREFETCH = true, DIRECT = false;
     static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1;
+    static constexpr bool DYN_TILE = true;    // the kernel takes the tile size at run time (bu_balanced_tile)
     static constexpr bool ALL_SIZES = false;  // up to 3 Ki blocks per CU the launcher uses 512 x 2 (1024-block tiles, all resident): bu_launch_uastc
 };
 template <>
@@ -198,9 +199,11 @@ struct BuBigCfg<BU_TGT_BC7> {
     static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
     static constexpr bool PREFETCH = true, DIRECT = false;  // 64 VGPRs with the next tile's two loads in flight: still four workgroups per CU
+    static constexpr bool DYN_TILE = false;
 };
 template <>
 struct BuBigCfg<BU_TGT_ASTC> {
+    static constexpr bool DYN_TILE = false;
     static constexpr bool PREFETCH = false, DIRECT = false;
     static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = true;
@@ -232,7 +235,7 @@ struct BuBigCfg<BU_TGT_ASTC> {
 template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                                const BuTables* __restrict__ tables, unsigned cus BU_STAMP_ARG)
+                                                                const BuTables* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
 {
     BU_STAMP_DECL
     BU_STAMP(0)
@@ -271,13 +274,21 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
     __shared__ uint32_t cnt[2][32], next_chunk[2];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
-    const unsigned n_tiles = (n_blocks + BU_TILE - 1) / BU_TILE;  // 32-bit indices: the host splits launches above 2^26 blocks
+    // Blocks per tile.  The ETC shape is one workgroup per CU on tiles of up to 4096 blocks; with a fixed tile a slice of
+    // 1.5 tiles per CU takes as long as one of 2 (1.5 Mi blocks 33.4 us, 2 Mi 34.2).  There the launcher sizes the tile so
+    // that every CU gets the same number of equal tiles (`tile_rt` <= BU_TILE, a multiple of 64); threads past the end of
+    // a shorter tile sit out like threads past the end of the slice.  Every other shape passes tile_rt = BU_TILE and
+    // compiles to what it was.
+    constexpr bool DYN_TILE = (TARGET == BU_TGT_ETC1 || TARGET == BU_TGT_ETC2) && BU_TILE == 4096;
+    const unsigned tile_blocks = DYN_TILE ? tile_rt : (unsigned)BU_TILE;
+    const unsigned n_tiles = (n_blocks + tile_blocks - 1) / tile_blocks;  // 32-bit indices: the host splits launches above 2^26 blocks
+    auto in_tile = [&](unsigned l) { return !DYN_TILE || l < tile_blocks; };
     unsigned tile = blockIdx.x;
     uint4 v[BU_BPT];
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++) {
-        const unsigned idx = tile * BU_TILE + j * BU_WG + tid;
-        v[j] = (tile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+        const unsigned idx = tile * tile_blocks + j * BU_WG + tid;
+        v[j] = (tile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
     // Table staging in two steps.  The sort phases read only key_lut (128 B): that goes to LDS now.  Everything else is first
     // read in the chunk phase; its loads are issued here, behind the block loads, and stay in registers until the first tile's
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     BU_STAMP(1)
     unsigned par = 0;
     for (; tile < n_tiles; tile += gridDim.x, par ^= 1u) {
-        const unsigned tbase = tile * BU_TILE;
+        const unsigned tbase = tile * tile_blocks;
         // ---- A: sort key + rank within the key (counting sort, pass 1) ----
         // key = position of the block's mode in BU_COST_ORDER (runs are laid out heaviest code path first).
         // Rank within the key = one LDS atomic per block.  64 lanes adding to ONE counter serialise, though, and that is
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         bool uniform = true;
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
-            const bool valid = tbase + j * BU_WG + tid < n_blocks;
+            const bool valid = tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid);
             key[j] = valid ? T.key_lut[v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && key[j] < 20u;
         }
@@ -370,8 +381,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
-                vn[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+                const unsigned idx = ntile * tile_blocks + j * BU_WG + tid;
+                vn[j] = (ntile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
         BU_STAMP(4)
@@ -467,8 +478,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         } else {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const unsigned idx = ntile * BU_TILE + j * BU_WG + tid;
-                v[j] = (ntile < n_tiles && idx < n_blocks) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+                const unsigned idx = ntile * tile_blocks + j * BU_WG + tid;
+                v[j] = (ntile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
         // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only

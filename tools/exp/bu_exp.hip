@@ -142,47 +142,47 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
     case code: {                                                                                                            \
         const size_t t_ = (n_blocks + (size_t)(W) * (B)-1) / ((size_t)(W) * (B));                                           \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, W, B, MINW, PF, DIR>), dim3((unsigned)((t_ + (DIV)-1) / (DIV))), dim3(W), 0, s, in, d_out[k], \
-                           (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);                   \
+                           (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);                   \
     } break;
             SV(0, 256, 4, 1, 1, true, false) SV(10, 256, 4, 1, 1, false, true) SV(11, 512, 4, 1, 1, false, false) SV(12, 512, 4, 1, 1, false, true)
             SV(13, 1024, 4, 1, 1, false, false) SV(14, 1024, 4, 1, 1, false, true) SV(15, 256, 8, 1, 1, false, true) SV(16, 512, 2, 1, 1, false, true)
         case 24: {
             const size_t t_ = (n_blocks + 1023) / 1024;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 2, 1, false, false, 0>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 30: {  // 1024 x 1, two persistent workgroups per CU, prefetch: two tiles per workgroup
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 1024, 1, 1, true, false, 0>), dim3((unsigned)(2 * ctx->cu_count)), dim3(1024), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 31: {  // 512 x 2, two persistent workgroups per CU, prefetch
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 2, 1, true, false, 0>), dim3((unsigned)(2 * ctx->cu_count)), dim3(512), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 23: {
             const size_t t_ = (n_blocks + 2047) / 2048;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 1024, 2, 8, false, false, 0>), dim3((unsigned)t_), dim3(1024), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 22: {
             const size_t t_ = (n_blocks + 2047) / 2048;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 1024, 2, 1, false, false, 0>), dim3((unsigned)t_), dim3(1024), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 21: {
             const size_t t_ = (n_blocks + 2047) / 2048;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 4, 1, false, false, 40>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 40: {  // the shipped ETC1 shape
             const size_t t_ = (n_blocks + 4095) / 4096;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC1, 1024, 4, 1, false, false, 0>), dim3((unsigned)t_), dim3(1024), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, 4096u, g_stamps);
         } break;
         case 41: {  // the shipped ETC2 shape
             const size_t t_ = (n_blocks + 2047) / 2048;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_ETC2, 512, 4, 1, false, false, 0>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
-                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, g_stamps);
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
 #undef SV
         default: return BU_ERR_ARGUMENT;
