@@ -686,7 +686,7 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __
         uint32_t lo = 0, hi = n_slices;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (__builtin_amdgcn_readfirstlane(slices[mid].unit0) <= unit) lo = mid;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)slices[mid].unit0) <= unit) lo = mid;
             else hi = mid;
         }
         const BuEtc1sSlice sd = slices[lo];
