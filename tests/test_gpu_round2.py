@@ -528,3 +528,23 @@ def test_device_side_data_crc_folds_pieces_gaps_and_tails(ctx, golden, oracle):
     st, hdr, want = oracle.read_to("rgba", f)
     h, got = bu.read_to_rgba(f, ctx)
     assert st == 0 and len(got) == 4 and all(a.data.tobytes() == w[3].tobytes() for a, w in zip(got, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [786433, 1000000, 1572865])
+def test_etc_shapes_at_sizes_between_the_tile_multiples(ctx, golden, n):
+    """just above the switch to the 4096-block shape, a size that is no multiple of 64, and 1.5 tiles per CU (the launcher
+    sizes the ETC tile at run time: two rounds of 3072-block tiles): outputs against the known answers, and a bad block in
+    the last tile reported with its own index"""
+    from basisu_rs_amd import BasisuError
+
+    idx = synth.gold_indices(n, seed=n)
+    blocks = golden["uastc"][idx]
+    for name, fmt in (("etc1", _lib.ETC1), ("etc2", _lib.ETC2)):
+        got = ctx.transcode(fmt, blocks).reshape(n, -1)
+        assert (got == golden[name][idx]).all(), name
+    bad = blocks.copy()
+    bad[n - 3, 0] = 0x45  # the one 7-bit prefix that is no mode code (uastc.rs:560-577)
+    with pytest.raises(BasisuError) as e:
+        ctx.transcode(_lib.ETC1, bad)
+    assert e.value.first_bad_block == n - 3
