@@ -8,7 +8,8 @@ from oracle.pyoracle import Oracle
 ctx = Context(0); o = Oracle()
 FMT = {"astc": _lib.ASTC, "bc7": _lib.BC7, "etc1": _lib.ETC1, "etc2": _lib.ETC2}
 t0 = time.time(); total = 0
-for seed in range(int(os.environ.get("FUZZ_SEEDS", 4))):
+SEED0 = int(os.environ.get("FUZZ_SEED0", 0))
+for seed in range(SEED0, SEED0 + int(os.environ.get("FUZZ_SEEDS", 4))):
     n = 1 << 20
     for kind in ("valid", "raw"):
         if kind == "valid":
