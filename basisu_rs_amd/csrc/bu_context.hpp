@@ -131,12 +131,19 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             case BU_TARGET_RGBA32: {
                 // 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows, the input tile
                 // aliased into row 0) so the image rows leave as coalesced 1 KiB stores; persistent workgroups walk their
-                // tiles with prefetch.  BU_RGBA_WGS threads x BU_RGBA_BPT blocks, BU_RGBA_WG_PER_CU resident per CU.
-                const size_t rtiles = (nb + (BU_RGBA_WGS * BU_RGBA_BPT) - 1) / (BU_RGBA_WGS * BU_RGBA_BPT);
+                // tiles with prefetch, two per CU.  Up to 3 Mi blocks 1024 threads per tile (32 waves per CU: 2^18 blocks
+                // 7.8 -> 7.2 us, 2^20 17.95 -> 16.9, 2^21 35.0 -> 33.75), above that 512 threads x 2 blocks (2^22 blocks 62.7
+                // against 64.4 us, 2^24 252 against 265).  The zero-copy launches (grid_cap) keep the 512 x 2 shape.
+                constexpr size_t rtile = 1024;
+                const size_t rtiles = (nb + rtile - 1) / rtile;
                 const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * BU_RGBA_WG_PER_CU;
                 const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
-                hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, BU_RGBA_WGS, BU_RGBA_BPT, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(BU_RGBA_WGS), 0, stream, pin,
-                                   pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)(BU_RGBA_WGS * BU_RGBA_BPT) BU_STAMP_PASS);
+                if (grid_cap == 0 && nb <= ((size_t)3 << 20))
+                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 1024, 1, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(1024), 0, stream, pin,
+                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)rtile BU_STAMP_PASS);
+                else
+                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 512, 2, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(512), 0, stream, pin,
+                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)rtile BU_STAMP_PASS);
             } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }

@@ -208,17 +208,13 @@ struct BuBigCfg<BU_TGT_ASTC> {
     static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
     static constexpr bool ALL_SIZES = true;
 };
-// RGBA32 configuration (tile = 1024 blocks either way)
-#ifndef BU_RGBA_WGS
-#define BU_RGBA_WGS 512
-#define BU_RGBA_BPT 2
+// RGBA32 configuration: 1024-block tiles, two workgroups per CU, 1024 x 1 or 512 x 2 threads x blocks by slice size (bu_launch_uastc)
 #define BU_RGBA_WG_PER_CU 2
-#endif
 #ifndef BU_RGBA_PREFETCH
 #define BU_RGBA_PREFETCH true
 #endif
 #ifndef BU_RGBA_SKEW
-#define BU_RGBA_SKEW 20
+#define BU_RGBA_SKEW 0
 #endif
 
 
