@@ -138,12 +138,15 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
                 const size_t rtiles = (nb + rtile - 1) / rtile;
                 const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * BU_RGBA_WG_PER_CU;
                 const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
+                // generation priorities only when every workgroup walks at least two tiles (2^19 blocks 10.7 -> 10.3 us and
+                // 786 432 blocks 15.75 -> 14.24 without them, 2^20 blocks 16.7 against 18.7 with them)
+                const unsigned rcus = rtiles >= 2 * (size_t)rgrid ? (unsigned)ctx->cu_count : 0u;
                 if (grid_cap == 0 && nb <= ((size_t)3 << 20))
                     hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 1024, 1, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(1024), 0, stream, pin,
-                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)rtile BU_STAMP_PASS);
+                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, rcus, (unsigned)rtile BU_STAMP_PASS);
                 else
                     hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 512, 2, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(512), 0, stream, pin,
-                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)rtile BU_STAMP_PASS);
+                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, rcus, (unsigned)rtile BU_STAMP_PASS);
             } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }

@@ -243,8 +243,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // 1.5 us apart and the last one runs its latency-bound chain with the vector units nearly idle (phase stamps,
     // profiles/r02_*stamps*).  Raising the later generations' priority makes them catch up while the older ones fill
     // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
-    {
-        const unsigned gen = blockIdx.x / (cus ? cus : 1u);
+    // cus = 0 switches it off: RGBA32 launches in which the workgroups do not all walk the same number of tiles (786 432
+    // blocks: the one-tile workgroups of the second generation would run ahead of the two-tile ones, 15.75 against 14.24 us).
+    if (cus != 0) {
+        const unsigned gen = blockIdx.x / cus;
         if (gen == 1) __builtin_amdgcn_s_setprio(1);
         if (gen == 2) __builtin_amdgcn_s_setprio(2);
         if (gen >= 3) __builtin_amdgcn_s_setprio(3);
