@@ -105,7 +105,12 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const unsigned long long pbase = base + done;
             // large inputs: the per-target BuBigCfg configuration, see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
-    if (grid_cap == 0 && (many || BuBigCfg<T>::ALL_SIZES)) {                                                                           \
+    if (grid_cap == 0 && nb <= (size_t)1024 * ctx->cu_count) {                                                                         \
+        /* at most one tile per CU: 16 waves on it (BC7 1 Ki blocks 4.32 -> 3.92 us, 2^16 5.16 -> 4.80, 2^18 5.70 -> 5.41; */          \
+        /* ETC1 6.76 -> 6.47, 7.95 -> 7.64, 8.82 -> 8.54) */                                                                           \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 1, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(1024), 0, stream, pin, pout, \
+                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, 1024u BU_STAMP_PASS);                                  \
+    } else if (grid_cap == 0 && (many || BuBigCfg<T>::ALL_SIZES)) {                                                                    \
         using C = BuBigCfg<T>;                                                                                                          \
         const size_t tile_rt = bu_balanced_tile((size_t)C::WGS * C::BPT, nb, (size_t)ctx->cu_count * C::WG_PER_CU, C::DYN_TILE);        \
         const size_t btiles = (nb + tile_rt - 1) / tile_rt;                                                                             \
@@ -116,10 +121,6 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
                            dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus,                                       \
                            (unsigned)tile_rt BU_STAMP_PASS);                                                                                                       \
-    } else if (grid_cap == 0 && nb <= (size_t)1024 * ctx->cu_count) {                                                                  \
-        /* at most one tile per CU: 16 waves on it (ETC1 1 Ki blocks 6.76 -> 6.47 us, 2^16 7.95 -> 7.64, 2^18 8.82 -> 8.54) */        \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 1, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(1024), 0, stream, pin, pout, \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, 1024u BU_STAMP_PASS);                                  \
     } else if (grid_cap == 0) {                                                                                                         \
         /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(512), 0, stream, pin, pout, \
