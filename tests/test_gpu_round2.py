@@ -548,3 +548,32 @@ def test_etc_shapes_at_sizes_between_the_tile_multiples(ctx, golden, n):
     with pytest.raises(BasisuError) as e:
         ctx.transcode(_lib.ETC1, bad)
     assert e.value.first_bad_block == n - 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [262144, 263168, 786432, 787456, 3145728, 3146752])
+def test_every_target_on_both_sides_of_the_launch_shape_thresholds(ctx, golden, n):
+    """the launcher changes workgroup shape at one tile per CU (all targets), three tiles per CU (ETC1 / ETC2) and 3 Mi blocks
+    (RGBA32), and switches the generation priorities off for uneven tile counts: device-resident slices of exactly those sizes
+    and one block row more, all five targets against the known answers (torch-side comparison, nothing leaves the GPU)"""
+    import torch
+
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(n)
+    idx = torch.randint(0, 608, (n,), device="cuda", generator=gen)
+    d_in = gu[idx].contiguous()
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    for name, fmt, ob in (("bc7", _lib.BC7, 16), ("astc", _lib.ASTC, 16), ("etc1", _lib.ETC1, 8), ("etc2", _lib.ETC2, 16), ("rgba", _lib.RGBA32, 64)):
+        want = torch.from_numpy(golden[name]).cuda()[idx]
+        d_out = torch.zeros((n, ob), dtype=torch.uint8, device="cuda")
+        ctx.status_word_reset(status)
+        ctx.transcode_device(fmt, d_in, n, d_out, blocks_per_row=1024, d_status=status)
+        torch.cuda.synchronize()
+        ctx.status_word_check(int(status.item()))
+        if name == "rgba":  # image rows -> per-block texel rows
+            got = d_out.view(n // 1024, 4, 1024, 16).permute(0, 2, 1, 3).reshape(n, 64)
+        else:
+            got = d_out
+        assert torch.equal(got, want), name
+        del d_out, want
