@@ -39,3 +39,16 @@ each = (ctypes.c_float * 20)()
 warm(25); run(5); torch.cuda.synchronize()
 lib.bu_time_uastc_launches_each(ctx.handle, _lib.BC7, ip, op, NBUF, rot[0] % NBUF, N, 1024, 20, None, sp, each)
 print("per launch (event to event):", " ".join("%.1f" % e for e in each))
+# keep the GPU busy up to the synchronize in front of the timed window: untimed launches on a side stream
+side = torch.cuda.Stream(device=dev); ssp = ctypes.c_void_p(side.cuda_stream)
+for n_async in (0, 50, 200, 800):
+    res = []
+    for rep in range(8):
+        time.sleep(0.05)
+        warm(25); run(5)
+        for i in range(n_async):
+            k = (rot[0] + i) % NBUF
+            lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(ip[k]), N, ctypes.c_void_p(op[k]), 1024, 0, None, ssp)
+        torch.cuda.synchronize()
+        res.append(run(20))
+    print("%4d async launches before the synchronize:  %s   mean %.2f" % (n_async, " ".join("%.2f" % r for r in res), sum(sorted(res)[:7]) / 7), flush=True)
