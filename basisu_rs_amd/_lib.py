@@ -25,10 +25,10 @@ SYMBOLS = [
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
     "bu_basis_read_header", "bu_basis_read_slice_descs", "bu_basis_crc16", "bu_read_query", "bu_read_to", "bu_basislz_decode",
     "bu_basis_write_uastc",
-    "bu_comm_unique_id", "bu_comm_create", "bu_comm_destroy", "bu_allgather_inplace",
+    "bu_comm_unique_id", "bu_comm_create", "bu_comm_destroy", "bu_comm_query", "bu_allgather_inplace",
     "bu_ipc_export", "bu_ipc_open", "bu_ipc_close", "bu_allgather_peer", "bu_array_transcode_sharded",
     "bu_device_alloc", "bu_device_free", "bu_memcpy",
-    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_copy_launches",
+    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_window", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_copy_launches",
 ]
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
@@ -139,6 +139,9 @@ def load():
     lib.bu_copy_ceiling_device.restype = c.c_int
     lib.bu_time_uastc_launches.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches.restype = c.c_int
+    lib.bu_time_uastc_launches_window.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, c.c_int, vp, vp,
+                                                  c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_int)]
+    lib.bu_time_uastc_launches_window.restype = c.c_int
     lib.bu_time_uastc_launches_each.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, vp, vp, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches_each.restype = c.c_int
     # multi-GPU
@@ -148,6 +151,8 @@ def load():
     lib.bu_comm_create.restype = c.c_int
     lib.bu_comm_destroy.argtypes = [vp]
     lib.bu_comm_destroy.restype = None
+    lib.bu_comm_query.argtypes = [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    lib.bu_comm_query.restype = c.c_int
     lib.bu_allgather_inplace.argtypes = [vp, vp, sz, vp]
     lib.bu_allgather_inplace.restype = c.c_int
     lib.bu_ipc_export.argtypes = [vp, vp, vp]

@@ -14,6 +14,25 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
     return BU_OK;
 }
 
+// spin until `ev` has completed, at most BU_SPIN_SECONDS: a GPU hang must not become an endless 100 % CPU loop
+constexpr double BU_SPIN_SECONDS = 120.0;
+static bu_status bu_spin_event(bu_context* ctx, hipEvent_t ev, std::chrono::steady_clock::time_point* when)
+{
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(BU_SPIN_SECONDS);
+    for (unsigned n = 0;; n++) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
+        if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) {
+            snprintf(ctx->err, sizeof(ctx->err), "hipEventQuery: event still pending after %.0f s", BU_SPIN_SECONDS);
+            return BU_ERR_HIP;
+        }
+    }
+    if (when) *when = std::chrono::steady_clock::now();
+    (void)hipGetLastError();
+    return BU_OK;
+}
+
 bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
                                  size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches, uint64_t* d_status, void* stream,
                                  float* out_ms)
@@ -27,15 +46,45 @@ bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* 
         if (st) return st;
     }
     BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
-    // poll instead of a blocking wait: the caller's wall clock around this call (bench.py's `value`) should not carry the
-    // tens of microseconds a sleeping host thread needs to be woken up -- they are as long as several steps
-    for (;;) {
-        const hipError_t q = hipEventQuery(ctx->ev1);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
-    }
-    (void)hipGetLastError();
+    // poll instead of a blocking wait: the caller's wall clock around this call should not carry the tens of microseconds a
+    // sleeping host thread needs to be woken up -- they are as long as several steps
+    bu_status st = bu_spin_event(ctx, ctx->ev1, nullptr);
+    if (st) return st;
     BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return BU_OK;
+}
+
+// The timed region of bench.py on a GPU that never went idle: `lead` untimed launches, event 0, exactly `launches` timed
+// launches, event 1 -- all enqueued back to back on `stream` with no host synchronisation in between (rotation continuing
+// through both parts).  The host then watches the two events: host_ms = steady_clock time between "event 0 has completed"
+// and "event 1 has completed" as seen by hipEventQuery polling, i.e. a wall-clock bracket around exactly the timed
+// launches; event_ms = hipEventElapsedTime of the same pair.  *late = 1 when event 0 had already completed at the first
+// query (the host was still enqueueing when the GPU got there: host_ms then starts late and the caller must use
+// max(host_ms, event_ms)).
+bu_status bu_time_uastc_launches_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                        size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches,
+                                        uint64_t* d_status, void* stream, float* out_event_ms, float* out_host_ms, int* out_late)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || lead < 0 || !out_event_ms || !out_host_ms) return BU_ERR_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < lead + launches; i++) {
+        if (i == lead) BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
+        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, stream);
+        if (st) return st;
+    }
+    BU_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    const hipError_t first = hipEventQuery(ctx->ev0);
+    if (first != hipSuccess && first != hipErrorNotReady) return bu_fail(ctx, first, "hipEventQuery");
+    (void)hipGetLastError();
+    if (out_late) *out_late = first == hipSuccess ? 1 : 0;
+    std::chrono::steady_clock::time_point t0, t1;
+    bu_status st = bu_spin_event(ctx, ctx->ev0, &t0);
+    if (st) return st;
+    st = bu_spin_event(ctx, ctx->ev1, &t1);
+    if (st) return st;
+    *out_host_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    BU_HIP(ctx, hipEventElapsedTime(out_event_ms, ctx->ev0, ctx->ev1));
     return BU_OK;
 }
 

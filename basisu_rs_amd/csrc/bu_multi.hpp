@@ -34,6 +34,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;     // optional: how many ranks the communicator itself reports
+    int (*CommUserRank)(void*, int*) = nullptr;  // optional
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -54,6 +56,8 @@ inline const Rccl& rccl()
         t.CommDestroy = reinterpret_cast<decltype(t.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         t.AllGather = reinterpret_cast<decltype(t.AllGather)>(dlsym(h, "ncclAllGather"));
         t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        t.CommCount = reinterpret_cast<decltype(t.CommCount)>(dlsym(h, "ncclCommCount"));
+        t.CommUserRank = reinterpret_cast<decltype(t.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
         t.ok = t.GetUniqueId && t.CommInitRank && t.CommDestroy && t.AllGather;
         return t;
     }();
@@ -126,6 +130,20 @@ void bu_comm_destroy(bu_comm* comm)
     delete comm;
 }
 
+bu_status bu_comm_query(bu_comm* comm, int* out_ranks, int* out_rank)
+{
+    if (!comm || !comm->nccl) return BU_ERR_ARGUMENT;
+    const bu_multi::Rccl& r = bu_multi::rccl();
+    if (!r.CommCount || !r.CommUserRank) return BU_ERR_UNSUPPORTED;
+    int n = 0, me = 0;
+    int rc = r.CommCount(comm->nccl, &n);
+    if (rc == 0) rc = r.CommUserRank(comm->nccl, &me);
+    if (rc != 0) return bu_multi::nccl_fail(comm->ctx, rc, "ncclCommCount");
+    if (out_ranks) *out_ranks = n;
+    if (out_rank) *out_rank = me;
+    return BU_OK;
+}
+
 bu_status bu_allgather_inplace(bu_comm* comm, void* d_full, size_t shard_bytes, void* stream)
 {
     if (!comm || (shard_bytes && !d_full)) return BU_ERR_ARGUMENT;
@@ -183,6 +201,8 @@ bu_status bu_allgather_peer(bu_context* ctx, void* d_full, void* const* d_peer_f
 {
     if (!ctx || world < 1 || rank < 0 || rank >= world || (shard_bytes && (!d_full || !d_peer_full))) return BU_ERR_ARGUMENT;
     if (world == 1 || shard_bytes == 0) return BU_OK;
+    for (int p = 0; p < world; p++)  // every pointer is checked before the first copy is queued
+        if (p != rank && !d_peer_full[p]) return BU_ERR_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BU_HIP(ctx, hipSetDevice(ctx->device));
     const int lanes = world - 1 < 7 ? world - 1 : 7;
@@ -190,11 +210,11 @@ bu_status bu_allgather_peer(bu_context* ctx, void* d_full, void* const* d_peer_f
     if (st) return st;
     // the pulls start once `stream` (which carries this rank's transcode) reaches this point and are joined back into it.
     // The caller guarantees the PEERS' shards are complete (a barrier between the transcode and this call).
+    BuDrain drain(ctx);  // an error below must not leave pulls in flight on the side streams, un-joined
     BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int k = 0;
     for (int p = 0; p < world; p++) {
         if (p == rank) continue;
-        if (!d_peer_full[p]) return BU_ERR_ARGUMENT;
         hipStream_t ps = ctx->extra_streams[k % lanes];
         if (k < lanes) BU_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev0, 0));
         const size_t ofs = (size_t)p * shard_bytes;
@@ -206,6 +226,7 @@ bu_status bu_allgather_peer(bu_context* ctx, void* d_full, void* const* d_peer_f
         BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[i]));
         BU_HIP(ctx, hipStreamWaitEvent(s, ctx->ev1, 0));
     }
+    drain.armed = false;
     return BU_OK;
 }
 
@@ -218,17 +239,55 @@ bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_targ
     if (bb == 0 || target == BU_TARGET_RGBA32) return BU_ERR_ARGUMENT;  // block-linear targets: shards are contiguous byte ranges
     for (int i = 0; i < n_ctx; i++)
         if (!ctxs[i]) return BU_ERR_ARGUMENT;
-    bu_context* c0 = ctxs[0];
     std::vector<size_t> lo(n_ctx), hi(n_ctx);
-    // 1. every device transcodes its contiguous slice range into its own full buffer, at the range's final position
+    // every argument is checked before the first launch: nothing may be queued on devices 0..i-1 when device i is refused
     for (int i = 0; i < n_ctx; i++) {
         bu_multi::partition(n_slices, n_ctx, i, &lo[i], &hi[i]);
+        if (hi[i] > lo[i] && blocks_per_slice && (!d_in_shard[i] || !d_full[i])) return BU_ERR_ARGUMENT;
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return BU_ERR_ARGUMENT;  // one status word and one stream per context: contexts must be distinct
+    }
+    // the call owns every context's status word and stream until it returns: locks taken in index order (callers that pass
+    // the same set in the same order cannot deadlock each other), released by the guard
+    struct Locks {
+        bu_context* const* c;
+        int n = 0;
+        ~Locks()
+        {
+            for (int i = n - 1; i >= 0; i--) c[i]->lock.unlock();
+        }
+    } locks{ctxs};
+    for (int i = 0; i < n_ctx; i++) {
+        ctxs[i]->lock.lock();
+        locks.n = i + 1;
+    }
+    // an early error return must not leave kernels or copies in flight on any of the contexts
+    struct DrainAll {
+        bu_context* const* c;
+        int n;
+        bool armed = true;
+        ~DrainAll()
+        {
+            if (!armed) return;
+            // callers read bu_last_error from the first context: bring the failing context's message there
+            for (int i = 1; i < n && c[0]->err[0] == 0; i++)
+                if (c[i]->err[0]) memcpy(c[0]->err, c[i]->err, sizeof(c[0]->err));
+            for (int i = 0; i < n; i++) {
+                (void)hipSetDevice(c[i]->device);
+                if (c[i]->stream) (void)hipStreamSynchronize(c[i]->stream);
+                for (hipStream_t es : c[i]->extra_streams)
+                    if (es) (void)hipStreamSynchronize(es);
+            }
+        }
+    } drain{ctxs, n_ctx};
+    for (int i = 0; i < n_ctx; i++) ctxs[i]->err[0] = 0;
+    // 1. every device transcodes its contiguous slice range into its own full buffer, at the range's final position
+    for (int i = 0; i < n_ctx; i++) {
         bu_context* c = ctxs[i];
         BU_HIP(c, hipSetDevice(c->device));
         BU_HIP(c, hipMemsetAsync(c->d_status, 0xFF, sizeof(uint64_t), c->stream));
         const size_t nb = (hi[i] - lo[i]) * blocks_per_slice;
         if (nb == 0) continue;
-        if (!d_in_shard[i] || !d_full[i]) return BU_ERR_ARGUMENT;
         bu_status st = bu_launch_uastc(c, target, d_in_shard[i], nb, static_cast<uint8_t*>(d_full[i]) + lo[i] * blocks_per_slice * bb, 1,
                                        lo[i] * blocks_per_slice, reinterpret_cast<uint64_t*>(c->d_status), c->stream);
         if (st) return st;
@@ -241,14 +300,14 @@ bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_targ
         uint64_t word = BU_STATUS_WORD_CLEAR;
         hipError_t e = hipMemcpyAsync(&word, c->d_status, sizeof(word), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) {
-            for (int j = 0; j < n_ctx; j++) (void)hipStreamSynchronize(ctxs[j]->stream);
-            return bu_fail(c, e, "status download");
-        }
+        if (e != hipSuccess) return bu_fail(c, e, "status download");
         if (word < best) best = word;
     }
     bu_status st = bu_status_word_decode(best, first_bad_block);
-    if (st) return st;
+    if (st) {  // (every stream was synchronised by the status downloads: nothing left to drain)
+        drain.armed = false;
+        return st;
+    }
     // 3. all-gather by direct peer pulls: device i copies range j from device j's buffer, all pairs in flight together
     if (gather && n_ctx > 1) {
         for (int i = 0; i < n_ctx; i++) {
@@ -281,7 +340,7 @@ bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_targ
             for (int l = 0; l < lanes; l++) BU_HIP(c, hipStreamSynchronize(c->extra_streams[l]));
         }
     }
-    (void)c0;
+    drain.armed = false;
     return BU_OK;
 }
 

@@ -219,7 +219,9 @@ class GatherWatchdog:
         if self.env.rank == 0:
             self.line["allgather"] = {"error": "timed out: no transport finished; the transcode numbers above are unaffected"}
             os.write(self.env.json_fd, (json.dumps(self.line) + "\n").encode())
-        os._exit(0)
+        # a stuck collective is a failed run even though the headline line was written: the caller sees a non-zero code
+        # (no in-process restart of anything that has touched the GPU; the launcher tears the other ranks down)
+        os._exit(3)
 
     def cancel(self):
         self.t.cancel()
@@ -325,6 +327,9 @@ def measure_gather(env, full_buf, shard_bytes, verify=None, reps=10):
         st_c = lib.bu_comm_create(ctx.handle, world, rank, idb, ctypes.byref(comm))  # collective: every rank calls it
         if not all_ok(st_c == 0):
             raise RuntimeError("bu_comm_create: " + lib.bu_status_string(st_c).decode())
+        nr, me = ctypes.c_int(-1), ctypes.c_int(-1)
+        if lib.bu_comm_query(comm, ctypes.byref(nr), ctypes.byref(me)) == 0:  # what RCCL itself says (ncclCommCount / ncclCommUserRank)
+            out["rccl_comm"] = {"ranks": nr.value, "this_rank": me.value}
         scrub()
         s = timed(lambda: check(env, lib.bu_allgather_inplace(comm, ctypes.c_void_p(full_buf.ptr), shard_bytes, env.sp), "bu_allgather_inplace"))
         ok = bool(verify(full_buf.tensor())) if verify else None
@@ -441,15 +446,24 @@ def run_array512(env):
         lib.bu_uastc_transcode_device(ctx.handle, env._lib.BC7, ctypes.c_void_p(in_ptrs[k]), nb, ctypes.c_void_p(out_ptrs[k]), 256, 0, None, ssp)
 
     busy_barrier(env, warm_async, max(2, 12 // world))  # ~3 ms of work
-    t0 = time.perf_counter()
-    ev_ms = run(args.steps)
+    # timed region as in run_atlas4096: lead untimed launches, event 0, K timed launches, event 1, no host sync in between
+    lead = 16
+    ev_c, host_c, late_c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+    check(env, lib.bu_time_uastc_launches_window(ctx.handle, env._lib.BC7, in_ptrs, out_ptrs, nrot, rot[0], nb, 256, lead, args.steps,
+                                                 ctypes.c_void_p(status.data_ptr()), env.sp, ctypes.byref(ev_c), ctypes.byref(host_c),
+                                                 ctypes.byref(late_c)), "bu_time_uastc_launches_window")
+    rot[0] = (rot[0] + lead + args.steps) % nrot
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ev_ms, dt = ev_c.value, max(host_c.value, ev_c.value) / 1e3
     if env.use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([dt, ev_ms / 1e3], dtype=torch.float64, device=dev)
+    per_rank_kernel_us = [round(ev_ms / args.steps * 1e3, 3)]
     if env.use_dist:
+        every = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, t[1:2].clone())
+        per_rank_kernel_us = [round(float(x) / args.steps * 1e6, 3) for x in every.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, ev_max = float(t[0]), float(t[1])
     ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
@@ -470,6 +484,7 @@ def run_array512(env):
                    "prewarm": {"launches": prewarm_launches, "ms": 4 * args.prewarm_ms,
                                "note": "untimed launches ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}},
         "transcode_only": {"mblocks_s": round(total / kern_s / 1e6, 1), "us_per_step_kernel_max_over_ranks": round(kern_s * 1e6, 3),
+                           "us_per_step_kernel_per_rank": per_rank_kernel_us,
                            "note": "all blocks / slowest rank's kernel time (hipEvents on the launch stream)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
@@ -483,12 +498,12 @@ def run_array512(env):
         torch.cuda.synchronize()
         dist.barrier()
 
-        def verify(full_t):  # first and last slice of every rank's range
+        def verify(full_t):  # EVERY slice of every rank's range (outside the timed regions)
             ok = True
             v = full_t.view(world, per * bps, 16)
             for r_ in range(world):
                 a, b = (n_slices * r_) // world, (n_slices * (r_ + 1)) // world
-                for s in {a, b - 1} if b > a else ():
+                for s in range(a, b):
                     ok = ok and bool(torch.equal(v[r_][(s - a) * bps: (s - a + 1) * bps], expect(s)))
             return ok
 
@@ -541,6 +556,15 @@ def run_atlas4096(env):
         rot[0] += launches
         return ms.value
 
+    def run_window(lead, launches):
+        ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+        st = lib.bu_time_uastc_launches_window(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, lead, launches,
+                                               ctypes.c_void_p(status.data_ptr()), sp, ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+        if st != 0:
+            raise RuntimeError("bu_time_uastc_launches_window: " + lib.bu_status_string(st).decode())
+        rot[0] += lead + launches
+        return ev.value, host.value, late.value
+
     def ramp(**kw):
         """untimed launches of the row's own kernel for --prewarm-ms (at least 64): the rows after the host-side phases
         start from idle clocks otherwise"""
@@ -572,11 +596,19 @@ def run_atlas4096(env):
         k = (rot[0] + i) % nbuf
         lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(in_ptrs[k]), N_BLOCKS, ctypes.c_void_p(out_ptrs[k]), NBX, 0, None, ssp)
 
+    # The contract's barrier + synchronize (the ranks meet while a few ms of untimed launches keep the GPU busy), then the
+    # timed region of bu_time_uastc_launches_window: F untimed launches of the same kernel, event 0, EXACTLY K timed launches,
+    # event 1 -- enqueued back to back with no host synchronisation in between, so the K steps run on a GPU that never went
+    # idle.  The host clock starts when event 0 is first seen complete and stops when event 1 is: `value` brackets exactly
+    # the K steps.  (A synchronize() directly in front of K = 20 launches put ~35 us of pipeline refill into a 200 us
+    # window: round-2 driver run 11.47 us per launch against 9.77 us in the long pre-warm loop of the same process.)
     busy_barrier(env, warm_async, 400)  # ~4 ms of work
-    t0 = time.perf_counter()
-    ev_ms = run(args.steps)  # K launches, hipEvents recorded on the launch stream around them
+    lead = max(256, 2 * args.steps)
+    ev_ms, host_ms, late = run_window(lead, args.steps)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks below is the job's time
+    # this rank's K steps: never less than what the GPU's own events say (a host that was still enqueueing when event 0
+    # fired starts its bracket late); the MAX over ranks below is the job's time
+    dt = max(host_ms, ev_ms) / 1e3
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -785,7 +817,10 @@ def run_atlas4096(env):
                                "%d distinct atlases rotated (cold cache)" % nbuf,
                    "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1),
                    "prewarm": {"launches": prewarm_launches, "ms": args.prewarm_ms,
-                               "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}},
+                               "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"},
+                   "timed_region": {"lead_launches": lead, "host_ms": round(host_ms, 6), "event_ms": round(ev_ms, 6), "host_started_late": bool(late),
+                                    "note": "barrier + synchronize, then lead untimed launches, event 0, K timed launches, event 1 enqueued back to "
+                                            "back; host clock from event 0 seen complete to event 1 seen complete; value uses max(host, event)"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                      "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),

@@ -250,6 +250,9 @@ bu_status bu_comm_unique_id(uint8_t id[BU_COMM_ID_BYTES]);
 /* collective over all `world` ranks (ncclCommInitRank) on ctx's device */
 bu_status bu_comm_create(bu_context* ctx, int world, int rank, const uint8_t id[BU_COMM_ID_BYTES], bu_comm** out_comm);
 void bu_comm_destroy(bu_comm* comm);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank): evidence in a benchmark record that RCCL saw
+ * `world` ranks.  BU_ERR_UNSUPPORTED if the resolved RCCL lacks the two entry points. */
+bu_status bu_comm_query(bu_comm* comm, int* out_ranks, int* out_rank);
 /* d_full: world * shard_bytes bytes on this rank's device, this rank's shard already at rank * shard_bytes (written by
  * work enqueued on `stream` before this call).  Asynchronous on `stream`; afterwards every rank holds every shard. */
 bu_status bu_allgather_inplace(bu_comm* comm, void* d_full, size_t shard_bytes, void* stream);
@@ -290,6 +293,16 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
 bu_status bu_time_uastc_launches(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                  size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int launches,
                                  uint64_t* d_status, void* stream, float* out_ms);
+/* The timed region of bench.py on a GPU that never went idle: `lead` untimed launches, event 0, exactly `launches` timed
+ * launches, event 1, enqueued back to back on `stream` with no host synchronisation in between (buffer rotation continues
+ * through both parts).  *out_event_ms = hipEventElapsedTime(event 0, event 1); *out_host_ms = host steady-clock time from the
+ * moment event 0 is first seen complete to the moment event 1 is (hipEventQuery polling): a wall-clock bracket around exactly
+ * the timed launches.  *out_late (optional) = 1 if event 0 had already completed when the host finished enqueueing -- the
+ * host bracket then started late and the caller must take max(host, event). */
+bu_status bu_time_uastc_launches_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
+                                        size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead,
+                                        int launches, uint64_t* d_status, void* stream, float* out_event_ms, float* out_host_ms,
+                                        int* out_late);
 /* Same launches with one hipEvent between every two of them: out_us[i] = microseconds from the event before launch i to
  * the event after it (includes the event's own packet; the batch form above is the one the mean is taken from, this one
  * gives the distribution: median, min, max). */

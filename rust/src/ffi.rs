@@ -132,6 +132,7 @@ extern "C" {
     pub fn bu_comm_unique_id(id: *mut u8) -> c_int;
     pub fn bu_comm_create(ctx: *mut bu_context, world: c_int, rank: c_int, id: *const u8, out_comm: *mut *mut bu_comm) -> c_int;
     pub fn bu_comm_destroy(comm: *mut bu_comm);
+    pub fn bu_comm_query(comm: *mut bu_comm, out_ranks: *mut c_int, out_rank: *mut c_int) -> c_int;
     pub fn bu_allgather_inplace(comm: *mut bu_comm, d_full: *mut c_void, shard_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn bu_ipc_export(ctx: *mut bu_context, d_ptr: *mut c_void, handle: *mut u8) -> c_int;
     pub fn bu_ipc_open(ctx: *mut bu_context, handle: *const u8, d_peer: *mut *mut c_void) -> c_int;
