@@ -61,13 +61,13 @@ bu_status bu_context_create(int device, bu_context** out_ctx)
     do {
         if (hipSetDevice(device) != hipSuccess) { st = BU_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = BU_ERR_HIP; break; }
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTables)) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTablesAll)) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { st = BU_ERR_HIP; break; }
-        BuTables* h = new (std::nothrow) BuTables();
+        BuTablesAll* h = new (std::nothrow) BuTablesAll();
         if (!h) { st = BU_ERR_HIP; break; }
         bu_build_tables(h);
-        hipError_t e = hipMemcpy(ctx->d_tables, h, sizeof(BuTables), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy(ctx->d_tables, h, sizeof(BuTablesAll), hipMemcpyHostToDevice);
         delete h;
         if (e != hipSuccess) { st = BU_ERR_HIP; break; }
         // CRC tables of the device-side data CRC: registers after (byte, k zero bytes), and x^(2048 k) for the in-piece fold

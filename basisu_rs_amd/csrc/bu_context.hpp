@@ -8,7 +8,7 @@ struct bu_context {
     int device = -1;
     int cu_count = 256;
     hipStream_t stream = nullptr;
-    BuTables* d_tables = nullptr;
+    BuTablesAll* d_tables = nullptr;
     BuCrcTables* d_crc_tables = nullptr;  // bu_crc16_pieces_kernel
     void* d_in = nullptr;
     size_t in_cap = 0;

@@ -11,16 +11,22 @@ constexpr int BU_WG = 256;            // 4 waves
 constexpr int BU_SORT_MIN_BLOCKS = 8;
 
 // ------------------------------------------------------------------------------------------------
-// stage the parts of the table blob TARGET reads (bu_table_range), 16 bytes per thread per step
+// LDS image of the tables of TARGET: [BuBc7Tables (BC7 only)][BuTables up to the end of the target's ranges]
+constexpr unsigned bu_lds_front(int target) { return target == 1 ? (unsigned)sizeof(BuBc7Tables) : 0u; }
+constexpr unsigned bu_lds_table_bytes(int target) { return bu_lds_front(target) + bu_table_bytes(target); }
+// stage the parts of the table blob TARGET reads (bu_table_range; BC7: its own tables in front), 16 bytes per thread per step
 template <int WGS, int TARGET>
-__device__ __forceinline__ void bu_stage_tables_n(BuTables& dst, const BuTables* __restrict__ src)
+__device__ __forceinline__ void bu_stage_tables_n(uint4* dst, const BuTablesAll* __restrict__ src)
 {
     constexpr BuTableRange R = bu_table_range(TARGET);
-    const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4* d = reinterpret_cast<uint4*>(&dst);
-    for (int i = R.lo / 16 + threadIdx.x; i < (int)(R.hi / 16); i += WGS) d[i] = s[i];
+    constexpr int F = (int)bu_lds_front(TARGET) / 16;
+    // (for BC7 the image is the blob from its first byte; for the others it starts at BuTablesAll::t)
+    const uint4* s = reinterpret_cast<const uint4*>(TARGET == 1 ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(&src->t));
+    uint4* d = dst;
+    for (int i = threadIdx.x; i < F + (int)(R.hi / 16); i += WGS)
+        if (i < F || i >= F + (int)(R.lo / 16)) d[i] = s[i];
     if constexpr (R.lo2 < R.hi2) {
-        for (int i = R.lo2 / 16 + threadIdx.x; i < (int)(R.hi2 / 16); i += WGS) d[i] = s[i];
+        for (int i = F + R.lo2 / 16 + threadIdx.x; i < F + (int)(R.hi2 / 16); i += WGS) d[i] = s[i];
     }
 }
 
@@ -85,15 +91,15 @@ __device__ __forceinline__ void bu_st_stream(uint2* p, const uint2 v)
 template <int TARGET>
 __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
                                                          unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                         const BuTables* __restrict__ tables)
+                                                         const BuTablesAll* __restrict__ tables)
 {
-    __shared__ uint4 t_store[bu_table_bytes(TARGET) / 16];  // the front of the blob, as far as TARGET reads it
-    BuTables& T = *reinterpret_cast<BuTables*>(t_store);
+    __shared__ uint4 t_store[bu_lds_table_bytes(TARGET) / 16];  // the blob as far as TARGET reads it (BC7: its own tables in front)
+    BuTables& T = *reinterpret_cast<BuTables*>(t_store + bu_lds_front(TARGET) / 16);
     const size_t stride = (size_t)gridDim.x * BU_WG;
     size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x;
     // first block load is issued before the table copy so both are in flight together
     uint4 v = idx < n_blocks ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
-    bu_stage_tables_n<BU_WG, TARGET>(T, tables);
+    bu_stage_tables_n<BU_WG, TARGET>(t_store, tables);
     __syncthreads();
     while (idx < n_blocks) {
         const size_t next = idx + stride;
@@ -141,20 +147,6 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 //   LDS per workgroup: tile 16 B x BU_TILE + tables 5.9 KiB + 1 B x BU_TILE status + counters and the chunk list.
 // Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr),
 // BU_RUN_PIECE_MIB (piece size of the two-stream upload pipeline, 0 = off).
-// modes by descending code-path length (BC7 VALU counts), 5 bits each: entries 0-11 / 12-19
-constexpr unsigned long long bu_cost_pack(int from, int n)
-{
-    unsigned long long v = 0;
-    for (int i = 0; i < n; i++) v |= (unsigned long long)BU_COST_ORDER[from + i] << (5 * i);
-    return v;
-}
-constexpr unsigned long long BU_COST_ORDER_LO = bu_cost_pack(0, 12), BU_COST_ORDER_HI = bu_cost_pack(12, 8);
-static_assert(BU_COST_ORDER_LO == 0x2c8cb0b0e281123ull && BU_COST_ORDER_HI == 0x9bdb1401caull, "cost order moved");
-// mode of sort key k (scalar)
-__device__ __forceinline__ uint32_t bu_mode_of_key(uint32_t k)
-{
-    return (uint32_t)((k < 12 ? (BU_COST_ORDER_LO >> (5 * k)) : (BU_COST_ORDER_HI >> (5 * (k - 12)))) & 31u);
-}
 // inclusive add-scan over lanes 0..31 (and 32..63) with DPP row shifts: 5 VALU, no LDS round trips
 __device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
 {
@@ -231,7 +223,7 @@ struct BuBigCfg<BU_TGT_ASTC> {
 template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                                const BuTables* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
+                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
 {
     BU_STAMP_DECL
     BU_STAMP(0)
@@ -252,8 +244,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         if (gen >= 3) __builtin_amdgcn_s_setprio(3);
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
-    __shared__ uint4 t_store[bu_table_bytes(TARGET) / 16];  // the front of the blob, as far as TARGET reads it
-    BuTables& T = *reinterpret_cast<BuTables*>(t_store);
+    __shared__ uint4 t_store[bu_lds_table_bytes(TARGET) / 16];  // the blob as far as TARGET reads it (BC7: its own tables in front)
+    BuTables& T = *reinterpret_cast<BuTables*>(t_store + bu_lds_front(TARGET) / 16);
     // RGBA32 through LDS: four pixel rows of 16 B per block, stored row-major by row index so that both the
     // sorted-order writes and the original-order reads are 16-byte strided (no bank conflicts).  The sorted input tile
     // lives IN row 0 of that output tile: a lane reads its block from slot s and later overwrites exactly slot s with
@@ -261,12 +253,15 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // which is what lets two workgroups share a CU.
     constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
-    static_assert(!BU_ALIAS || bu_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
+    static_assert(!BU_ALIAS || bu_lds_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
                   "the RGBA32 workgroup no longer fits twice per CU: shrink BuTables or stage it per target in LDS too");
     __shared__ uint4 sblk_store[BU_ALIAS ? 1 : BU_TILE];
     __shared__ uint4 sout[BU_ALIAS ? 4 * BU_TILE : 1];
     uint4* const sblk = BU_ALIAS ? sout : sblk_store;
-    __shared__ uint8_t sst[DIRECT ? 16 : BU_TILE];
+    // BC7 and ASTC carry a failing block's status inside its result slot (a valid block of either format has a non-zero first
+    // byte: BC7's unary mode prefix, ASTC's block mode / void-extent marker), the other targets in a byte per block
+    constexpr bool INBLOCK = (TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC) && !DIRECT;
+    __shared__ uint8_t sst[(DIRECT || INBLOCK) ? 16 : BU_TILE];
     __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
     // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
     // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
@@ -282,31 +277,47 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     const unsigned n_tiles = (n_blocks + tile_blocks - 1) / tile_blocks;  // 32-bit indices: the host splits launches above 2^26 blocks
     auto in_tile = [&](unsigned l) { return !DYN_TILE || l < tile_blocks; };
     unsigned tile = blockIdx.x;
+    // Table staging.  The staged 16-byte pieces of the LDS image are numbered 0..TVT-1: BC7's own tables, then the target's one or
+    // two ranges of the common blob; piece i sits at t_store[tdst(i)] and comes from the same index of the image's source in device
+    // memory.  Every thread issues ALL its table loads back to back (round 2 ran a load / wait / store loop: a second L2 round
+    // trip per 8 KiB of tables in front of the first barrier) and, where the image is small, BEFORE the tile's block loads.
+    // Images above 16 KiB (ETC: 26.6 KiB) go tile loads first, only key_lut (128 B: all the sort phases read) staged up front, the
+    // rest held in registers until the first tile's rank atomics are out (A/B: ETC1 19.45 -> 19.0 us in round 2; tables first
+    // 19.2 -> 19.8 in round 3).
+    constexpr BuTableRange TR = bu_table_range(TARGET);
+    constexpr bool SPLIT = bu_lds_table_bytes(TARGET) > 16384;
+    constexpr int TF = (int)bu_lds_front(TARGET) / 16, TV1 = (int)(TR.hi - TR.lo) / 16, TV2 = TR.lo2 < TR.hi2 ? (int)(TR.hi2 - TR.lo2) / 16 : 0;
+    constexpr int TVT = TF + TV1 + TV2, TVN = (TVT + WGS - 1) / WGS;
+    const uint4* const tsrc = reinterpret_cast<const uint4*>(TARGET == BU_TGT_BC7 ? reinterpret_cast<const void*>(tables) : reinterpret_cast<const void*>(&tables->t));
+    auto tdst = [&](int i) { return i < TF ? i : (i < TF + TV1 ? (int)(TR.lo / 16) + i : TF + (int)(TR.lo2 / 16) + (i - TF - TV1)); };
+    uint4 tv[TVN];
+    if constexpr (!SPLIT) {
+#pragma unroll
+        for (int k = 0; k < TVN; k++) {
+            const int i = k * WGS + (int)tid;
+            tv[k] = i < TVT ? tsrc[tdst(i)] : make_uint4(0, 0, 0, 0);
+        }
+    }
     uint4 v[BU_BPT];
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++) {
         const unsigned idx = tile * tile_blocks + j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
-    // Table staging in two steps.  The sort phases read only key_lut (128 B): that goes to LDS now.  Everything else is first
-    // read in the chunk phase; its loads are issued here, behind the block loads, and stay in registers until the first tile's
-    // rank atomics are out -- the copy (26.6 KiB per workgroup for ETC) leaves the path to the first sorted tile.
-    // Only where the copy is big (ETC: A/B ETC1 19.45 -> 19.0 us); with the 6-8 KiB of BC7 / ASTC the registers it holds through
-    // the rank phase cost more than the copy (BC7 10.13 -> 10.25), those stage everything up front.
-    constexpr BuTableRange TR = bu_table_range(TARGET);
-    constexpr bool SPLIT = bu_table_bytes(TARGET) > 16384;
-    constexpr int TV1 = (int)(TR.hi - TR.lo) / 16, TV2 = TR.lo2 < TR.hi2 ? (int)(TR.hi2 - TR.lo2) / 16 : 0, TVN = SPLIT ? (TV1 + TV2 + WGS - 1) / WGS : 1;
-    uint4 tv[TVN];
-    if constexpr (!SPLIT) bu_stage_tables_n<WGS, TARGET>(T, tables);
-    else {
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < TVN; k++) {
-        const int i = k * WGS + (int)tid;
-        const int src = i < TV1 ? (int)(TR.lo / 16) + i : (int)(TR.lo2 / 16) + (i - TV1);
-        tv[k] = i < TV1 + TV2 ? reinterpret_cast<const uint4*>(tables)[src] : make_uint4(0, 0, 0, 0);
-    }
-    static_assert(offsetof(BuTables, key_lut) % 4 == 0 && sizeof(T.key_lut) == 128, "key_lut is staged as 32 dwords");
-    if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut)[tid] = reinterpret_cast<const uint32_t*>(tables->key_lut)[tid];
+        for (int k = 0; k < TVN; k++) {
+            const int i = k * WGS + (int)tid;
+            if (i < TVT) t_store[tdst(i)] = tv[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TVN; k++) {
+            const int i = k * WGS + (int)tid;
+            tv[k] = i < TVT ? tsrc[tdst(i)] : make_uint4(0, 0, 0, 0);
+        }
+        static_assert(offsetof(BuTables, key_lut) % 4 == 0 && sizeof(T.key_lut) == 128, "key_lut is staged as 32 dwords");
+        if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut)[tid] = reinterpret_cast<const uint32_t*>(tables->t.key_lut)[tid];
     }
     bool tables_staged = !SPLIT;
     if (tid < 64) (&cnt[0][0])[tid] = 0;
@@ -344,8 +355,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int k = 0; k < TVN; k++) {
                 const int i = k * WGS + (int)tid;
-                const int dst = i < TV1 ? (int)(TR.lo / 16) + i : (int)(TR.lo2 / 16) + (i - TV1);
-                if (i < TV1 + TV2) reinterpret_cast<uint4*>(&T)[dst] = tv[k];
+                if (i < TVT) t_store[tdst(i)] = tv[k];
             }
             tables_staged = true;
         }
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             const uint32_t r = (uint32_t)__builtin_ctzll(__ballot((run_incl >> 16) > c));
             const uint32_t r_pk = (uint32_t)__builtin_amdgcn_readlane((int)run_pk, (int)r), r_ex = (uint32_t)__builtin_amdgcn_readlane((int)run_excl, (int)r);
             const uint32_t k64 = (c - (r_ex >> 16)) << 6;
-            const uint32_t m = bu_mode_of_key(r), s0 = (r_ex & 0xFFFFu) + k64, left = (r_pk & 0xFFFFu) - k64, count = left < 64u ? left : 64u;
+            const uint32_t s0 = (r_ex & 0xFFFFu) + k64, left = (r_pk & 0xFFFFu) - k64, count = left < 64u ? left : 64u;
             const bool active = lane < count;
             const uint32_t slot = s0 + (active ? lane : 0u);
             const uint4 bv = sblk[slot];
@@ -414,9 +424,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             for (int i = 0; i < NO; i++) o[i] = 0;
             int st = BU_ST_BAD_MODE;
             if (active) {
-                switch (m) {
+                switch (r) {  // the run number IS the sort key: run k holds mode BU_COST_ORDER[k] (run 19: invalid mode codes)
 #define BU_CASE(k) \
-    case k: st = bu_block_mode<TARGET, k>(T, b, o); break;
+    case k: st = bu_block_mode<TARGET, BU_COST_ORDER[k]>(T, b, o); break;
                     BU_CASE(0) BU_CASE(1) BU_CASE(2) BU_CASE(3) BU_CASE(4) BU_CASE(5) BU_CASE(6) BU_CASE(7) BU_CASE(8) BU_CASE(9)
                     BU_CASE(10) BU_CASE(11) BU_CASE(12) BU_CASE(13) BU_CASE(14) BU_CASE(15) BU_CASE(16) BU_CASE(17) BU_CASE(18)
 #undef BU_CASE
@@ -440,6 +450,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
                     for (int r2 = 0; r2 < 4; r2++) sout[r2 * BU_TILE + slot] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
                     sst[slot] = (uint8_t)st;
+                } else if constexpr (INBLOCK) {
+                    sblk[slot] = make_uint4(o[0], o[1], o[2], o[3] | (uint32_t)st);  // (a failing block's o[] is all zeros)
                 } else {
                     sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
                     sst[slot] = (uint8_t)st;
@@ -455,6 +467,15 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             for (int j = 0; j < BU_BPT; j++) {
                 if (key[j] < 20u) {
                     const unsigned idx = tbase + j * BU_WG + tid;
+                    if constexpr (INBLOCK) {
+                        uint4 r = sblk[dest[j]];
+                        if ((r.x & 0xFFu) == 0u) {  // no valid block of these formats starts with a zero byte: word 3 is the status
+                            bu_report(status, base + idx, (int)r.w);
+                            r.w = 0;
+                        }
+                        bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
+                        continue;
+                    }
                     const uint32_t st = sst[dest[j]];
                     if (st) bu_report(status, base + idx, (int)st);
                     if constexpr (TARGET == BU_TGT_RGBA) {
@@ -598,10 +619,10 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
                                                               unsigned nbx, size_t n_blocks, const uint32_t* __restrict__ endpoints,
                                                               uint32_t n_ep, const uint2* __restrict__ selectors, uint32_t n_sel,
                                                               uint4* __restrict__ out, unsigned long long* status,
-                                                              const BuTables* __restrict__ tables)
+                                                              const BuTablesAll* __restrict__ tables)
 {
     __shared__ int16_t mods[32];
-    if (threadIdx.x < 32) mods[threadIdx.x] = tables->etc1_mod[threadIdx.x];
+    if (threadIdx.x < 32) mods[threadIdx.x] = tables->t.etc1_mod[threadIdx.x];
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * BU_WG;
     for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
@@ -671,11 +692,11 @@ template <bool RGBA>
 __global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __restrict__ idx, const BuEtc1sSlice* __restrict__ slices, uint32_t n_slices,
                                                               uint32_t n_units, const uint32_t* __restrict__ endpoints, uint32_t n_ep,
                                                               const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
-                                                              unsigned long long* status, const BuTables* __restrict__ tables)
+                                                              unsigned long long* status, const BuTablesAll* __restrict__ tables)
 {
     __shared__ int16_t mods[32];
     if constexpr (RGBA) {
-        if (threadIdx.x < 32) mods[threadIdx.x] = tables->etc1_mod[threadIdx.x];
+        if (threadIdx.x < 32) mods[threadIdx.x] = tables->t.etc1_mod[threadIdx.x];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u, wpg = BU_WG / 64;

@@ -36,6 +36,22 @@ struct BuPart {  // one UASTC partition pattern (layout documented in bu_tables.
     uint8_t bpart, perm;
 };
 static_assert(sizeof(BuPart) == 16, "BuPart must be 16 bytes");
+// The BC7 packer's own view of a partition pattern: everything bu_block_bc7 derives from a BuPart at run time (anchor bit
+// positions, sorted deletion order, placement shifts), precomputed on the host.  "Label" = which format's subset numbering
+// the record speaks: BC7's for the 2-subset patterns [0,30), the mode-7 family [41,60) and the mode-1 record 60; UASTC's for
+// the 3-subset family [30,41) (UASTC mode 3 places whole per-subset endpoint fields with a variable shift, so its subsets keep
+// their UASTC numbers and only the field position knows about BC7's order).  All bit positions are for 2-bit weights
+// (2 * texel + 1 = the weight's MSB) unless stated.
+struct BuPart7 {
+    uint32_t pat;  // subset of every texel in the record's label, 2 bits per texel, texel 0 low
+    uint32_t pos;  // 5-bit fields: [0] uq_lo, [5] uq_hi: MSB positions of the UASTC anchors other than texel 0, ascending (31 = none)
+                   //   [10] dq_hi, [15] dq_lo: MSB positions of the BC7 anchors other than texel 0, DEscending (dq_lo 0 = none)
+                   //   [20] aq_0, [25] aq_1: MSB position of the BC7 anchor of subset 0 / 1 of the label
+    uint32_t aux;  // [0:5) aq_2, [5:11) BC7 partition id, [11:16) sh_0, [16:21) sh_1, [21:26) sh_2: 10 x the BC7 slot of UASTC
+                   //   subset s (family [30,41) only), [26:32) UASTC source subset of BC7 subset j, 2 bits each (bc7.rs:144)
+    uint32_t w3;   // 3-bit weights (UASTC mode 2, patterns [0,30)): [0:6) 3 * ua + 2 (the UASTC anchor's MSB), [6:12) 3 * a1 + 2 (BC7's)
+};
+static_assert(sizeof(BuPart7) == 16, "BuPart7 must be 16 bytes");
 struct BuU2 {
     uint32_t x, y;
 };
@@ -64,7 +80,9 @@ static_assert(31u * BU_Q_M < (1u << 24), "the quantiser runs on v_mad_u32_u24");
 // runs out in this order so that dynamically scheduled chunks end with the cheap ones.  Entry 19 = invalid mode code.
 constexpr uint8_t BU_COST_ORDER[20] = {3, 9, 4, 16, 2, 7, 12, 1, 11, 6, 18, 5, 10, 14, 0, 8, 17, 13, 15, 19};
 
-struct BuTables {
+// The BC7 packer's own tables (bu_uastc_bc7.hpp).  They sit IN FRONT of the common blob, in device memory and in the LDS of the
+// BC7 kernels alike (BuTablesAll), so that only BC7 reserves and stages them; bu_bc7_tables() steps back from the common blob.
+struct BuBc7Tables {
     // ---- BC7 only ----
     alignas(16) uint8_t deq5[56];  // (deq*31+127)/255 for ranges 7 (ofs 0) and 12 (ofs 16): BC7 mode 2 endpoints (bc7.rs:262-264)
     uint32_t w3mask[30][2];  // 2-subset patterns, BC7 subset-1 texel mask at 3 bits/texel (48 bits)
@@ -73,13 +91,29 @@ struct BuTables {
     uint16_t m5opt[256];   // BC7 mode 5 solid colour lo | hi<<8 (bc7.rs:734-863)
     uint16_t m6opt[258];   // BC7 mode 6 solid colour lo | hi<<8, index c + !p (bc7.rs:866-1136)
     uint8_t w5to4x2[1024];    // two 5-bit weights (10 bits) -> two 4-bit BC7 weights, x>>1 except 14 -> 6 and 17 -> 9 (bc7.rs:381-384)
+    BuPart7 part7[61];        // the BC7 packer's partition records (same indexing as `part`)
+    // BISE range 7 endpoint PAIR (lo, hi) of one channel -> BC7 mode 2's two 5-bit fields (UASTC mode 3): index = eb_lo | eb_hi << 2 |
+    // tq_lo << 4 | tq_hi << 6; value = (lo5 | hi5 << 5) | (hi5 | lo5 << 5) << 16, the swapped pair for an inverted subset
+    uint32_t pair7x[256];
+    // 4-bit endpoint PAIR (lo, hi) of one channel -> BC7 mode 1 (6 bits + p-bit shared by the subset's six values; UASTC mode 2):
+    // index = lo | hi << 4 (+ 256: swapped), value = q0_lo | q0_hi << 6 | q1_lo << 12 | q1_hi << 18 (the 6-bit fields for p = 0 / 1)
+    // | (8 + err1 - err0) << 24, err_p = the pair's summed squared error of 17 * v under p-bit p (at most 4 per value): the subset takes
+    // p = 1 iff the three channels' bytes sum to less than 24 (bc7.rs:408-475: strictly smaller error, ties -> 0)
+    uint32_t pair4m1[512];
+    // 4-bit endpoint PAIR (lo, hi) of one channel -> BC7 mode 7 (5 bits + one p-bit per endpoint; UASTC mode 9): index = lo | hi << 4,
+    // x = q0_lo | q1_lo << 5 | q0_hi << 10 | q1_hi << 15, y = err0_lo | err1_lo << 8 | err0_hi << 16 | err1_hi << 24
+    BuU2 pair4m7[256];
+};
+static_assert(sizeof(BuBc7Tables) % 16 == 0, "staged in 16-byte pieces, and the common blob behind it stays 16-byte aligned");
+
+struct BuTables {
     // ---- common front-end (every target) ----
     alignas(16) uint16_t trit5[256];  // 8-bit group -> 5 trits, digit i in bits [2i,2i+2)   (uastc.rs:657-685)
     uint16_t quint3[128];  // 7-bit group -> 3 quints, digit i in bits [3i,3i+3)  (uastc.rs:629-655)
     uint8_t deq[504];      // endpoint dequantisation, ranges 7,8,11,12,13,18,19  (uastc.rs:585-614)
     uint8_t mode_lut[128];    // uastc.rs:560-577
     uint8_t key_lut[128];     // sort key of the mode-sorted kernel: position of the block's mode in BU_COST_ORDER (19 = invalid code)
-    BuPart part[61];       // partition records
+    alignas(16) BuPart part[61];  // partition records (every target but BC7, which reads part7: last of the group, outside BC7's range)
     // ---- texel unpack (RGBA32, ETC1, ETC2) ----
     alignas(16) uint32_t wpack[64];  // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
     // ---- ASTC only ----
@@ -116,6 +150,11 @@ struct BuTables {
     alignas(16) uint8_t end_marker[16];
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
+struct BuTablesAll {  // the device blob: one allocation, one kernel argument
+    BuBc7Tables b7;
+    BuTables t;
+};
+static_assert(offsetof(BuTablesAll, t) == sizeof(BuBc7Tables), "bu_bc7_tables() steps back by sizeof(BuBc7Tables)");
 
 // byte ranges [lo, hi) of BuTables a target reads (target ids as in bu_uastc_dispatch.hpp: 0 ASTC, 1 BC7, 2 ETC1, 3 ETC2,
 // 4 RGBA32); a second range is empty unless lo2 < hi2.  All bounds are multiples of 16.
@@ -124,7 +163,7 @@ struct BuTableRange {
 };
 constexpr BuTableRange bu_table_range(int target)
 {
-    return target == 1   ? BuTableRange{(unsigned)offsetof(BuTables, deq5), (unsigned)offsetof(BuTables, wpack), 0u, 0u}
+    return target == 1   ? BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, part), 0u, 0u}
            : target == 0 ? BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, etc1_mod), 0u, 0u}
            : target == 4 ? BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, w3mask_u), 0u, 0u}
                          : BuTableRange{(unsigned)offsetof(BuTables, trit5), (unsigned)offsetof(BuTables, w3mask_u),
@@ -159,9 +198,11 @@ static inline int bu_etc1_bias1_host(int v, int delta, int limit)
     return (m < 0 || m > limit) ? v - delta : m;
 }
 
-static inline void bu_build_tables(BuTables* t)
+static inline void bu_build_tables(BuTablesAll* all)
 {
-    memset(t, 0, sizeof(*t));
+    memset(all, 0, sizeof(*all));
+    BuTables* t = &all->t;
+    BuBc7Tables* b7 = &all->b7;
     for (int r = 0; r < 256; r++) {
         uint8_t v = (uint8_t)r;
         uint16_t packed = 0;
@@ -187,8 +228,8 @@ static inline void bu_build_tables(BuTables* t)
         int n = (BU_BISE[r].trits ? 3 : BU_BISE[r].quints ? 5 : 1) << BU_BISE[r].bits;
         for (int i = 0; i < n; i++) t->deq[bu_deq_ofs(r) + i] = BU_ENDPOINT_DEQ[8 * BU_BISE[r].lut_ofs_div8 + i];
     }
-    for (int i = 0; i < 12; i++) t->deq5[i] = (uint8_t)((t->deq[bu_deq_ofs(7) + i] * 31 + 127) / 255);
-    for (int i = 0; i < 40; i++) t->deq5[16 + i] = (uint8_t)((t->deq[bu_deq_ofs(12) + i] * 31 + 127) / 255);
+    for (int i = 0; i < 12; i++) b7->deq5[i] = (uint8_t)((t->deq[bu_deq_ofs(7) + i] * 31 + 127) / 255);
+    for (int i = 0; i < 40; i++) b7->deq5[16 + i] = (uint8_t)((t->deq[bu_deq_ofs(12) + i] * 31 + 127) / 255);
     for (int i = 0; i < 61; i++) {
         t->part[i].upat = BU_PART[i].upat;
         t->part[i].bpat = BU_PART[i].bpat;
@@ -198,28 +239,73 @@ static inline void bu_build_tables(BuTables* t)
         t->part[i].bpart = BU_PART[i].bpart;
         t->part[i].perm = BU_PART[i].perm;
     }
+    for (int i = 0; i < 61; i++) {
+        const bool three = i >= BU_PART_BASE3 && i < BU_PART_BASE23;  // UASTC label
+        const int nb = (i < BU_PART_BASE3 || i == BU_PART_MODE1) ? 2 : 3;       // BC7 subsets
+        const int nu = i == BU_PART_MODE1 ? 1 : (i < BU_PART_BASE3 || i >= BU_PART_BASE23) ? 2 : 3;  // UASTC subsets
+        int ua[3], ba[3], src[3], slot[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) {
+            ua[k] = (BU_PART[i].uanch >> (4 * k)) & 15;
+            ba[k] = (BU_PART[i].banch >> (4 * k)) & 15;
+            src[k] = (BU_PART[i].perm >> (2 * k)) & 3;
+        }
+        for (int j = 0; j < nb; j++)
+            if (src[j] < 3) slot[src[j]] = j;  // (the 3-subset family's perm is a bijection)
+        int un[2] = {31, 31}, n = 0;  // UASTC anchors other than texel 0, ascending
+        for (int k = 0; k < nu; k++)
+            if (ua[k]) un[n++] = 2 * ua[k] + 1;
+        if (n == 2 && un[0] > un[1]) { const int x = un[0]; un[0] = un[1]; un[1] = x; }
+        int dn[2] = {0, 0};  // BC7 anchors other than texel 0, descending
+        n = 0;
+        for (int j = 1; j < nb; j++) dn[n++] = 2 * ba[j] + 1;
+        if (n == 2 && dn[0] < dn[1]) { const int x = dn[0]; dn[0] = dn[1]; dn[1] = x; }
+        int aq[3];
+        for (int k = 0; k < 3; k++) aq[k] = three ? 2 * ba[slot[k]] + 1 : 2 * ba[k] + 1;
+        BuPart7& r = b7->part7[i];
+        r.pat = three ? BU_PART[i].upat : BU_PART[i].bpat;
+        r.pos = (uint32_t)un[0] | (uint32_t)un[1] << 5 | (uint32_t)dn[0] << 10 | (uint32_t)dn[1] << 15 | (uint32_t)aq[0] << 20 | (uint32_t)aq[1] << 25;
+        r.aux = (uint32_t)aq[2] | (uint32_t)BU_PART[i].bpart << 5 | (uint32_t)(10 * slot[0]) << 11 | (uint32_t)(10 * slot[1]) << 16 |
+                (uint32_t)(10 * slot[2]) << 21 | (uint32_t)(BU_PART[i].perm & 63u) << 26;
+        r.w3 = i < BU_PART_BASE3 ? (uint32_t)(3 * (ua[0] | ua[1]) + 2) | (uint32_t)(3 * ba[1] + 2) << 6 : 0u;
+    }
+    for (int i = 0; i < 256; i++) {
+        const int el = i & 3, eh = (i >> 2) & 3, tl = (i >> 4) & 3, th = (i >> 6) & 3;
+        const uint32_t lo5 = b7->deq5[(tl << 2) | el], hi5 = b7->deq5[(th << 2) | eh];
+        b7->pair7x[i] = (tl < 3 && th < 3) ? ((lo5 | hi5 << 5) | (hi5 | lo5 << 5) << 16) : 0u;
+    }
     for (int i = 0; i < 30; i++) {
         uint64_t m = 0;
         for (int tx = 0; tx < 16; tx++)
             if ((BU_PART[i].bpat >> (2 * tx)) & 1) m |= 7ull << (3 * tx);
-        t->w3mask[i][0] = (uint32_t)m;
-        t->w3mask[i][1] = (uint32_t)(m >> 32);
+        b7->w3mask[i][0] = (uint32_t)m;
+        b7->w3mask[i][1] = (uint32_t)(m >> 32);
     }
     for (int x = 0; x < 256; x++) {  // 6 total bits (BC7 mode 7)
         int q0 = bu_quant_p(x, 63, 0), q1 = bu_quant_p(x, 63, 1);
         int s0 = ((q0 << 2) | (q0 >> 4)) & 255, s1 = ((q1 << 2) | (q1 >> 4)) & 255;
         int e0 = (s0 - x) * (s0 - x), e1 = (s1 - x) * (s1 - x);
-        t->pbit6[x] = (uint32_t)(q0 >> 1) | (uint32_t)(q1 >> 1) << 8 | (uint32_t)e0 << 16 | (uint32_t)e1 << 24;
+        b7->pbit6[x] = (uint32_t)(q0 >> 1) | (uint32_t)(q1 >> 1) << 8 | (uint32_t)e0 << 16 | (uint32_t)e1 << 24;
     }
     for (int i = 0; i < 16; i++) {  // 7 total bits (BC7 mode 1), inputs are multiples of 17
         int x = 17 * i;
         int q0 = bu_quant_p(x, 127, 0), q1 = bu_quant_p(x, 127, 1);
         int s0 = ((q0 << 1) | (q0 >> 6)) & 255, s1 = ((q1 << 1) | (q1 >> 6)) & 255;
         int e0 = (s0 - x) * (s0 - x), e1 = (s1 - x) * (s1 - x);
-        t->pbit7[i] = (uint32_t)(q0 >> 1) | (uint32_t)(q1 >> 1) << 8 | (uint32_t)e0 << 16 | (uint32_t)e1 << 24;
+        b7->pbit7[i] = (uint32_t)(q0 >> 1) | (uint32_t)(q1 >> 1) << 8 | (uint32_t)e0 << 16 | (uint32_t)e1 << 24;
     }
-    for (int i = 0; i < 256; i++) t->m5opt[i] = BU_BC7_M5_OPT[i];
-    for (int i = 0; i < 257; i++) t->m6opt[i] = BU_BC7_M6_OPT[i];
+    for (int i = 0; i < 512; i++) {
+        const int a = (i & 256) ? (i >> 4) & 15 : i & 15, b = (i & 256) ? i & 15 : (i >> 4) & 15;  // (lo, hi), swapped above 256
+        const uint32_t ea = b7->pbit7[a], eb = b7->pbit7[b];
+        const uint32_t e0 = ((ea >> 16) & 255u) + ((eb >> 16) & 255u), e1 = (ea >> 24) + (eb >> 24);
+        b7->pair4m1[i] = (ea & 63u) | (eb & 63u) << 6 | ((ea >> 8) & 63u) << 12 | ((eb >> 8) & 63u) << 18 | (8u + e1 - e0) << 24;
+    }
+    for (int i = 0; i < 256; i++) {
+        const uint32_t ea = b7->pbit6[17 * (i & 15)], eb = b7->pbit6[17 * (i >> 4)];
+        b7->pair4m7[i].x = (ea & 31u) | ((ea >> 8) & 31u) << 5 | (eb & 31u) << 10 | ((eb >> 8) & 31u) << 15;
+        b7->pair4m7[i].y = ((ea >> 16) & 255u) | (ea >> 24) << 8 | ((eb >> 16) & 255u) << 16 | (eb >> 24) << 24;
+    }
+    for (int i = 0; i < 256; i++) b7->m5opt[i] = BU_BC7_M5_OPT[i];
+    for (int i = 0; i < 257; i++) b7->m6opt[i] = BU_BC7_M6_OPT[i];
     for (int i = 0; i < 243; i++) t->astc_trit[i] = BU_ASTC_TRIT_ENC[i];
     for (int i = 0; i < 125; i++) t->astc_quint[i] = BU_ASTC_QUINT_ENC[i];
     for (int i = 0; i < 20; i++) t->astc_mode13[i] = BU_ASTC_BLOCK_MODE13[i];
@@ -328,7 +414,7 @@ static inline void bu_build_tables(BuTables* t)
     for (int i = 0; i < 1024; i++) {
         const int a = i & 31, b = i >> 5;
         const int va = (a >> 1) - (a == 14) + (a == 17), vb = (b >> 1) - (b == 14) + (b == 17);
-        t->w5to4x2[i] = (uint8_t)(va | (vb << 4));
+        b7->w5to4x2[i] = (uint8_t)(va | (vb << 4));
     }
     for (int bits = 1; bits <= 5; bits++)
         for (int r = 0; r < (1 << bits); r++) {

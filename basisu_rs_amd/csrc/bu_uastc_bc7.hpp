@@ -11,6 +11,12 @@
 #pragma once
 #include "bu_uastc_front.hpp"
 
+// the BC7 tables of a common blob that lives inside a BuTablesAll (the BC7 kernels' LDS image, the host build's global)
+BU_DEV const BuBc7Tables& bu_bc7_tables(const BuTables& T)
+{
+    return *reinterpret_cast<const BuBc7Tables*>(reinterpret_cast<const unsigned char*>(&T) - sizeof(BuBc7Tables));
+}
+
 // UASTC mode -> BC7 mode (bc7.rs:582-589)
 constexpr int BU_BC7_OF[19] = {6, 3, 1, 2, 3, 6, 5, 2, -1, 7, 6, 5, 6, 5, 6, 6, 7, 5, 6};
 
@@ -62,6 +68,51 @@ BU_DEV uint64_t bu_del_rt64(uint64_t x, uint32_t q)
 }
 BU_DEV uint32_t bu_sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
 
+// v_bfe_u32 / v_bfe_i32 with a run-time offset (offset and width use their low five bits)
+BU_DEV uint32_t bu_ubfe(uint32_t v, uint32_t ofs, uint32_t n)
+{
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_ubfe(v, ofs, n);
+#else
+    return (v >> (ofs & 31u)) & ((1u << n) - 1u);
+#endif
+}
+// all-ones if bit `ofs` of v is set
+BU_DEV uint32_t bu_sbfe1(uint32_t v, uint32_t ofs)
+{
+#if defined(__HIPCC__)
+    return (uint32_t)__builtin_amdgcn_sbfe((int)v, ofs, 1u);
+#else
+    return 0u - ((v >> (ofs & 31u)) & 1u);
+#endif
+}
+// four 7-bit fields sitting in the four bytes of x -> one 28-bit string, byte 0 lowest: two v_dot4 (weights 1, 128 on a byte pair)
+// and a shift-or
+BU_DEV uint32_t bu_pack7x4(uint32_t x) { return bu_udot4(x, 0x00008001u, 0u) | (bu_udot4(x, 0x80010000u, 0u) << 14); }
+
+// ---- multi-subset index strings (2-bit weights) ------------------------------------------------------------------------------
+// W: the regularised UASTC weight string (bu_decode_weights).  Every subset whose BC7 anchor weight has its MSB set is inverted
+// (its weights complemented here, its endpoints swapped by the caller: k[s] = all-ones) and the anchors' MSBs, now zero, are
+// squeezed out, highest position first (bc7.rs:171-195, 296-307).  NS = subsets in the record's label; AQ0 = true: subset 0's
+// anchor is texel 0 (BC7 labels), false: read it from the record (UASTC labels).
+template <int NS, bool AQ0>
+BU_DEV uint32_t bu_bc7_index2(uint32_t W, const BuPart7& pr, uint32_t k[3])
+{
+    k[0] = AQ0 ? bu_sbfe1(W, 1u) : bu_sbfe1(W, pr.pos >> 20);
+    k[1] = bu_sbfe1(W, pr.pos >> 25);
+    k[2] = NS == 3 ? bu_sbfe1(W, pr.aux) : 0u;
+    const uint32_t m1 = (pr.pat & 0x55555555u) * 3u;
+    if constexpr (NS == 3) {
+        const uint32_t m2 = ((pr.pat >> 1) & 0x55555555u) * 3u;
+        W ^= (k[0] & ~(m1 | m2)) | (k[1] & m1) | (k[2] & m2);
+    } else {
+        W ^= (k[1] & m1) | (k[0] & ~m1);
+    }
+    W = bu_del_rt32(W, (pr.pos >> 10) & 31u);
+    if constexpr (NS == 3) W = bu_del_rt32(W, (pr.pos >> 15) & 31u);
+    return (W & 1u) | ((W >> 1) & ~1u);
+}
+
 // ---- p-bit selection ---------------------------------------------------------------------------
 // determine_unique_pbits (bc7.rs:478-553) for 8 total bits (BC7 modes 3 and 6), one endpoint, all
 // channels at once on the packed RGBA word.  With S = 255 the reference's quantiser reduces to
@@ -83,6 +134,17 @@ BU_DEV uint32_t bu_pbit8(uint32_t c, uint32_t* p)
     return p1 ? half : q0;
 }
 
+// the same for three components with the p-bit returned in byte 3 of the result (c's byte 3 must be 0): the four bytes then
+// travel together through the byte transposes of the BC7 mode 3 emitter
+BU_DEV uint32_t bu_pbit8p3(uint32_t c)
+{
+    const uint32_t odd = bu_popc(c & 0x00010101u);
+    const uint32_t half = (c >> 1) & 0x7F7F7F7Fu;
+    uint32_t q0 = half + (c & 0x01010101u);
+    q0 -= (q0 >> 7) & 0x01010101u;
+    return 3u < 2u * odd ? (half | 0x01000000u) : q0;
+}
+
 // ---- emit helpers ------------------------------------------------------------------------------
 BU_DEV uint32_t bu_byte(uint32_t c, int ch) { return (c >> (8 * ch)) & 0xFFu; }
 // four W-bit fields sitting in the four bytes of x -> one 4W-bit string, byte 0 lowest (two SWAR squeezes:
@@ -99,6 +161,7 @@ BU_DEV uint32_t bu_pack4(uint32_t x)
 template <int M>
 BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
 {
+    const BuBc7Tables& T7 = bu_bc7_tables(T);
     out[0] = out[1] = out[2] = out[3] = 0;
     if constexpr (M == 8) {
         // ---- solid colour (bc7.rs:18-59, 312-375) ----
@@ -109,27 +172,287 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
         const bool has0 = (((c - 0x01010101u) & nc) & 0x80808080u) != 0u, has255 = (((nc - 0x01010101u) & c) & 0x80808080u) != 0u;
         if (has0 && has255) {
             // BC7 mode 5: colour weights all 1, alpha weights all 0, rotation 0
-            const uint32_t rg = (uint32_t)T.m5opt[bu_byte(c, 0)] | ((uint32_t)T.m5opt[bu_byte(c, 1)] << 16);  // bytes R0 R1 G0 G1
-            const uint32_t bl = T.m5opt[bu_byte(c, 2)];
+            const uint32_t rg = (uint32_t)T7.m5opt[bu_byte(c, 0)] | ((uint32_t)T7.m5opt[bu_byte(c, 1)] << 16);  // bytes R0 R1 G0 G1
+            const uint32_t bl = T7.m5opt[bu_byte(c, 2)];
             bu_put(out, 0, 6, 1u << 5);
-            bu_put(out, 8, 28, bu_pack4<7>(rg));
+            bu_put(out, 8, 28, bu_pack7x4(rg));
             bu_put(out, 36, 14, (bl & 0x7Fu) | ((bl >> 1) & 0x3F80u));
             bu_put(out, 50, 16, (c >> 24) * 0x0101u);
             bu_put(out, 66, 1, 1u);               // anchor: 1 bit
             bu_put(out, 67, 30, 0x15555555u);     // 15 x 0b01
         } else {
             const uint32_t p = (has255 && !has0) ? 1u : 0u, ofs = p ^ 1u;  // best_err1 < best_err0
-            const uint32_t rg = (uint32_t)T.m6opt[bu_byte(c, 0) + ofs] | ((uint32_t)T.m6opt[bu_byte(c, 1) + ofs] << 16);
-            const uint32_t ba = (uint32_t)T.m6opt[bu_byte(c, 2) + ofs] | ((uint32_t)T.m6opt[bu_byte(c, 3) + ofs] << 16);
+            const uint32_t rg = (uint32_t)T7.m6opt[bu_byte(c, 0) + ofs] | ((uint32_t)T7.m6opt[bu_byte(c, 1) + ofs] << 16);
+            const uint32_t ba = (uint32_t)T7.m6opt[bu_byte(c, 2) + ofs] | ((uint32_t)T7.m6opt[bu_byte(c, 3) + ofs] << 16);
             bu_put(out, 0, 7, 1u << 6);
-            bu_put(out, 7, 28, bu_pack4<7>(rg));
-            bu_put(out, 35, 28, bu_pack4<7>(ba));
+            bu_put(out, 7, 28, bu_pack7x4(rg));
+            bu_put(out, 35, 28, bu_pack7x4(ba));
             bu_put(out, 63, 2, p * 3u);
             // weights all 5: anchor 3 bits (0b101) then 15 x 0b0101, from bit 65
             bu_put(out, 65, 3, 5u);
             bu_put(out, 68, 28, 0x5555555u);
             bu_put(out, 96, 32, 0x55555555u);
         }
+        return BU_ST_OK;
+    } else if constexpr (M == 3) {
+        // ---- UASTC mode 3 (three subsets, BISE range 7) -> BC7 mode 2 (bc7.rs:116-307) ----------------------------------------
+        // The 18 endpoints are 18 two-bit values E (one 36-bit string) and 18 trits (four LUT reads -> one 36-bit string of 2-bit
+        // digits at the same positions).  A channel's (lo, hi) pair is one nibble of each string; the two nibbles index pair7x,
+        // which returns BC7's two 5-bit fields in both orders.  Subsets keep their UASTC numbers: the 10-bit field of subset s
+        // goes to slot sh_s / 10 with a run-time shift, an inverted subset reads the swapped half of its LUT words.
+        using L = BuLayout<3>;
+        const uint32_t pat = bu_bits(b, L::pos_pat, L::pat_bits);
+        if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;
+        const BuPart7 pr = T7.part7[L::part_base + pat];
+        // weights: regularise (UASTC anchors), invert / squeeze (BC7 anchors)
+        uint32_t W = bu_bits(b, L::pos_w, L::w_raw);
+        W = (W & 1u) | ((W & ~1u) << 1);
+        W = bu_ins0_rt32(W, pr.pos & 31u);
+        W = bu_ins0_rt32(W, (pr.pos >> 5) & 31u);
+        uint32_t k[3];
+        const uint32_t idx = bu_bc7_index2<3, false>(W, pr, k);
+        // index bytes: E nibble | trit nibble << 4, pairs 0..3 in Z0, 4..7 in Z1, 8 in Z2
+        const uint32_t e_lo = bu_bits(b, L::pos_epbits, 32), e_hi = bu_bits(b, L::pos_epbits + 32, 4);
+        const uint32_t g0 = T.trit5[bu_bits(b, L::pos_ep, 8)], g1 = T.trit5[bu_bits(b, L::pos_ep + 8, 8)], g2 = T.trit5[bu_bits(b, L::pos_ep + 16, 8)],
+                       g3 = T.trit5[bu_bits(b, L::pos_ep + 24, 5)];
+        const uint32_t t_lo = g0 | (g1 << 10) | (g2 << 20) | (g3 << 30), t_hi = g3 >> 2;
+        const uint32_t e_sh = e_lo >> 4, t_sh = t_lo >> 4;
+        const uint32_t Z0 = bu_bfi(0x0F0F0F0Fu, bu_perm(e_sh, e_lo, 0x05010400u), bu_perm(t_sh, t_lo, 0x05010400u) << 4);
+        const uint32_t Z1 = bu_bfi(0x0F0F0F0Fu, bu_perm(e_sh, e_lo, 0x07030602u), bu_perm(t_sh, t_lo, 0x07030602u) << 4);
+        const uint32_t Z2 = e_hi | (t_hi << 4);
+        uint32_t C[3] = {0, 0, 0};
+        BU_UNROLL
+        for (int sub = 0; sub < 3; sub++) {
+            const uint32_t sh = (pr.aux >> (11 + 5 * sub)) & 31u, half = k[sub] & 16u;
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) {
+                const int pk = 3 * sub + c;
+                const uint32_t z = pk < 4 ? Z0 : (pk < 8 ? Z1 : Z2);
+                const uint32_t e = T7.pair7x[(z >> (8 * (pk & 3))) & 0xFFu];
+                C[c] |= bu_ubfe(e, half, 10u) << sh;
+            }
+        }
+        out[0] = 4u | (((pr.aux >> 5) & 63u) << 3) | (C[0] << 9);
+        out[1] = (C[0] >> 23) | (C[1] << 7);
+        out[2] = (C[1] >> 25) | (C[2] << 5);
+        out[3] = (C[2] >> 27) | (idx << 3);
+        return BU_ST_OK;
+    } else if constexpr (M == 2) {
+        // ---- UASTC mode 2 (two subsets, 4-bit endpoints, 3-bit weights) -> BC7 mode 1 (6 bits + a p-bit shared by each subset) -------
+        // determine_shared_pbits (bc7.rs:408-475) on inputs that are multiples of 17: a channel's (lo, hi) nibble pair indexes
+        // pair4m1, which holds the pair's 6-bit fields under both p-bits and its error difference; three byte sums decide the
+        // subset's p-bit.  Integer comparison == the reference's f32 comparison on this domain (tests/test_float_sites.py).
+        using L = BuLayout<2>;
+        const uint32_t pat = bu_bits(b, L::pos_pat, L::pat_bits);
+        if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;
+        const BuPart7 pr = T7.part7[L::part_base + pat];
+        // weights: 46 stored bits -> 48 (zero MSBs at texel 0 and the UASTC anchor), invert by BC7 subset, squeeze BC7's anchors out
+        uint64_t W = (uint64_t)bu_bits(b, L::pos_w, 32) | ((uint64_t)bu_bits(b, L::pos_w + 32, L::w_raw - 32) << 32);
+        W = (W & 3u) | ((W & ~3ull) << 1);
+        {
+            const uint32_t q = pr.w3 & 63u;
+            W = W + (W & (~0ull << q));
+        }
+        const uint32_t aq1 = (pr.w3 >> 6) & 63u;
+        uint32_t k[2];
+        k[0] = bu_sbfe1((uint32_t)W, 2u);
+        k[1] = 0u - (uint32_t)((W >> aq1) & 1u);
+        {
+            const uint64_t m1 = (uint64_t)T7.w3mask[pat][0] | ((uint64_t)T7.w3mask[pat][1] << 32);
+            const uint64_t k0 = (uint64_t)k[0] | ((uint64_t)(k[0] & 0xFFFFu) << 32), k1 = (uint64_t)k[1] | ((uint64_t)(k[1] & 0xFFFFu) << 32);
+            W ^= (k1 & m1) | (k0 & ~m1);
+            W = bu_del_rt64(W, aq1);
+            W = (W & 3u) | ((W >> 1) & ~3ull);
+        }
+        // endpoints: byte c of X_s = channel c's (lo, hi) nibble pair of UASTC subset s; BC7 subset j reads UASTC subset src_j
+        const uint32_t x0 = bu_bits(b, L::pos_epbits, 24), x1 = bu_bits(b, L::pos_epbits + 24, 24);
+        const bool swp = (pr.aux >> 26) & 1u;  // src_0 == 1 (the permutation of two subsets is the identity or the swap)
+        uint32_t C[3] = {0, 0, 0}, sp = 0;
+        BU_UNROLL
+        for (int j = 0; j < 2; j++) {
+            const uint32_t y = (swp != (j == 1)) ? x1 : x0, tofs = k[j] & 256u;
+            uint32_t e[3], sum = 0;
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) {
+                e[c] = T7.pair4m1[((y >> (8 * c)) & 0xFFu) + tofs];
+                sum += e[c] >> 24;
+            }
+            const bool p1 = sum < 24u;
+            sp |= (p1 ? 1u : 0u) << j;
+            const uint32_t psh = p1 ? 12u : 0u;
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) C[c] |= bu_ubfe(e[c], psh, 12u) << (12 * j);
+        }
+        const uint32_t wlo = (uint32_t)W, whi = (uint32_t)(W >> 32);
+        out[0] = 2u | (((pr.aux >> 5) & 63u) << 2) | (C[0] << 8);
+        out[1] = C[1] | (C[2] << 24);
+        out[2] = (C[2] >> 8) | (sp << 16) | (wlo << 18);
+        out[3] = (wlo >> 14) | (whi << 18);
+        return BU_ST_OK;
+    } else if constexpr (M == 9 || M == 16) {
+        // ---- UASTC modes 9 (RGBA, 4-bit endpoints) and 16 (LA, 8-bit endpoints), two subsets -> BC7 mode 7 (5 bits + one p-bit per
+        // endpoint) -- determine_unique_pbits at 6 total bits (bc7.rs:478-553) through LUTs whose entries carry both quantisations
+        // and both squared errors, so that summing entries sums the errors (at most 4 x 16 per field: no carries).
+        using L = BuLayout<M>;
+        const uint32_t pat = bu_bits(b, L::pos_pat, L::pat_bits);
+        if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;
+        const BuPart7 pr = T7.part7[L::part_base + pat];
+        uint32_t W = bu_bits(b, L::pos_w, L::w_raw);
+        W = (W & 1u) | ((W & ~1u) << 1);
+        W = bu_ins0_rt32(W, pr.pos & 31u);
+        uint32_t k[3];
+        const uint32_t idx = bu_bc7_index2<2, true>(W, pr, k);
+        // X_s: the endpoint bits of UASTC subset s (mode 9: byte c = channel c's (lo, hi) nibbles; mode 16: bytes L lo, L hi, A lo, A hi)
+        const uint32_t x0 = bu_bits(b, L::pos_epbits, 32), x1 = bu_bits(b, L::pos_epbits + 32, 32);
+        const bool swp = (pr.aux >> 26) & 1u;
+        uint32_t C[4] = {0, 0, 0, 0}, pb = 0;
+        BU_UNROLL
+        for (int j = 0; j < 2; j++) {
+            const uint32_t y = (swp != (j == 1)) ? x1 : x0;
+            if constexpr (M == 9) {
+                BuU2 e[4];
+                uint32_t sum = 0;
+                BU_UNROLL
+                for (int c = 0; c < 4; c++) {
+                    e[c] = T7.pair4m7[(y >> (8 * c)) & 0xFFu];
+                    sum += e[c].y;
+                }
+                // bit offsets of the chosen quantisation inside e.x: lo endpoint 0 / 5, hi endpoint 10 / 15 (odd = p-bit set)
+                const uint32_t s_lo = ((sum >> 8) & 0xFFu) < (sum & 0xFFu) ? 5u : 0u, s_hi = (sum >> 24) < ((sum >> 16) & 0xFFu) ? 15u : 10u;
+                const uint32_t sa = bu_bfi(k[j], s_hi, s_lo), sb = bu_bfi(k[j], s_lo, s_hi);  // an inverted subset emits hi first
+                pb |= ((sa & 1u) | ((sb & 1u) << 1)) << (2 * j);
+                BU_UNROLL
+                for (int c = 0; c < 4; c++) C[c] |= (bu_ubfe(e[c].x, sa, 5u) | (bu_ubfe(e[c].x, sb, 5u) << 5)) << (10 * j);
+            } else {
+                // an inverted subset swaps lo and hi before the lookups: bytes (L hi, L lo, A hi, A lo)
+                const uint32_t z = bu_bfi(k[j], bu_perm(y, y, 0x02030001u), y);
+                uint32_t en[4];
+                BU_UNROLL
+                for (int i = 0; i < 4; i++) en[i] = T7.pbit6[(z >> (8 * i)) & 0xFFu];  // L a, L b, A a, A b
+                const uint32_t suma = 3u * (en[0] >> 16) + (en[2] >> 16), sumb = 3u * (en[1] >> 16) + (en[3] >> 16);  // R = G = B = L
+                const uint32_t sa = (suma >> 8) < (suma & 0xFFu) ? 8u : 0u, sb = (sumb >> 8) < (sumb & 0xFFu) ? 8u : 0u;
+                pb |= ((sa >> 3) | (sb >> 2)) << (2 * j);
+                C[0] |= (bu_ubfe(en[0], sa, 5u) | (bu_ubfe(en[1], sb, 5u) << 5)) << (10 * j);
+                C[3] |= (bu_ubfe(en[2], sa, 5u) | (bu_ubfe(en[3], sb, 5u) << 5)) << (10 * j);
+            }
+        }
+        if constexpr (M == 16) C[1] = C[2] = C[0];
+        out[0] = 0x80u | (((pr.aux >> 5) & 63u) << 8) | (C[0] << 14);
+        out[1] = (C[0] >> 18) | (C[1] << 2) | (C[2] << 22);
+        out[2] = (C[2] >> 10) | (C[3] << 10) | (pb << 30);
+        out[3] = (pb >> 2) | (idx << 2);
+        return BU_ST_OK;
+    } else if constexpr (M == 1 || M == 4) {
+        // ---- UASTC modes 1 (one subset, 8-bit endpoints) and 4 (two subsets, BISE range 12) -> BC7 mode 3 (two subsets, 7 bits + one
+        // p-bit per endpoint, RGB) ------------------------------------------------------------------------------------------------
+        // The p-bit of an endpoint depends on the endpoint alone (bu_pbit8), so it is taken per UASTC endpoint, before the subset
+        // permutation and the inversions: q = 7-bit R, G, B and the p-bit in bytes 0..3.  Two levels of byte permutes then turn the
+        // four endpoints of the block into one register per channel (a0, b0, a1, b1) -- an inverted subset swaps its two source
+        // registers, which is one bit in every selector byte of the first level -- and the p-bits fall out as the fourth channel.
+        using L = BuLayout<M>;
+        uint32_t W = bu_bits(b, L::pos_w, L::w_raw), idx, part, k[3];
+        W = (W & 1u) | ((W & ~1u) << 1);
+        uint32_t ql[2], qh[2];  // per UASTC subset
+        bool swp = false;
+        if constexpr (M == 1) {
+            // BC7 partition 0 with both subsets fed by the one UASTC subset: everything about the pattern is a constant
+            constexpr uint32_t m1 = (BU_PART[BU_PART_MODE1].bpat & 0x55555555u) * 3u, a1 = (BU_PART[BU_PART_MODE1].banch >> 4) & 15u;
+            static_assert(a1 == 15 && BU_PART[BU_PART_MODE1].bpart == 0, "UASTC mode 1 maps to BC7 partition 0 (anchor 15)");
+            k[0] = bu_sbfe1(W, 1u);
+            k[1] = bu_sbfe1(W, 31u);
+            W ^= (k[1] & m1) | (k[0] & ~m1);
+            W &= 0x7FFFFFFFu;                    // anchor 15's MSB is the top bit
+            idx = (W & 1u) | ((W >> 1) & ~1u);
+            part = 0;
+            const uint32_t x0 = bu_bits(b, L::pos_epbits, 32), x1 = bu_bits(b, L::pos_epbits + 32, 16);  // R lo, R hi, G lo, G hi | B lo, B hi
+            ql[0] = ql[1] = bu_pbit8p3(bu_perm(x1, x0, 0x0C040200u));
+            qh[0] = qh[1] = bu_pbit8p3(bu_perm(x1, x0, 0x0C050301u));
+        } else {
+            const uint32_t pat = bu_bits(b, L::pos_pat, L::pat_bits);
+            if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;
+            const BuPart7 pr = T7.part7[L::part_base + pat];
+            W = bu_ins0_rt32(W, pr.pos & 31u);
+            idx = bu_bc7_index2<2, true>(W, pr, k);
+            part = (pr.aux >> 5) & 63u;
+            swp = (pr.aux >> 26) & 1u;
+            // 12 endpoints: quint digit (four LUT reads, three digits each) and three plain bits -> dequantised byte
+            uint32_t e[12];
+            BU_UNROLL
+            for (int g = 0; g < 4; g++) {
+                const uint32_t dg = T.quint3[bu_bits(b, L::pos_ep + 7 * g, 7)];
+                BU_UNROLL
+                for (int t = 0; t < 3; t++) {
+                    const int n = 3 * g + t;
+                    e[n] = T.deq[bu_deq_ofs(12) + ((((dg >> (3 * t)) & 7u) << 3) | bu_bits(b, L::pos_epbits + 3 * n, 3))];
+                }
+            }
+            BU_UNROLL
+            for (int sub = 0; sub < 2; sub++) {
+                ql[sub] = bu_pbit8p3(e[6 * sub] | (e[6 * sub + 2] << 8) | (e[6 * sub + 4] << 16));
+                qh[sub] = bu_pbit8p3(e[6 * sub + 1] | (e[6 * sub + 3] << 8) | (e[6 * sub + 5] << 16));
+            }
+        }
+        // first level: (a.R, b.R, a.G, b.G) and (a.B, b.B, a.p, b.p) of each BC7 subset; a = lo unless the subset is inverted
+        uint32_t t0[2], t1[2];
+        BU_UNROLL
+        for (int j = 0; j < 2; j++) {
+            const bool s1 = M == 4 && (swp != (j == 1));
+            const uint32_t lo = s1 ? ql[1] : ql[0], hi = s1 ? qh[1] : qh[0];
+            const uint32_t sel = 0x05010400u ^ (k[j] & 0x04040404u);
+            t0[j] = bu_perm(hi, lo, sel);
+            t1[j] = bu_perm(hi, lo, sel + 0x02020202u);
+        }
+        const uint32_t R = bu_pack7x4(bu_perm(t0[1], t0[0], 0x05040100u)), G = bu_pack7x4(bu_perm(t0[1], t0[0], 0x07060302u)),
+                       B = bu_pack7x4(bu_perm(t1[1], t1[0], 0x05040100u));
+        const uint32_t pb = bu_udot4(bu_perm(t1[1], t1[0], 0x07060302u), 0x08040201u, 0u);
+        out[0] = 8u | (part << 4) | (R << 10);
+        out[1] = (R >> 22) | (G << 6);
+        out[2] = (G >> 26) | (B << 2) | (pb << 30);
+        out[3] = (pb >> 2) | (idx << 2);
+        return BU_ST_OK;
+    } else if constexpr (M == 7) {
+        // ---- UASTC mode 7 (two subsets, BISE range 12, the 2/3-subset pattern family) -> BC7 mode 2 (three subsets, 5 bits) -----------
+        // Each BC7 subset j reads UASTC subset src_j (two of the three share one).  deq5 returns the 5-bit endpoint; a channel's
+        // (lo, hi) goes into one register as both orders, lo | hi << 5 | (hi | lo << 5) << 16, and BC7 subset j picks its half.
+        using L = BuLayout<7>;
+        const uint32_t pat = bu_bits(b, L::pos_pat, L::pat_bits);
+        if (pat >= (uint32_t)L::pat_count) return BU_ST_BAD_PATTERN;
+        const BuPart7 pr = T7.part7[L::part_base + pat];
+        uint32_t W = bu_bits(b, L::pos_w, L::w_raw);
+        W = (W & 1u) | ((W & ~1u) << 1);
+        W = bu_ins0_rt32(W, pr.pos & 31u);
+        uint32_t k[3];
+        const uint32_t idx = bu_bc7_index2<3, true>(W, pr, k);
+        uint32_t e[12];
+        BU_UNROLL
+        for (int g = 0; g < 4; g++) {
+            const uint32_t dg = T.quint3[bu_bits(b, L::pos_ep + 7 * g, 7)];
+            BU_UNROLL
+            for (int t = 0; t < 3; t++) {
+                const int n = 3 * g + t;
+                e[n] = T7.deq5[16 + ((((dg >> (3 * t)) & 7u) << 3) | bu_bits(b, L::pos_epbits + 3 * n, 3))];
+            }
+        }
+        uint32_t pp[2][3];
+        BU_UNROLL
+        for (int sub = 0; sub < 2; sub++)
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) {
+                const uint32_t lo = e[6 * sub + 2 * c], hi = e[6 * sub + 2 * c + 1];
+                pp[sub][c] = (lo * 0x00200001u) | (hi * 0x00010020u);
+            }
+        uint32_t C[3] = {0, 0, 0};
+        BU_UNROLL
+        for (int j = 0; j < 3; j++) {
+            const bool s1 = (pr.aux >> (26 + 2 * j)) & 1u;
+            const uint32_t half = k[j] & 16u;
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) C[c] |= bu_ubfe(s1 ? pp[1][c] : pp[0][c], half, 10u) << (10 * j);
+        }
+        out[0] = 4u | (((pr.aux >> 5) & 63u) << 3) | (C[0] << 9);
+        out[1] = (C[0] >> 23) | (C[1] << 7);
+        out[2] = (C[1] >> 25) | (C[2] << 5);
+        out[3] = (C[2] >> 27) | (idx << 3);
         return BU_ST_OK;
     } else {
         using L = BuLayout<M>;
@@ -152,10 +475,14 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
         bu_decode_quant<M>(T, b, tq, eb);
 
         // ---- weights in BC7 width: WB[plane] = 16 fields of bwb bits -------------------------
-        uint32_t W[3];
-        bu_decode_weights<M>(b, pr.uanch, W);
+        // 4-bit weights of a single subset are BC7 mode 6's index string as stored (texel 0 is the anchor of both, its MSB is
+        // dropped in both): the 63 bits are copied, never regularised
+        constexpr bool WCOPY = planes == 1 && wb == 4 && bwb == 4 && bsub == 1;
+        uint32_t W[3] = {0, 0, 0};
+        if constexpr (!WCOPY) bu_decode_weights<M>(b, pr.uanch, W);
         uint32_t w0lo = 0, w0hi = 0, w1lo = 0;  // plane 0: up to 64 bits; plane 1: 32 bits (bwb = 2)
-        if constexpr (planes == 1) {
+        if constexpr (WCOPY) {
+        } else if constexpr (planes == 1) {
             if constexpr (wb == bwb) {
                 w0lo = W[0];
                 w0hi = W[1];
@@ -176,7 +503,7 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                     const int pos = 10 * i, wi = pos >> 5, sh = pos & 31;
                     uint32_t x = W[wi] >> sh;
                     if (sh + 10 > 32) x |= W[wi + 1] << (32 - sh);
-                    const uint32_t v = T.w5to4x2[x & 1023u];
+                    const uint32_t v = T7.w5to4x2[x & 1023u];
                     if (i < 4) w0lo |= v << (8 * i);
                     else w0hi |= v << (8 * (i - 4));
                 }
@@ -203,7 +530,7 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
             BU_UNROLL
             for (int i = 0; i < 18; i++) {
                 if (i < L::ep_count) {
-                    if constexpr (BM == 2) e[i] = T.deq5[(L::d.range == 7 ? 0 : 16) + ((tq[i] << L::ebits) | eb[i])];
+                    if constexpr (BM == 2) e[i] = T7.deq5[(L::d.range == 7 ? 0 : 16) + ((tq[i] << L::ebits) | eb[i])];
                     else e[i] = bu_deq<L::d.range>(T, tq[i], eb[i]);
                 } else e[i] = 0;
             }
@@ -269,7 +596,7 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                 }
             }
             if constexpr (bwb == 3) {  // BC7 mode 1: 48-bit masks from the table
-                const uint32_t m1lo = T.w3mask[pat][0], m1hi = T.w3mask[pat][1];
+                const uint32_t m1lo = T7.w3mask[pat][0], m1hi = T7.w3mask[pat][1];
                 w0lo ^= bu_sel(inv1, m1lo, 0u) ^ bu_sel(inv0, ~m1lo, 0u);
                 w0hi ^= (bu_sel(inv1, m1hi, 0u) ^ bu_sel(inv0, ~m1hi, 0u)) & 0xFFFFu;
             } else {  // 2 bits per texel: masks straight from the 2-bit pattern word
@@ -309,10 +636,8 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                     c = (c & 0x00FFFFFFu) | (cs << 24);           // alpha <- compsel channel
                 }
             }
-            // drop texel 0's MSB per plane
+            // drop texel 0's MSB per plane (BC7 mode 6: folded into the emission below, where the index string starts at an odd bit)
             if constexpr (bwb == 4) {
-                w0lo = (w0lo & 7u) | ((w0lo >> 1) & ~7u) | (w0hi << 31);
-                w0hi >>= 1;
             } else {
                 w0lo = (w0lo & 1u) | ((w0lo >> 1) & ~1u);
                 w1lo = (w1lo & 1u) | ((w1lo >> 1) & ~1u);
@@ -331,14 +656,21 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
             uint32_t p0, p1;
             const uint32_t q0 = bu_pbit8<4>(blo[0], &p0), q1 = bu_pbit8<4>(bhi[0], &p1);
             // R0 R1 G0 G1 | B0 B1 A0 A1, 7 bits each: interleave the bytes of the two endpoints, squeeze 8 -> 7
-            const uint32_t rg = bu_pack4<7>(bu_perm(q1, q0, 0x05010400u)), ba = bu_pack4<7>(bu_perm(q1, q0, 0x07030602u));
+            const uint32_t rg = bu_pack7x4(bu_perm(q1, q0, 0x05010400u)), ba = bu_pack7x4(bu_perm(q1, q0, 0x07030602u));
             bu_put(out, pos, 28, rg);
             bu_put(out, pos + 28, 28, ba);
             pos += 56;
             bu_put(out, pos, 2, p0 | (p1 << 1));
             pos += 2;  // = 65
-            bu_put(out, pos, 31, w0lo & 0x7FFFFFFFu);
-            bu_put(out, pos + 31, 32, (w0lo >> 31) | (w0hi << 1));
+            static_assert(BM != 6 || bsub == 1, "BC7 mode 6 has one subset");
+            if constexpr (WCOPY) {
+                out[2] |= bu_bits(b, L::pos_w, 31) << 1;
+                out[3] = bu_bits(b, L::pos_w + 31, 32);
+            } else {
+                // the squeezed string starts at bit 65: every bit above texel 0 moves down by one and up by one -- it stays
+                out[2] |= (w0lo & ~15u) | ((w0lo & 7u) << 1);
+                out[3] = w0hi;
+            }
         } else if constexpr (BM == 3) {
             uint32_t p[2][2], q[2][2];
             BU_UNROLL
@@ -371,7 +703,7 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                     uint32_t en[4], sum = 0;
                     BU_UNROLL
                     for (int ch = 0; ch < 4; ch++) {
-                        en[ch] = T.pbit6[bu_byte(c, ch)];
+                        en[ch] = T7.pbit6[bu_byte(c, ch)];
                         sum += en[ch] >> 16;
                     }
                     const bool p1 = (sum >> 8) < (sum & 0xFFu);  // err1 < err0
@@ -405,7 +737,7 @@ BU_DEV int bu_block_bc7(const BuTables& T, const BuBlk& b, uint32_t out[4])
                 for (int k = 0; k < 2; k++)
                     BU_UNROLL
                     for (int ch = 0; ch < 3; ch++) {
-                        en[k][ch] = T.pbit7[bu_byte(k ? bhi[s] : blo[s], ch)];
+                        en[k][ch] = T7.pbit7[bu_byte(k ? bhi[s] : blo[s], ch)];
                         sum += en[k][ch] >> 16;
                     }
                 const bool p1 = (sum >> 8) < (sum & 0xFFu);

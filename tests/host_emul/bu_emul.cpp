@@ -4,7 +4,7 @@
 // library and nothing under basisu_rs_amd/ loads it.
 #include "bu_uastc_dispatch.hpp"
 
-static BuTables g_tables;
+static BuTablesAll g_tables;
 static bool g_init = false;
 static const BuTables& tables()
 {
@@ -12,7 +12,7 @@ static const BuTables& tables()
         bu_build_tables(&g_tables);
         g_init = true;
     }
-    return g_tables;
+    return g_tables.t;
 }
 
 extern "C" {
@@ -42,5 +42,5 @@ void bu_emul_batch(int target, const uint8_t* in, size_t n_blocks, uint8_t* out,
     const size_t obs = target == BU_TGT_ETC1 ? 8 : (target == BU_TGT_RGBA ? 64 : 16);
     for (size_t i = 0; i < n_blocks; i++) st[i] = (uint8_t)bu_emul_block(target, in + 16 * i, out + obs * i);
 }
-size_t bu_emul_tables_size(void) { return sizeof(BuTables); }
+size_t bu_emul_tables_size(void) { return sizeof(BuTablesAll); }
 }

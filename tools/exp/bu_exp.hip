@@ -35,9 +35,10 @@ constexpr int BU_BPT = 4, BU_TILE = 1024, BU_MAX_CHUNKS = BU_TILE / 64 + 20;
 // V=1 no transcode (identity through the sort); V=2 additionally no atomics/sort; V=3 load->LDS->store
 template <int V>
 __global__ __launch_bounds__(BU_WG) void bu_exp_kernel(const uint4* __restrict__ in, void* __restrict__ out, size_t n_blocks,
-                                                       const BuTables* __restrict__ tables)
+                                                       const BuTablesAll* __restrict__ tables)
 {
-    __shared__ BuTables T;
+    __shared__ uint4 t_all[sizeof(BuTablesAll) / 16];
+    BuTables& T = reinterpret_cast<BuTablesAll*>(t_all)->t;
     __shared__ uint4 sblk[BU_TILE];
     __shared__ uint8_t sst[BU_TILE];
     __shared__ uint32_t cnt[32], start[32], chunk[BU_MAX_CHUNKS + 4], n_chunks;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(BU_WG) void bu_exp_kernel(const uint4* __restrict__
         const size_t idx = tile * BU_TILE + (size_t)j * BU_WG + tid;
         v[j] = (tile < n_tiles && idx < n_blocks) ? in[idx] : make_uint4(0, 0, 0, 0);
     }
-    if (V != 3) bu_stage_tables_n<BU_WG, BU_TGT_BC7>(T, tables);
+    if (V != 3) bu_stage_tables_n<BU_WG, BU_TGT_BC7>(t_all, tables);
     if (tid < 32) cnt[tid] = 0;
     __syncthreads();
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -149,6 +150,11 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
         case 24: {
             const size_t t_ = (n_blocks + 1023) / 1024;
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 2, 1, false, false, 0>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
+                               (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
+        } break;
+        case 25: {  // the shipped BC7 shape: 512 x 2, prefetch build, one tile per workgroup at 2^20 blocks
+            const size_t t_ = (n_blocks + 1023) / 1024;
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, 512, 2, 1, true, false, 0>), dim3((unsigned)t_), dim3(512), 0, s, in, d_out[k],
                                (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
         case 30: {  // 1024 x 1, two persistent workgroups per CU, prefetch: two tiles per workgroup

@@ -4,10 +4,11 @@
 #include "../../basisu_rs_amd/csrc/bu_uastc_dispatch.hpp"
 
 template <int TARGET, int M>
-__global__ void mode_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, const BuTables* __restrict__ tg)
+__global__ void mode_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, const BuTablesAll* __restrict__ tg)
 {
-    __shared__ BuTables T;
-    for (unsigned i = threadIdx.x; i < sizeof(BuTables) / 4; i += blockDim.x) ((uint32_t*)&T)[i] = ((const uint32_t*)tg)[i];
+    __shared__ BuTablesAll TA;
+    for (unsigned i = threadIdx.x; i < sizeof(BuTablesAll) / 4; i += blockDim.x) ((uint32_t*)&TA)[i] = ((const uint32_t*)tg)[i];
+    const BuTables& T = TA.t;
     __syncthreads();
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint4 v = in[i];
@@ -22,7 +23,7 @@ __global__ void mode_kernel(const uint4* __restrict__ in, uint4* __restrict__ ou
         }
     }
 }
-#define INST(T, M) template __global__ void mode_kernel<T, M>(const uint4*, uint4*, const BuTables*);
+#define INST(T, M) template __global__ void mode_kernel<T, M>(const uint4*, uint4*, const BuTablesAll*);
 #define INST_T(T) INST(T,0) INST(T,1) INST(T,2) INST(T,3) INST(T,4) INST(T,5) INST(T,6) INST(T,7) INST(T,8) INST(T,9) \
     INST(T,10) INST(T,11) INST(T,12) INST(T,13) INST(T,14) INST(T,15) INST(T,16) INST(T,17) INST(T,18)
 INST_T(0) INST_T(1) INST_T(2) INST_T(3) INST_T(4)

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from basisu_rs_amd import synth
 variant, lg, wpw, tile = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "exp", "libbu_exp.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "exp", os.environ.get("BU_EXP_LIB", "libbu_exp.so")))
 vp = ctypes.c_void_p
 lib.bu_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
 lib.bu_exp_time.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
@@ -31,13 +31,16 @@ for _ in range(3):
 print("variant %d, 2^%d blocks: %.2f us per launch (no stamps)" % (variant, lg, best))
 n_wg = (N + tile - 1) // tile
 nw = n_wg * wpw
-buf = torch.zeros(nw * 16 + 64, dtype=torch.int64, device=dev)
+buf = torch.zeros(nw * 32 + 64, dtype=torch.int64, device=dev)  # 32 words per wave: [0,16) first tile, [16,32) the second one (BU_STAMP)
 lib.bu_exp_set_stamps(vp(buf.data_ptr()))
 # one launch on a cold buffer, preceded by a few others so that clocks are up
 lib.bu_exp_time(h, variant, ip, op, NBUF, N, 5, sp, ctypes.byref(ms))
 torch.cuda.synchronize()
 lib.bu_exp_set_stamps(None)
-raw = buf.cpu().numpy()[: nw * 16].reshape(nw, 16)
+allraw = buf.cpu().numpy()[: nw * 32].reshape(nw, 32)
+BLK = int(os.environ.get("STAMP_BLOCK", 0))  # 0: the first pass through the tile loop, 1: the second one
+raw = allraw[:, 16 * BLK: 16 * BLK + 16].copy()
+if BLK: raw[:, [0, 1, 9, 11]] = allraw[:, [0, 1, 9, 11]]  # stamps 0, 1, 11 and the start time are taken once, before the loop
 s = raw[:, :9].astype(np.float64)
 rt = (raw[:, 10] - raw[:, 9]).astype(np.float64)  # s_memrealtime ticks (100 MHz) over the wave's life
 ok = rt > 0
@@ -67,11 +70,14 @@ for q in range(4):
 
 # per-slot Gantt: median real time (us after the first wave) at which waves of each CU slot pass each stamp
 mhz = np.median((s[ok, 8] - s[ok, 0]) / rt[ok]) * 100
-x11 = (raw[:, 11].astype(np.float64) - s[:, 1]) / mhz
-x12 = (raw[:, 12].astype(np.float64) - raw[:, 11].astype(np.float64)) / mhz
-x2 = (s[:, 2] - raw[:, 12].astype(np.float64)) / mhz
-for nm, x in (("stamp1 -> stamp11 (back to back: cost of one stamp)", x11), ("stamp11 -> keys known", x12), ("keys known -> A done (atomics returned)", x2)):
-    print("%-55s p10 %.3f p50 %.3f p90 %.3f us" % (nm, np.percentile(x, 10), np.median(x), np.percentile(x, 90)))
+t11 = st_us + (raw[:, 11].astype(np.float64) - s[:, 0]) / mhz
+t12 = st_us + (raw[:, 12].astype(np.float64) - s[:, 0]) / mhz
+for q in range(4):
+    sel = (wg // 256) == q
+    if sel.any():
+        print("  slot %d: tables in LDS (before barrier 0) p50 %.2f p90 %.2f | barrier 0 passed p50 %.2f | keys known (tile data arrived) p10 %.2f p50 %.2f p90 %.2f | A done p50 %.2f" % (
+            q, np.median(t11[sel]), np.percentile(t11[sel], 90), np.median(st_us[sel] + (s[sel, 1] - s[sel, 0]) / mhz), np.percentile(t12[sel], 10), np.median(t12[sel]), np.percentile(t12[sel], 90),
+            np.median(st_us[sel] + (s[sel, 2] - s[sel, 0]) / mhz)))
 t_us = st_us[:, None] + (s - s[:, :1]) / mhz
 print("median time (us) at each stamp, per CU slot:   " + "  ".join("%-6s" % n[:6] for n in names))
 for q in range(4):
