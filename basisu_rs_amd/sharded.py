@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 _CLEAR = (1 << 63) - 1  # "no failing block" as an int64 that loses every MIN against a real status word
+_RANK_FAILED = -1       # "this rank's transcode raised": wins every MIN (real status words are block << 8 | status >= 1)
 
 
 def partition(n_items, world_size, rank):
@@ -63,15 +64,27 @@ def transcode_array_sharded(slices, transcode_fn, group=None, gather=True, block
     mine = full[rank * per: rank * per + (hi - lo)] if want_full else full
     d_in = slices[lo:hi].reshape(-1, 16)
     word = _CLEAR
+    local_exc = None
     if hi > lo:
-        if len(inspect.signature(transcode_fn).parameters) >= 3:
-            word = transcode_fn(d_in, mine.view(-1, bb), lo * bps)
-        else:  # plain one-argument function returning the result (CPU tests)
-            mine.view(-1, bb).copy_(transcode_fn(d_in).reshape(-1, bb))
+        # A rank whose transcode RAISES (HIP error, out of memory, a bad transcode_fn) must still take part in the all_reduce:
+        # leaving before it would park every other rank in the collective until the RCCL time-out.  The exception travels as
+        # a sentinel status word below every real one, so all ranks stop together.
+        try:
+            if len(inspect.signature(transcode_fn).parameters) >= 3:
+                word = transcode_fn(d_in, mine.view(-1, bb), lo * bps)
+            else:  # plain one-argument function returning the result (CPU tests)
+                mine.view(-1, bb).copy_(transcode_fn(d_in).reshape(-1, bb))
+        except Exception as e:  # noqa: BLE001 -- re-raised below, after the ranks have met
+            local_exc = e
+            word = _RANK_FAILED
     if world > 1:
         w = torch.tensor([word], dtype=torch.int64, device=slices.device)
         dist.all_reduce(w, op=dist.ReduceOp.MIN, group=group)
         word = int(w.item())
+    if local_exc is not None:
+        raise local_exc
+    if word == _RANK_FAILED:
+        raise RuntimeError("the transcode raised on another rank; no rank enters the all-gather")
     if word != _CLEAR:
         raiser = getattr(transcode_fn, "raise_for", None)
         if raiser:

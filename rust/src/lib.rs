@@ -183,6 +183,9 @@ pub fn transcode_slice(format: TargetTextureFormat, data: &[u8]) -> Result<Vec<u
 /// transcoded array (`gather = true`: peer pulls over xGMI), and the array is returned from device 0.
 pub fn transcode_array_sharded(format: TargetTextureFormat, slices: &[u8], n_slices: usize, devices: &[i32], gather: bool) -> Result<Vec<u8>> {
     use core::ffi::c_void;
+    if devices.is_empty() || n_slices == 0 || slices.len() % (UASTC_BLOCK_SIZE * n_slices) != 0 {
+        return Err("transcode_array_sharded: need at least one device, one slice and whole slices of whole blocks".to_string());
+    }
     let bps = slices.len() / UASTC_BLOCK_SIZE / n_slices.max(1);
     let bb = unsafe { ffi::bu_target_block_bytes(format as c_int) };
     let n = devices.len();

@@ -85,6 +85,32 @@ def _worker_failing(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_raising(rank, world, port, q):
+    """rank 1's transcode RAISES (not a block error): rank 0 must not be left waiting in a collective"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basisu_rs_amd import sharded
+
+        slices = torch.zeros((4, 8, 16), dtype=torch.uint8)
+
+        def fn(t, out, base):
+            if rank == 1:
+                raise ValueError("device fell over on rank 1")
+            out.zero_()
+            return sharded._CLEAR
+
+        fn.block_bytes = 16
+        try:
+            sharded.transcode_array_sharded(slices, fn)
+            q.put((rank, "no error"))
+        except (RuntimeError, ValueError) as e:
+            q.put((rank, type(e).__name__ + ": " + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _spawn(target, args_of_rank, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -101,6 +127,12 @@ def _spawn(target, args_of_rank, world=2):
 def test_failing_shard_raises_on_every_rank():
     res = _spawn(_worker_failing, ())
     assert res[0][1] == res[1][1] and "block 70 failed" in res[0][1], res
+
+
+def test_a_raising_rank_stops_every_rank_before_the_gather():
+    res = _spawn(_worker_raising, ())
+    assert res[0] == (0, "RuntimeError: the transcode raised on another rank; no rank enters the all-gather"), res
+    assert res[1] == (1, "ValueError: device fell over on rank 1"), res
 
 
 @pytest.mark.parametrize("n_slices", [8, 7, 1])
@@ -149,3 +181,4 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-8:] == ["--gpus", "8", "--steps", "7", "--warmup", "3", "--config", "array512"] and cmd[-9].endswith("bench.py")
     assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") not in (None, "0")
+    assert d["parent_initialised_cuda"] is False  # the parent only counted devices: nothing that a child could not re-do
