@@ -26,8 +26,15 @@ def sources():
     return out
 
 
-def build_hip(force=False, verbose=False):
-    """Compile csrc/bu_hip.hip for gfx950 -> libbasisu_hip.so.  Returns the library path."""
+LIB_ST0 = os.path.join(HERE, "libbasisu_hip_st0.so")  # canary build: intrinsic nontemporal stores instead of the `sc1 nt` asm stores
+
+
+def build_hip(force=False, verbose=False, canary=False):
+    """Compile csrc/bu_hip.hip for gfx950 -> libbasisu_hip.so.  Returns the library path.
+    canary=True builds libbasisu_hip_st0.so instead: the same sources with -DBU_ST_MODE=0 (every result store is the compiler's
+    own nontemporal store, no inline asm, no hand-placed s_nop); tests/test_gpu_round3.py compares its output with the shipped
+    build's, so a compiler that schedules differently around the asm store shows up as a difference."""
+    LIB = LIB_ST0 if canary else globals()["LIB"]
     if not force and _newer_than(LIB, sources()):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -44,12 +51,14 @@ def build_hip(force=False, verbose=False):
            # flight (BC7 10.73 -> 10.41 us, ASTC 9.97 -> 9.72 in an A/B run)
            "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-o", LIB, os.path.join(CSRC, "bu_hip.hip")]
+    if canary:
+        cmd.insert(1, "-DBU_ST_MODE=0")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libbasisu_hip.so")
+        raise RuntimeError("hipcc failed building " + os.path.basename(LIB))
     if verbose:
         sys.stderr.write(r.stderr)
     return LIB

@@ -79,6 +79,9 @@ size_t bu_balanced_tile(size_t max_tile, size_t n_blocks, size_t slots, bool dyn
     return t < 64 ? 64 : (t > max_tile ? max_tile : t);
 }
 
+// targets whose 1024-block tile shapes are also compiled with rectangular tiles (bu_uastc_sorted_kernel, RECT)
+constexpr bool bu_rect_compiled(int target) { return target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA; }
+
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
                           uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0)
@@ -103,13 +106,29 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * 7;
             const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
             const unsigned long long pbase = base + done;
+            // Rectangular tiles (kernel, RECT): the caller told us the block grid (blocks_per_row), it is a multiple of 64 wide and
+            // the piece is whole rows of 64 x 16-block tiles.  Compiled for the fixed 1024-block tile shapes of BC7, ASTC and
+            // RGBA32; ETC1 / ETC2 (run-time tile size) keep strips.
+            constexpr size_t RW = BU_RECT_W, RH = 1024 / BU_RECT_W;
+            // (one tile per row, blocks_per_row == 64: the strip IS the rectangle)
+            const bool rect = grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21) && nb % (RH * bpr) == 0 &&
+                              (n_blocks <= piece || piece % (RH * bpr) == 0);
+            const unsigned rect_magic = rect ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
+#define BU_GO(T, W, B, MINW, PF, DIR, SK, GRID, CUS, TRT)                                                                                       \
+    do {                                                                                                                                        \
+        if (bu_rect_compiled(T) && rect && (size_t)(W) * (B) == 1024)                                                                           \
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, bu_rect_compiled(T)>), dim3(GRID), dim3(W), 0, stream, pin, pout, \
+                               (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, rect_magic BU_STAMP_PASS);                           \
+        else                                                                                                                                    \
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, false>), dim3(GRID), dim3(W), 0, stream, pin, pout,          \
+                               (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, TRT BU_STAMP_PASS);                                  \
+    } while (0)
             // large inputs: the per-target BuBigCfg configuration, see its definition
 #define BU_LAUNCH_SORTED(T)                                                                                                             \
     if (grid_cap == 0 && nb <= (size_t)1024 * ctx->cu_count) {                                                                         \
         /* at most one tile per CU: 16 waves on it (BC7 1 Ki blocks 4.32 -> 3.92 us, 2^16 5.16 -> 4.80, 2^18 5.70 -> 5.41; */          \
         /* ETC1 6.76 -> 6.47, 7.95 -> 7.64, 8.82 -> 8.54) */                                                                           \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 1, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(1024), 0, stream, pin, pout, \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, 1024u BU_STAMP_PASS);                                  \
+        BU_GO(T, 1024, 1, 1, false, false, 0, (unsigned)((nb + 1023) / 1024), (unsigned)ctx->cu_count, 1024u);                                   \
     } else if (grid_cap == 0 && (many || BuBigCfg<T>::ALL_SIZES)) {                                                                    \
         using C = BuBigCfg<T>;                                                                                                          \
         const size_t tile_rt = bu_balanced_tile((size_t)C::WGS * C::BPT, nb, (size_t)ctx->cu_count * C::WG_PER_CU, C::DYN_TILE);        \
@@ -118,13 +137,10 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         /* generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per */      \
         /* slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0) */   \
         const unsigned pcus = (btiles <= bcap || btiles % bcap == 0) ? (unsigned)ctx->cu_count : 0u;                                    \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW>), dim3((unsigned)(btiles < bcap ? btiles : bcap)), \
-                           dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus,                                       \
-                           (unsigned)tile_rt BU_STAMP_PASS);                                                                                                       \
+        BU_GO(T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW, (unsigned)(btiles < bcap ? btiles : bcap), pcus, (unsigned)tile_rt); \
     } else if (grid_cap == 0) {                                                                                                         \
         /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0>), dim3((unsigned)((nb + 1023) / 1024)), dim3(512), 0, stream, pin, pout, \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, 1024u BU_STAMP_PASS);                                  \
+        BU_GO(T, 512, 2, 1, false, false, 0, (unsigned)((nb + 1023) / 1024), (unsigned)ctx->cu_count, 1024u);                                    \
     } else                                                                                                                              \
         hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
                            (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)(BU_SORT_WGS * BU_SORT_BPT) BU_STAMP_PASS);
@@ -150,15 +166,14 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
                 // 786 432 blocks 15.75 -> 14.24 without them, 2^20 blocks 16.7 against 18.7 with them)
                 const unsigned rcus = rtiles >= 2 * (size_t)rgrid ? (unsigned)ctx->cu_count : 0u;
                 if (grid_cap == 0 && nb <= ((size_t)3 << 20))
-                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 1024, 1, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(1024), 0, stream, pin,
-                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, rcus, (unsigned)rtile BU_STAMP_PASS);
+                    BU_GO(BU_TGT_RGBA, 1024, 1, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW, rgrid, rcus, (unsigned)rtile);
                 else
-                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_RGBA, 512, 2, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW>), dim3(rgrid), dim3(512), 0, stream, pin,
-                                       pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, rcus, (unsigned)rtile BU_STAMP_PASS);
+                    BU_GO(BU_TGT_RGBA, 512, 2, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW, rgrid, rcus, (unsigned)rtile);
             } break;
             default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
             }
 #undef BU_LAUNCH_SORTED
+#undef BU_GO
             BU_HIP(ctx, hipGetLastError());
         }
         return BU_OK;

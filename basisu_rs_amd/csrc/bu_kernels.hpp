@@ -220,7 +220,16 @@ struct BuBigCfg<BU_TGT_ASTC> {
 // DIRECT: results are stored to global memory straight from the chunk loop at the block's original
 // index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
 // RGBA32 (64 B per block do not fit a second LDS tile; `bpr` = blocks per image row).
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0>
+// RECT: a tile is a BU_RECT_W x (tile / BU_RECT_W) RECTANGLE of the block grid (64 x 16 for the 1024-block tiles) instead of a strip
+// of consecutive blocks (the launcher picks it when blocks_per_row is a multiple of 64 and the slice is whole rows of such tiles,
+// bu_launch_uastc).  Texture content is coherent in two dimensions: a 1024-block strip of a 4096-px-wide image cuts an 8 x 8-block
+// region of one UASTC mode into eight runs of eight, a rectangle keeps it whole -- fewer, fuller runs per tile, fewer partly
+// filled chunks (mode-coherent atlas: BC7 -5...-10 %).  64 blocks wide: a wave's load / store instruction is still one contiguous
+// KiB (32-wide tiles, two 512-byte segments per instruction, cost the uniform-random atlas +3 % on BC7).  Nothing else changes (the
+// sort works on the index inside the tile).  A compile-time variant: as a run-time switch the extra index arithmetic cost the
+// strip path 4 % (round 2).
+constexpr unsigned BU_RECT_W = 64;
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, bool RECT = false>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
@@ -276,6 +285,23 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     const unsigned tile_blocks = DYN_TILE ? tile_rt : (unsigned)BU_TILE;
     const unsigned n_tiles = (n_blocks + tile_blocks - 1) / tile_blocks;  // 32-bit indices: the host splits launches above 2^26 blocks
     auto in_tile = [&](unsigned l) { return !DYN_TILE || l < tile_blocks; };
+    static_assert(!RECT || (!DYN_TILE && BU_TILE % BU_RECT_W == 0), "rectangular tiles are BU_RECT_W blocks wide and of fixed size");
+    // slice index of block l of tile t.  RECT: `tile_rt` carries ceil(2^32 / tiles per row) + 0 (bu_launch_uastc), which makes
+    // t / tpr one s_mul_hi_u32 (exact for t, tpr < 2^16: at most 2^26 blocks per launch, rows below 2^21 blocks)
+    const unsigned tpr = RECT ? bpr / BU_RECT_W : 1u;  // tiles per row of tiles
+    auto tile_xy = [&](unsigned t, unsigned& ty, unsigned& tx) {
+        ty = (unsigned)(((unsigned long long)t * tile_rt) >> 32);
+        tx = t - ty * tpr;
+    };
+    auto gidx = [&](unsigned t, unsigned l) {
+        if constexpr (RECT) {
+            unsigned ty, tx;
+            tile_xy(t, ty, tx);  // (wave-uniform: scalar)
+            return ((unsigned)(BU_TILE / BU_RECT_W) * ty + l / BU_RECT_W) * bpr + BU_RECT_W * tx + (l % BU_RECT_W);
+        } else {
+            return t * tile_blocks + l;
+        }
+    };
     unsigned tile = blockIdx.x;
     // Table staging.  The staged 16-byte pieces of the LDS image are numbered 0..TVT-1: BC7's own tables, then the target's one or
     // two ranges of the common blob; piece i sits at t_store[tdst(i)] and comes from the same index of the image's source in device
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     uint4 v[BU_BPT];
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++) {
-        const unsigned idx = tile * tile_blocks + j * BU_WG + tid;
+        const unsigned idx = gidx(tile, j * BU_WG + tid);
         v[j] = (tile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
     }
     if constexpr (!SPLIT) {
@@ -337,7 +363,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         bool uniform = true;
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
-            const bool valid = tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid);
+            const bool valid = RECT || (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid));  // (RECT: whole tiles only)
             key[j] = valid ? T.key_lut[v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && key[j] < 20u;
         }
@@ -389,7 +415,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const unsigned idx = ntile * tile_blocks + j * BU_WG + tid;
+                const unsigned idx = gidx(ntile, j * BU_WG + tid);
                 vn[j] = (ntile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                 }
                 // (a failing block leaves o[] at the zeros it was initialised with: every path checks before it writes)
                 if constexpr (DIRECT) {
-                    const unsigned idx = tbase + sorig[slot];
+                    const unsigned idx = gidx(tile, sorig[slot]);
                     if (st) bu_report(status, base + idx, st);
                     if constexpr (TARGET == BU_TGT_RGBA) {
                         const unsigned by = idx / bpr, bx = idx - by * bpr;
@@ -466,7 +492,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 if (key[j] < 20u) {
-                    const unsigned idx = tbase + j * BU_WG + tid;
+                    const unsigned idx = gidx(tile, j * BU_WG + tid);
                     if constexpr (INBLOCK) {
                         uint4 r = sblk[dest[j]];
                         if ((r.x & 0xFFu) == 0u) {  // no valid block of these formats starts with a zero byte: word 3 is the status
@@ -479,7 +505,17 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                     const uint32_t st = sst[dest[j]];
                     if (st) bu_report(status, base + idx, (int)st);
                     if constexpr (TARGET == BU_TGT_RGBA) {
-                        const unsigned by = idx / bpr, bx = idx - by * bpr;
+                        unsigned by, bx;
+                        if constexpr (RECT) {  // block row and column straight from the tile coordinates: no division
+                            const unsigned l = j * BU_WG + tid;
+                            unsigned ty, tx;
+                            tile_xy(tile, ty, tx);
+                            by = (unsigned)(BU_TILE / BU_RECT_W) * ty + l / BU_RECT_W;
+                            bx = BU_RECT_W * tx + (l % BU_RECT_W);
+                        } else {
+                            by = idx / bpr;
+                            bx = idx - by * bpr;
+                        }
                         uint4* img = reinterpret_cast<uint4*>(out);
 #pragma unroll
                         for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)((4 * by + r) * bpr + bx), sout[r * BU_TILE + dest[j]]);
@@ -497,7 +533,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         } else {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const unsigned idx = ntile * tile_blocks + j * BU_WG + tid;
+                const unsigned idx = gidx(ntile, j * BU_WG + tid);
                 v[j] = (ntile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }

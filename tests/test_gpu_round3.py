@@ -1,0 +1,141 @@
+"""Round-3 GPU tests: the store-policy canary (the shipped `sc1 nt` inline-asm stores against a build that lets the compiler emit
+every store), the timed-window helper of bench.py, BASELINE config 4 at its stated size through the whole-file API, and both
+sides of the rectangular-tile selection.  Everything goes through the C ABI; bit-exact.  Run on the GPU box: pytest -m gpu."""
+import ctypes
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from basisu_rs_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CANARY_CHILD = r'''
+import hashlib, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from basisu_rs_amd import Context, _lib, synth
+g = synth.load_golden(os.path.join(%(root)r, "tests", "golden", "uastc_kat.bin"))
+n = 1 << 20
+idx = synth.gold_indices(n, seed=77)
+blocks = g["uastc"][idx].copy()
+blocks[12345] = 0
+blocks[12345, 0] = 69  # the one invalid 7-bit mode code (uastc.rs:560-577): one failing block: the status word and the zeroed result travel the same stores
+ctx = Context(0)
+d_in = torch.from_numpy(blocks).cuda()
+out = {}
+for name, t, bb in (("astc", _lib.ASTC, 16), ("bc7", _lib.BC7, 16), ("etc1", _lib.ETC1, 8), ("etc2", _lib.ETC2, 16), ("rgba", _lib.RGBA32, 64)):
+    d_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+    st = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(st)
+    ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=1024, d_status=st)
+    torch.cuda.synchronize()
+    out[name] = [hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest(), int(st.item()) & 0xFFFFFFFFFFFFFFFF]
+ctx.close()
+print(json.dumps(out))
+'''
+
+
+def test_intrinsic_store_build_matches_the_asm_store_build():
+    """libbasisu_hip_st0.so (-DBU_ST_MODE=0: compiler-emitted nontemporal stores) and the shipped library (inline-asm
+    `global_store_dwordx4 ... sc1 nt` + a hand-placed s_nop) must produce identical bytes and status words on 2^20 blocks x 5
+    targets: the asm store's data-hazard padding is invisible to the compiler, this is the canary for a scheduling change."""
+    import json
+
+    from basisu_rs_amd import build
+
+    st0 = build.LIB_ST0
+    if not os.path.exists(st0):
+        build.build_hip(canary=True)
+    res = []
+    for lib in (_lib.LIB_PATH, st0):
+        env = dict(os.environ, BASISU_HIP_LIB=lib)
+        r = subprocess.run([sys.executable, "-c", _CANARY_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
+    for name in ("astc", "bc7", "etc1", "etc2", "rgba"):
+        assert res[0][name][1] == (12345 << 8) | 1, (name, hex(res[0][name][1]))  # invalid mode at block 12345
+
+
+def test_window_timing_helper_brackets_exactly_the_timed_launches():
+    """bu_time_uastc_launches_window: the host bracket and the event pair agree, and every launch (lead + timed) really ran"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+    n, nbuf = 1 << 18, 4
+    ctx = Context(0)
+    lib = _lib.load()
+    idx = [synth.gold_indices(n, seed=900 + k) for k in range(nbuf)]
+    ins = [torch.from_numpy(g["uastc"][i]).cuda() for i in idx]
+    outs = [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    A = ctypes.c_void_p * nbuf
+    ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(-1)
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = lib.bu_time_uastc_launches_window(ctx.handle, _lib.BC7, A(*[t.data_ptr() for t in ins]), A(*[t.data_ptr() for t in outs]), nbuf, 1, n, 512,
+                                           64, 40, None, sp, ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+    assert st == 0 and late.value in (0, 1)
+    torch.cuda.synchronize()
+    for k in range(nbuf):
+        assert torch.equal(outs[k].cpu(), torch.from_numpy(g["bc7"][idx[k]]))
+    assert ev.value > 0 and host.value > 0
+    if not late.value:
+        assert abs(host.value - ev.value) <= 0.25 * ev.value + 0.02, (host.value, ev.value)
+    # argument checks
+    assert lib.bu_time_uastc_launches_window(ctx.handle, _lib.BC7, A(*[t.data_ptr() for t in ins]), A(*[t.data_ptr() for t in outs]), nbuf, 0, n, 512,
+                                             -1, 4, None, sp, ctypes.byref(ev), ctypes.byref(host), None) == _lib.ERR_ARGUMENT
+    ctx.close()
+
+
+@pytest.mark.parametrize("target", ["astc", "bc7", "rgba"])
+def test_rectangular_tiles_on_both_sides_of_the_selection(golden, target):
+    """the launcher takes the RECT kernels when blocks_per_row is a multiple of 64 (at least 128) and the slice is whole rows of
+    64 x 16-block tiles, the strip kernels otherwise: same bytes either way, and the same first-error index (uastc.rs:157-165)"""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    t, bb = {"astc": (_lib.ASTC, 16), "bc7": (_lib.BC7, 16), "rgba": (_lib.RGBA32, 64)}[target]
+    # (blocks per row, block rows): rect 1 and 2 tiles per row, several tile rows, one big enough for every launch shape;
+    # strip: ragged rows of tiles, width not a multiple of 32, and the block-linear call without a grid (blocks_per_row 0)
+    shapes = [(128, 16, True), (128, 64, True), (192, 32, True), (1024, 512, True), (1024, 1024, True), (128, 63, False), (64, 64, False),
+              (96, 64, False), (0, 4096, False)]
+    for bpr, rows, rect in shapes:
+        n = (bpr or 1) * rows
+        idx = synth.gold_indices(n, seed=31 + bpr + rows)
+        blocks = golden["uastc"][idx].copy()
+        d_in = torch.from_numpy(blocks).cuda()
+        if target == "rgba":
+            if bpr == 0:
+                continue
+            d_out = torch.zeros((rows * 4, bpr * 16), dtype=torch.uint8, device="cuda")
+        else:
+            d_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+        ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr)
+        torch.cuda.synchronize()
+        if target == "rgba":
+            got = d_out.cpu().numpy().reshape(rows, 4, bpr, 16).transpose(0, 2, 1, 3).reshape(n, 64)
+        else:
+            got = d_out.cpu().numpy()
+        assert (got == golden[target][idx]).all(), (target, bpr, rows, rect)
+        # two failing blocks: the lower index is reported whichever tile (or strip) holds it
+        bad_hi, bad_lo = n - 3, (n * 5) // 8 + 7
+        blocks[bad_hi, 0] = 69  # the one invalid 7-bit mode code (uastc.rs:560-577)
+        blocks[bad_lo, 0] = 69
+        d_in = torch.from_numpy(blocks).cuda()
+        st = torch.empty(1, dtype=torch.int64, device="cuda")
+        ctx.status_word_reset(st)
+        ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr, d_status=st)
+        torch.cuda.synchronize()
+        with pytest.raises(BasisuError) as e:
+            ctx.status_word_check(int(st.item()))
+        assert e.value.status == _lib.ERR_INVALID_MODE and e.value.first_bad_block == bad_lo, (target, bpr, rows)
+    ctx.close()
