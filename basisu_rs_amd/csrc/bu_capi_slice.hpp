@@ -199,12 +199,35 @@ bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16]
 // ---- ETC1S ---------------------------------------------------------------------------------------
 void bu_etc1s_selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8]) { bu_host::selector_from_rows(rows, out_entry); }
 
+// dynamic LDS above 64 KiB has to be allowed per kernel, once (hipFuncSetAttribute); remembered in the context
+static bu_status bu_etc1s_lds_attr(bu_context* ctx, bool rgba, size_t lds)
+{
+    size_t& have = ctx->etc1s_lds_attr[rgba ? 1 : 0];
+    if (lds <= have) return BU_OK;
+    const void* fn = rgba ? reinterpret_cast<const void*>(&bu_etc1s_staged_kernel<true>) : reinterpret_cast<const void*>(&bu_etc1s_staged_kernel<false>);
+    BU_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BU_ETC1S_LDS_MAX));
+    have = BU_ETC1S_LDS_MAX;
+    return BU_OK;
+}
+
 bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx, size_t n_blocks, const uint32_t* d_endpoints,
                                          uint32_t n_endpoints, const void* d_selectors, uint32_t n_selectors, void* d_out,
                                          uint64_t* d_status, void* stream)
 {
     if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
     if (n_blocks == 0) return BU_OK;
+    const size_t lds = ((size_t)n_endpoints + n_selectors) * 4;
+    if (n_blocks >= BU_ETC1S_STAGED_MIN && lds <= BU_ETC1S_LDS_MAX) {
+        // codebooks in LDS; two workgroups per CU from 2^21 blocks where both fit (2^22 blocks: 15.8 against 17.5 us, 2^20: 7.7 against 6.7)
+        const unsigned per_cu = (n_blocks >= ((size_t)1 << 21) && 2 * lds <= BU_ETC1S_LDS_MAX) ? 2u : 1u;
+        bu_status st = bu_etc1s_lds_attr(ctx, false, lds);
+        if (st) return st;
+        hipLaunchKernelGGL(bu_etc1s_staged_kernel<false>, dim3((unsigned)ctx->cu_count * per_cu), dim3(1024), lds, static_cast<hipStream_t>(stream), d_idx,
+                           nullptr, 1u, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
+                           static_cast<uint8_t*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+        BU_HIP(ctx, hipGetLastError());
+        return BU_OK;
+    }
     hipLaunchKernelGGL(bu_etc1s_etc1_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream), d_idx,
                        n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors, static_cast<uint2*>(d_out),
                        reinterpret_cast<unsigned long long*>(d_status));
@@ -219,6 +242,16 @@ bu_status bu_etc1s_decode_rgba_device(bu_context* ctx, const uint32_t* d_idx, co
     const size_t n_blocks = nbx * nby;
     if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
     if (n_blocks == 0) return BU_OK;
+    const size_t lds = ((size_t)n_endpoints + n_selectors + 256) * 4;
+    if (n_blocks >= BU_ETC1S_STAGED_MIN && lds <= BU_ETC1S_LDS_MAX) {
+        bu_status st = bu_etc1s_lds_attr(ctx, true, lds);
+        if (st) return st;
+        hipLaunchKernelGGL(bu_etc1s_staged_kernel<true>, dim3((unsigned)ctx->cu_count), dim3(1024), lds, static_cast<hipStream_t>(stream), d_idx, d_alpha_idx,
+                           (unsigned)nbx, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
+                           static_cast<uint8_t*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+        BU_HIP(ctx, hipGetLastError());
+        return BU_OK;
+    }
     hipLaunchKernelGGL(bu_etc1s_rgba_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream), d_idx,
                        d_alpha_idx, (unsigned)nbx, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
                        static_cast<uint4*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);

@@ -19,6 +19,7 @@ struct bu_context {
     unsigned long long* d_status = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t etc1s_lds_attr[2] = {0, 0};  // dynamic LDS already allowed for bu_etc1s_staged_kernel<false / true>
     std::mutex lock;  // host-pointer entry points share the staging buffers
     char err[256] = {0};
 };

@@ -611,19 +611,38 @@ __global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict_
 }
 
 // ---- ETC1S back-end ----------------------------------------------------------------------------
-// etc.rs:396-431 for one base colour: colour k = clamp(extend5(c5) + modifier[inten][k])
-__device__ __forceinline__ uint32_t bu_etc1s_color(const int16_t* mods, uint32_t ep, int k)
+// basis_lz/mod.rs:122-146 for one block: 16 texels = colours[selector] of the colour endpoint, alpha = colours[selector].g of the
+// alpha slice's endpoint (:139-143).  Byte palettes: a channel's four colours are one etc1s_pal word (etc.rs:396-431 tabulated),
+// and the selectors of a block COLUMN are byte-aligned -- texel (x, y) sits at bits 8y + 2x of `rows` (etc.rs:354-361), so
+// (rows >> 2x) & 0x03030303 is the column's four selectors, one per byte: exactly a v_perm_b32 selector.  One v_perm per channel
+// and column looks the four texels up, two levels of byte permutes turn the channel columns into texel words (round 2: sixteen
+// four-way select chains per plane).
+__device__ __forceinline__ void bu_etc1s_block_rgba(const uint32_t* pal_lut, uint32_t ep, uint32_t rows, bool has_a, uint32_t aep, uint32_t arows,
+                                                    uint32_t px[16])
 {
-    const int md = mods[((ep >> 24) & 7u) * 4 + k];
-    uint32_t c = 0xFF000000u;
+    const uint32_t it = (ep >> 19) & 0xE0u;  // inten << 5
+    const uint32_t pr = pal_lut[it | (ep & 31u)], pg = pal_lut[it | ((ep >> 8) & 31u)], pb = pal_lut[it | ((ep >> 16) & 31u)];
+    uint32_t pa = 0;
+    if (has_a) pa = pal_lut[((aep >> 19) & 0xE0u) | ((aep >> 8) & 31u)];  // .a = colors[sel].g of the alpha endpoint
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        const uint32_t c5 = (ep >> (8 * ch)) & 0xFFu;
-        const int base = (int)(((c5 << 3) | (c5 >> 2)) & 0xFFu);
-        const int v = base + md;
-        c |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * ch);
+    for (int x = 0; x < 4; x++) {
+        const uint32_t sel = (rows >> (2 * x)) & 0x03030303u;
+        const uint32_t r = bu_perm(0u, pr, sel), g = bu_perm(0u, pg, sel), b = bu_perm(0u, pb, sel);
+        const uint32_t t01 = bu_perm(g, r, 0x05010400u), t23 = bu_perm(g, r, 0x07030602u);  // R0 G0 R1 G1 / R2 G2 R3 G3
+        if (has_a) {
+            const uint32_t a = bu_perm(0u, pa, (arows >> (2 * x)) & 0x03030303u);
+            const uint32_t u01 = bu_perm(a, b, 0x05010400u), u23 = bu_perm(a, b, 0x07030602u);
+            px[x] = bu_perm(u01, t01, 0x05040100u);
+            px[4 + x] = bu_perm(u01, t01, 0x07060302u);
+            px[8 + x] = bu_perm(u23, t23, 0x05040100u);
+            px[12 + x] = bu_perm(u23, t23, 0x07060302u);
+        } else {
+            px[x] = bu_perm(b, t01, 0x0D040100u);  // R G B 255
+            px[4 + x] = bu_perm(b, t01, 0x0D050302u);
+            px[8 + x] = bu_perm(b, t23, 0x0D060100u);
+            px[12 + x] = bu_perm(b, t23, 0x0D070302u);
+        }
     }
-    return c;
 }
 
 // basis_lz/mod.rs:163-181
@@ -657,8 +676,9 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
                                                               uint4* __restrict__ out, unsigned long long* status,
                                                               const BuTablesAll* __restrict__ tables)
 {
-    __shared__ int16_t mods[32];
-    if (threadIdx.x < 32) mods[threadIdx.x] = tables->t.etc1_mod[threadIdx.x];
+    __shared__ uint32_t pal_lut[256];
+    pal_lut[threadIdx.x] = tables->t.etc1s_pal[threadIdx.x];
+    static_assert(BU_WG == 256, "one palette word per thread");
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * BU_WG;
     for (size_t i = (size_t)blockIdx.x * BU_WG + threadIdx.x; i < n_blocks; i += stride) {
@@ -678,29 +698,13 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
         if (bad) {
             bu_report(status, i, BU_ERR_INDEX_RANGE);
         } else {
-            const uint32_t ep = endpoints[e];
-            const uint32_t rows = selectors[s].x;
-            uint32_t col[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) col[k] = bu_etc1s_color(mods, ep, k);
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const uint32_t sel = (rows >> (2 * t)) & 3u;  // row y in byte y, x = 0 in the low bits (etc.rs:354-361)
-                px[t] = sel == 0 ? col[0] : sel == 1 ? col[1] : sel == 2 ? col[2] : col[3];
-            }
+            const uint32_t ep = endpoints[e], rows = selectors[s].x;
+            uint32_t aep = 0, arows = 0;
             if (aidx) {
-                const uint32_t aep = endpoints[ae];
-                const uint32_t arows = selectors[as].x;
-                uint32_t ag[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) ag[k] = (bu_etc1s_color(mods, aep, k) >> 8) & 0xFFu;  // .a = colors[sel].g
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const uint32_t sel = (arows >> (2 * t)) & 3u;
-                    const uint32_t a = sel == 0 ? ag[0] : sel == 1 ? ag[1] : sel == 2 ? ag[2] : ag[3];
-                    px[t] = (px[t] & 0x00FFFFFFu) | (a << 24);
-                }
+                aep = endpoints[ae];
+                arows = selectors[as].x;
             }
+            bu_etc1s_block_rgba(pal_lut, ep, rows, aidx != nullptr, aep, arows, px);
         }
         const size_t by = i / nbx, bx = i - by * nbx;
 #pragma unroll
@@ -708,6 +712,65 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_rgba_kernel(const uint32_t* __
     }
 }
 
+
+// ---- large slices: both codebooks staged in LDS -------------------------------------------------------------------------------
+// One persistent 1024-thread workgroup per CU (two where they fit) copies the endpoint codebook (4 B per entry) and the half of the
+// selector codebook its target reads (4 B per entry: texel rows for RGBA32, ETC1 selector bytes for ETC1) into dynamic LDS and
+// walks the slice with LDS lookups.  Against the L2 gather above (tools/exp/etc1s_sweep.py, 4096 + 8192 entries, cold rotation):
+// 2^18 blocks 4.3 / 5.4 us against 4.3 / 5.0 (ETC1 / RGBA32: launch-bound either way), 2^20 6.7 / 16.0 against 10.3 / 23.3,
+// 2^22 15.8 / 56.1 against 38.7 / 91.8, 2^24 41.6 / 218 against 147 / 366 us (ETC1 at 4.8 TB/s, RGBA32 at 5.2 TB/s): the gather
+// is bound by the L2's random 4- and 8-byte reads, not by HBM.  The launcher takes this kernel from 2^19 blocks up.
+template <bool RGBA>
+__global__ __launch_bounds__(1024) void bu_etc1s_staged_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ aidx, unsigned nbx,
+                                                               size_t n_blocks, const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                               const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
+                                                               unsigned long long* status, const BuTablesAll* __restrict__ tables)
+{
+    extern __shared__ uint32_t bu_etc1s_lds[];
+    uint32_t* s_ep = bu_etc1s_lds;
+    uint32_t* s_sel = bu_etc1s_lds + n_ep;
+    uint32_t* pal_lut = s_sel + n_sel;
+    for (uint32_t i = threadIdx.x; i < n_ep; i += 1024) s_ep[i] = endpoints[i];
+    for (uint32_t i = threadIdx.x; i < n_sel; i += 1024) s_sel[i] = RGBA ? selectors[i].x : selectors[i].y;
+    if (RGBA && threadIdx.x < 256) pal_lut[threadIdx.x] = tables->t.etc1s_pal[threadIdx.x];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n_blocks; i += stride) {
+        const uint32_t ix = __builtin_nontemporal_load(idx + i);
+        const uint32_t e = ix & 0xFFFFu, sl = ix >> 16;
+        bool bad = e >= n_ep || sl >= n_sel;
+        if constexpr (!RGBA) {
+            uint2 o = make_uint2(0, 0);
+            if (bad) {
+                bu_report(status, i, BU_ERR_INDEX_RANGE);
+            } else {  // basis_lz/mod.rs:163-181
+                const uint32_t ep = s_ep[e], inten = ep >> 24;
+                o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
+                o.y = s_sel[sl];
+            }
+            bu_st_stream(reinterpret_cast<uint2*>(out) + i, o);
+        } else {  // basis_lz/mod.rs:122-146
+            uint32_t ae = 0, as = 0;
+            if (aidx) {
+                const uint32_t ax = __builtin_nontemporal_load(aidx + i);
+                ae = ax & 0xFFFFu;
+                as = ax >> 16;
+                bad = bad || ae >= n_ep || as >= n_sel;
+            }
+            uint32_t px[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) px[k] = 0;
+            if (bad) bu_report(status, i, BU_ERR_INDEX_RANGE);
+            else bu_etc1s_block_rgba(pal_lut, s_ep[e], s_sel[sl], aidx != nullptr, aidx ? s_ep[ae] : 0u, aidx ? s_sel[as] : 0u, px);
+            const size_t by = i / nbx, bx = i - by * nbx;
+            uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+            for (int r = 0; r < 4; r++) bu_st_stream(img + (4 * by + r) * (size_t)nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
+        }
+    }
+}
+// blocks from which the staged kernel is launched, and the LDS one CU can give a workgroup (160 KiB less a margin)
+constexpr size_t BU_ETC1S_STAGED_MIN = (size_t)1 << 19, BU_ETC1S_LDS_MAX = 152 * 1024;
 
 // ---- whole-file ETC1S launches (bu_read_to): every slice of the file in ONE launch -----------------------------------
 // The host concatenates the per-slice index arrays (each padded to a multiple of 64 words) and describes the slices in a
@@ -730,9 +793,9 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __
                                                               const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
                                                               unsigned long long* status, const BuTablesAll* __restrict__ tables)
 {
-    __shared__ int16_t mods[32];
+    __shared__ uint32_t pal_lut[RGBA ? 256 : 1];
     if constexpr (RGBA) {
-        if (threadIdx.x < 32) mods[threadIdx.x] = tables->t.etc1_mod[threadIdx.x];
+        pal_lut[threadIdx.x] = tables->t.etc1s_pal[threadIdx.x];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u, wpg = BU_WG / 64;
@@ -776,29 +839,13 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __
             if (bad) {
                 bu_report(status + sd.image, i, BU_ERR_INDEX_RANGE);
             } else {
-                const uint32_t ep = endpoints[e];
-                const uint32_t rows = selectors[sl].x;
-                uint32_t col[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) col[k] = bu_etc1s_color(mods, ep, k);
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const uint32_t sel = (rows >> (2 * t)) & 3u;
-                    px[t] = sel == 0 ? col[0] : sel == 1 ? col[1] : sel == 2 ? col[2] : col[3];
-                }
+                const uint32_t ep = endpoints[e], rows = selectors[sl].x;
+                uint32_t aep = 0, arows = 0;
                 if (has_a) {
-                    const uint32_t aep = endpoints[ae];
-                    const uint32_t arows = selectors[as].x;
-                    uint32_t ag[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) ag[k] = (bu_etc1s_color(mods, aep, k) >> 8) & 0xFFu;
-#pragma unroll
-                    for (int t = 0; t < 16; t++) {
-                        const uint32_t sel = (arows >> (2 * t)) & 3u;
-                        const uint32_t a = sel == 0 ? ag[0] : sel == 1 ? ag[1] : sel == 2 ? ag[2] : ag[3];
-                        px[t] = (px[t] & 0x00FFFFFFu) | (a << 24);
-                    }
+                    aep = endpoints[ae];
+                    arows = selectors[as].x;
                 }
+                bu_etc1s_block_rgba(pal_lut, ep, rows, has_a, aep, arows, px);
             }
             const uint32_t by = i / sd.nbx, bx = i - by * sd.nbx;
             uint4* img = reinterpret_cast<uint4*>(out + sd.out_ofs);

@@ -148,6 +148,10 @@ struct BuTables {
     // channels these are -(L0 + L1), L2 - L0 and L3 - L1, from which the three luma thresholds follow by two subtractions.
     alignas(16) BuU2 etc1_thr[3][512];
     alignas(16) uint8_t end_marker[16];
+    // ---- ETC1S kernels only (behind every UASTC target's ranges: read from device memory / staged by those kernels themselves) ----
+    // the four colours of one channel of an ETC1S endpoint as a byte palette: [inten << 5 | c5] -> clamp(extend5(c5) + modifier[inten][k])
+    // in byte k (etc.rs:396-431)
+    alignas(16) uint32_t etc1s_pal[256];
 };
 static_assert(sizeof(BuTables) % 16 == 0, "BuTables is copied to LDS in 16-byte pieces");
 struct BuTablesAll {  // the device blob: one allocation, one kernel argument
@@ -310,6 +314,15 @@ static inline void bu_build_tables(BuTablesAll* all)
     for (int i = 0; i < 125; i++) t->astc_quint[i] = BU_ASTC_QUINT_ENC[i];
     for (int i = 0; i < 20; i++) t->astc_mode13[i] = BU_ASTC_BLOCK_MODE13[i];
     for (int i = 0; i < 32; i++) t->etc1_mod[i] = BU_ETC1_MOD[i];
+    for (int inten = 0; inten < 8; inten++)
+        for (int c5 = 0; c5 < 32; c5++) {
+            uint32_t pal = 0;
+            for (int k = 0; k < 4; k++) {
+                const int v = ((c5 << 3) | (c5 >> 2)) + BU_ETC1_MOD[inten * 4 + k];
+                pal |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * k);
+            }
+            t->etc1s_pal[(inten << 5) | c5] = pal;
+        }
     for (int i = 0; i < 128; i++) {
         static const int by_rank[8] = {3, 2, 1, 0, 4, 5, 6, 7};
         t->eac_mods[i] = BU_ETC2_ALPHA_MOD[(i & ~7) + by_rank[i & 7]];

@@ -139,3 +139,58 @@ def test_rectangular_tiles_on_both_sides_of_the_selection(golden, target):
             ctx.status_word_check(int(st.item()))
         assert e.value.status == _lib.ERR_INVALID_MODE and e.value.first_bad_block == bad_lo, (target, bpr, rows)
     ctx.close()
+
+
+@pytest.mark.parametrize("alpha", [False, True])
+def test_config4_one_512x512_block_slice_end_to_end(ctx, oracle, alpha):
+    """BASELINE config 4 at its stated size: ONE ETC1S slice of 2048 x 2048 px (512 x 512 blocks; with `alpha` a colour + alpha
+    slice pair) in a .basis file, through the whole-file API -- host BasisLZ decode of 262 144 blocks against 4096-entry
+    codebooks, GPU codebook lookup + repack -- to ETC1 and to RGBA32, against the oracle's whole-file path (basis.rs:17-70,
+    102-124; basis_lz/mod.rs:97-186)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import basis_builder as bb
+    import basisu_rs_amd as bu
+
+    f, _, _ = bb.etc1s_file(np.random.default_rng(444 + alpha), [(512, 512)], n_codebook=4096, alpha=alpha)
+    for target, read in (("etc1", bu.read_to_etc1), ("rgba", bu.read_to_rgba)):
+        st, hdr, want = oracle.read_to(target, f)
+        # (read_to_etc1 returns every slice as an image: colour and alpha slice of a pair alike, basis.rs:102-124; read_to_rgba
+        # folds the pair into one image, basis.rs:17-70)
+        assert st == 0 and len(want) == (2 if alpha and target == "etc1" else 1)
+        res = read(f, ctx)
+        got = res[1] if target == "rgba" else res
+        assert len(got) == len(want)
+        for g, (w, h, stride, data) in zip(got, want):
+            assert (g.w, g.h, g.stride) == (w, h, stride) and (w, h) == (2048, 2048)
+            assert g.data.tobytes() == data.tobytes(), (target, alpha)
+    # the same through a page-locked output buffer (the kernel writes host memory directly)
+    pinned = ctx.host_alloc(bu.read_query(0, f)[1])
+    got = bu.read_to_rgba(f, ctx, out=pinned)[1]
+    assert got[0].data.tobytes() == want[0][3].tobytes()
+    ctx.host_free(pinned)
+
+
+@pytest.mark.parametrize("n_ep,n_sel", [(4096, 8192), (16128, 16128)])
+def test_etc1s_kernels_with_codebooks_staged_in_lds(ctx, oracle, n_ep, n_sel):
+    """slices of 2^19 blocks and more run the kernels that stage both codebooks in LDS (bu_etc1s_staged_kernel): config-4
+    codebooks (48 KiB) and the largest a .basis file can carry (126 KiB: dynamic LDS above the 64 KiB default), with and
+    without an alpha slice, one block past a multiple of the grid stride, and the lowest failing block of two
+    (basis_lz/mod.rs:122-181, 443-445)"""
+    from basisu_rs_amd import BasisuError, etc1s_selector_from_rows
+
+    ep, rows = synth.etc1s_codebooks(n_ep, n_sel, seed=3)
+    sel = etc1s_selector_from_rows(rows)
+    nbx, nby = 1024, 513  # 525 312 blocks
+    n = nbx * nby
+    idx = synth.etc1s_indices(n, n_ep, n_sel, seed=21)
+    aidx = synth.etc1s_indices(n, n_ep, n_sel, seed=22)
+    assert (ctx.etc1s_transcode_to_etc1(idx, ep, sel) == oracle.etc1s_to_etc1(idx, ep, sel)).all()
+    assert (ctx.etc1s_decode_to_rgba(idx, None, nbx, nby, ep, sel) == oracle.etc1s_to_rgba(idx, None, nbx, nby, ep, sel)).all()
+    assert (ctx.etc1s_decode_to_rgba(idx, aidx, nbx, nby, ep, sel) == oracle.etc1s_to_rgba(idx, aidx, nbx, nby, ep, sel)).all()
+    bad = idx.copy()
+    bad[n - 5] = n_ep            # endpoint index one past the codebook
+    bad[400_000] = (n_sel << 16)  # selector index one past the codebook: the LOWER block is the one reported
+    for call in (lambda: ctx.etc1s_transcode_to_etc1(bad, ep, sel), lambda: ctx.etc1s_decode_to_rgba(idx, bad, nbx, nby, ep, sel)):
+        with pytest.raises(BasisuError) as e:
+            call()
+        assert e.value.status == _lib.ERR_INDEX_RANGE and e.value.first_bad_block == 400_000

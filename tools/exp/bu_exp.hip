@@ -199,3 +199,61 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
     BU_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
     return BU_OK;
 }
+
+// ---- ETC1S: codebooks staged in LDS against the shipped L2 gather (the north star's "LDS-staged codebook tables") ----------------
+// One persistent 1024-thread workgroup per CU copies the endpoint codebook (4 B per entry) and the half of the selector codebook
+// the target reads (4 B per entry: texel rows for RGBA32, ETC1 selector bytes for ETC1) into dynamic LDS, then walks the slice.
+template <bool RGBA>
+__global__ __launch_bounds__(1024) void bu_exp_etc1s_staged_kernel(const uint32_t* __restrict__ idx, unsigned nbx, size_t n_blocks,
+                                                                   const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                                   const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
+                                                                   const BuTablesAll* __restrict__ tables)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t* s_ep = lds;
+    uint32_t* s_sel = lds + n_ep;
+    uint32_t* pal_lut = s_sel + n_sel;
+    for (uint32_t i = threadIdx.x; i < n_ep; i += 1024) s_ep[i] = endpoints[i];
+    for (uint32_t i = threadIdx.x; i < n_sel; i += 1024) s_sel[i] = RGBA ? selectors[i].x : selectors[i].y;
+    if (RGBA && threadIdx.x < 256) pal_lut[threadIdx.x] = tables->t.etc1s_pal[threadIdx.x];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n_blocks; i += stride) {
+        const uint32_t ix = __builtin_nontemporal_load(idx + i);
+        const uint32_t e = ix & 0xFFFFu, sl = ix >> 16;
+        if (e >= n_ep || sl >= n_sel) continue;
+        const uint32_t ep = s_ep[e], sv = s_sel[sl];
+        if constexpr (!RGBA) {
+            const uint32_t inten = ep >> 24;
+            bu_st_stream(reinterpret_cast<uint2*>(out) + i, make_uint2(((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24), sv));
+        } else {
+            uint32_t px[16];
+            bu_etc1s_block_rgba(pal_lut, ep, sv, false, 0u, 0u, px);
+            const size_t by = i / nbx, bx = i - by * nbx;
+            uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+            for (int r = 0; r < 4; r++) bu_st_stream(img + (4 * by + r) * (size_t)nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
+        }
+    }
+}
+
+// variant 0: the shipped kernels (bu_etc1s_*_device); 1: staged, one workgroup per CU; 2: staged, two workgroups per CU
+extern "C" bu_status bu_exp_etc1s(bu_context* ctx, int variant, int rgba, const uint32_t* d_idx, unsigned nbx, size_t n_blocks, const uint32_t* d_ep,
+                                  uint32_t n_ep, const void* d_sel, uint32_t n_sel, void* d_out, void* stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (variant == 0) {
+        if (rgba) return bu_etc1s_decode_rgba_device(ctx, d_idx, nullptr, nbx, n_blocks / nbx, d_ep, n_ep, d_sel, n_sel, d_out, nullptr, stream);
+        return bu_etc1s_transcode_etc1_device(ctx, d_idx, n_blocks, d_ep, n_ep, d_sel, n_sel, d_out, nullptr, stream);
+    }
+    const size_t lds_bytes = ((size_t)n_ep + n_sel + 256) * 4;
+    const unsigned grid = (unsigned)ctx->cu_count * (variant == 2 ? 2u : 1u);
+    if (rgba)
+        hipLaunchKernelGGL(bu_exp_etc1s_staged_kernel<true>, dim3(grid), dim3(1024), lds_bytes, s, d_idx, nbx, n_blocks, d_ep, n_ep,
+                           static_cast<const uint2*>(d_sel), n_sel, static_cast<uint8_t*>(d_out), ctx->d_tables);
+    else
+        hipLaunchKernelGGL(bu_exp_etc1s_staged_kernel<false>, dim3(grid), dim3(1024), lds_bytes, s, d_idx, nbx, n_blocks, d_ep, n_ep,
+                           static_cast<const uint2*>(d_sel), n_sel, static_cast<uint8_t*>(d_out), ctx->d_tables);
+    BU_HIP(ctx, hipGetLastError());
+    return BU_OK;
+}
