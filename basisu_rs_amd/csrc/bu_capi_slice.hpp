@@ -158,6 +158,64 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
     return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream));
 }
 
+bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
+                                          const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
+                                          const uint64_t* index_base, uint64_t* d_status, void* stream)
+{
+    if (!ctx || (n_slices && (!d_in || !n_blocks || !d_out))) return BU_ERR_ARGUMENT;
+    const size_t bb = bu_target_block_bytes(target);
+    if (bb == 0 || (target == BU_TARGET_RGBA32 && blocks_per_row == 0)) return BU_ERR_ARGUMENT;
+    for (size_t i = 0; i < n_slices; i++) {  // every argument is checked before the first launch
+        if (n_blocks[i] && (!d_in[i] || !d_out[i])) return BU_ERR_ARGUMENT;
+        if (target == BU_TARGET_RGBA32 && n_blocks[i] % blocks_per_row != 0) return BU_ERR_ARGUMENT;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // runs of slices that are contiguous in input, output and block numbering become one launch each
+    struct Run {
+        const uint8_t* in;
+        uint8_t* out;
+        size_t n;
+        uint64_t base;
+    };
+    std::vector<Run> runs;
+    uint64_t next_base = 0;
+    for (size_t i = 0; i < n_slices; i++) {
+        const uint64_t base = index_base ? index_base[i] : next_base;
+        next_base = base + n_blocks[i];
+        if (n_blocks[i] == 0) continue;
+        const uint8_t* in = static_cast<const uint8_t*>(d_in[i]);
+        uint8_t* out = static_cast<uint8_t*>(d_out[i]);
+        if (!runs.empty()) {
+            Run& r = runs.back();
+            if (r.in + r.n * 16 == in && r.out + r.n * bb == out && r.base + r.n == base) {
+                r.n += n_blocks[i];
+                continue;
+            }
+        }
+        runs.push_back(Run{in, out, n_blocks[i], base});
+    }
+    if (runs.empty()) return BU_OK;
+    if (runs.size() == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s);
+    // several launches: side by side on up to four context-owned streams, forked from and joined back into `stream`
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    const int lanes = runs.size() < 4 ? (int)runs.size() : 4;
+    for (int i = 0; i < lanes; i++)
+        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
+    BuDrain drain(ctx);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < lanes; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
+    for (size_t k = 0; k < runs.size(); k++) {
+        bu_status st = bu_launch_uastc(ctx, target, runs[k].in, runs[k].n, runs[k].out, blocks_per_row, runs[k].base, d_status, ctx->extra_streams[k % lanes]);
+        if (st) return st;
+    }
+    for (int i = 0; i < lanes; i++) {
+        BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[i]));
+        BU_HIP(ctx, hipStreamWaitEvent(s, ctx->ev1, 0));
+    }
+    drain.armed = false;
+    return BU_OK;
+}
+
 bu_status bu_uastc_transcode(bu_context* ctx, bu_target target, const uint8_t* in, size_t in_bytes, uint8_t* out,
                              size_t out_bytes, uint64_t* first_bad_block)
 {

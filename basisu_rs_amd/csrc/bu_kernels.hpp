@@ -246,11 +246,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
     // cus = 0 switches it off: RGBA32 launches in which the workgroups do not all walk the same number of tiles (786 432
     // blocks: the one-tile workgroups of the second generation would run ahead of the two-tile ones, 15.75 against 14.24 us).
-    if (cus != 0) {
-        const unsigned gen = blockIdx.x / cus;
-        if (gen == 1) __builtin_amdgcn_s_setprio(1);
-        if (gen == 2) __builtin_amdgcn_s_setprio(2);
-        if (gen >= 3) __builtin_amdgcn_s_setprio(3);
+    if (cus != 0) {  // (comparisons, not blockIdx / cus: a scalar division is ~25 instructions in front of the first load)
+        if (blockIdx.x >= 3 * cus) __builtin_amdgcn_s_setprio(3);
+        else if (blockIdx.x >= 2 * cus) __builtin_amdgcn_s_setprio(2);
+        else if (blockIdx.x >= cus) __builtin_amdgcn_s_setprio(1);
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ uint4 t_store[bu_lds_table_bytes(TARGET) / 16];  // the blob as far as TARGET reads it (BC7: its own tables in front)
@@ -302,6 +301,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             return t * tile_blocks + l;
         }
     };
+    // RECT launches hold whole tiles only: every lane of every tile has a block (keys are 0..19, never the "no block" 31), and the
+    // validity tests below fold away
+    auto has_block = [&](uint32_t k) { return RECT || k < 20u; };
     unsigned tile = blockIdx.x;
     // Table staging.  The staged 16-byte pieces of the LDS image are numbered 0..TVT-1: BC7's own tables, then the target's one or
     // two ranges of the common blob; piece i sits at t_store[tdst(i)] and comes from the same index of the image's source in device
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++) {
         const unsigned idx = gidx(tile, j * BU_WG + tid);
-        v[j] = (tile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+        v[j] = (RECT || (tile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid))) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
     }
     if constexpr (!SPLIT) {
 #pragma unroll
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         for (int j = 0; j < BU_BPT; j++) {
             const bool valid = RECT || (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid));  // (RECT: whole tiles only)
             key[j] = valid ? T.key_lut[v[j].x & 127u] : 31u;
-            uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && key[j] < 20u;
+            uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
         if (uniform) {
             uint32_t lead[BU_BPT];
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             const uint32_t st = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key[j] << 2), (int)run_excl) & 0xFFFFu;
-            dest[j] = key[j] < 20u ? st + pos[j] : 0u;
-            if (key[j] < 20u) {
+            dest[j] = has_block(key[j]) ? st + pos[j] : 0u;
+            if (has_block(key[j])) {
                 sblk[dest[j]] = v[j];
                 if constexpr (DIRECT) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
             }
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 const unsigned idx = gidx(ntile, j * BU_WG + tid);
-                vn[j] = (ntile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+                vn[j] = (ntile < n_tiles && (RECT || (idx < n_blocks && in_tile(j * BU_WG + tid)))) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
         BU_STAMP(4)
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         if constexpr (!DIRECT) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                if (key[j] < 20u) {
+                if (has_block(key[j])) {
                     const unsigned idx = gidx(tile, j * BU_WG + tid);
                     if constexpr (INBLOCK) {
                         uint4 r = sblk[dest[j]];
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 const unsigned idx = gidx(ntile, j * BU_WG + tid);
-                v[j] = (ntile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid)) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+                v[j] = (ntile < n_tiles && (RECT || (idx < n_blocks && in_tile(j * BU_WG + tid)))) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
             }
         }
         // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only

@@ -662,6 +662,47 @@ def run_atlas4096(env):
             ss = ms.value / 1e3 / args.steps
             extra["streams_%d" % ns] = {"us_per_atlas": round(ss * 1e6, 3), "mblocks_s": round(N_BLOCKS / ss / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / ss / 1e9, 1),
                                         "note": "%d HIP streams, launches of independent atlases overlap; wall clock; not the roofline row" % ns}
+        # a loop over 64 independent slices of 65 536 blocks (256 x 256 blocks: a 1024 x 1024 px mip), the shape of the per-slice
+        # loops of basis.rs:246-257: launches back to back on one stream, round-robin on 2 and 4 streams, the batch entry point on
+        # separate allocations (it fans out over four context streams) and on one contiguous allocation (it merges: ONE launch)
+        try:
+            ns, nbs = 64, 65536
+            s_in = [ins[k % nbuf][(k // nbuf) * nbs: (k // nbuf + 1) * nbs] for k in range(ns)]  # 64 distinct 1 MiB pieces, 16 MiB apart
+            s_out = [outs[k % nbuf][(k // nbuf) * nbs: (k // nbuf + 1) * nbs] for k in range(ns)]
+            VPn, SZn = ctypes.c_void_p * ns, ctypes.c_size_t * ns
+            p_in, p_out, p_n = VPn(*[t.data_ptr() for t in s_in]), VPn(*[t.data_ptr() for t in s_out]), SZn(*([nbs] * ns))
+            cat_in = torch.cat(s_in).contiguous()
+            cat_out = torch.empty((ns * nbs, 16), dtype=torch.uint8, device=dev)
+            c_in = VPn(*[cat_in[k * nbs:(k + 1) * nbs].data_ptr() for k in range(ns)])
+            c_out = VPn(*[cat_out[k * nbs:(k + 1) * nbs].data_ptr() for k in range(ns)])
+            side = [torch.cuda.Stream(device=dev) for _ in range(4)]
+
+            def loop_streams(n_streams):
+                for k in range(ns):
+                    st_ = env.stream if n_streams == 1 else side[k % n_streams]
+                    lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, p_in[k], nbs, p_out[k], 256, 0, None, ctypes.c_void_p(st_.cuda_stream))
+
+            def batch(pi, po):
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, ns, pi, p_n, po, 256, None, None, sp) == 0
+
+            def wall(fn, reps=20):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps
+
+            rows = {"one_stream": wall(lambda: loop_streams(1)), "two_streams": wall(lambda: loop_streams(2)), "four_streams": wall(lambda: loop_streams(4)),
+                    "batch_call_separate_allocations": wall(lambda: batch(p_in, p_out)), "batch_call_contiguous": wall(lambda: batch(c_in, c_out))}
+            extra["slices_64_x_65536"] = {k: {"us_per_batch": round(v * 1e6, 2), "mblocks_s": round(ns * nbs / v / 1e6, 1)} for k, v in rows.items()}
+            extra["slices_64_x_65536"]["verified"] = bool(torch.equal(cat_out[:nbs], outs[0][:nbs]))
+            extra["slices_64_x_65536"]["note"] = ("wall clock per 64-slice batch (4 Mi blocks): a 65 536-block slice fills a quarter of the chip, so launches "
+                                                  "on one stream leave it mostly idle; bu_uastc_transcode_batch_device is what a per-slice loop should call")
+            del cat_in, cat_out
+        except Exception as e:  # secondary rows must never break the headline line
+            extra["slices_64_x_65536_error"] = repr(e)
         # mode-coherent atlases (mode chosen per 8x8-block tile): texture-like, waves see 1-2 modes
         coh = []
         for k in range(min(nbuf, 64)):
@@ -737,6 +778,26 @@ def run_atlas4096(env):
                 extra[name] = {"gb_s": round(bpb * nbl / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3), "mblocks_s": round(nbl / ts / 1e6, 1),
                                "bytes_per_block": bpb, "blocks": nbl}
             del d_idx, d_o8, d_o64
+            # the same kernels on a large slice (2^22 blocks, 2048 x 2048 blocks): the codebooks are staged in LDS from 2^19 blocks up
+            nbl2 = 1 << 22
+            d_idx2 = [torch.from_numpy(synth.etc1s_indices(nbl2, 4096, 8192, seed=300 + k).view(np.int32)).to(dev) for k in range(4)]
+            d_o8b = [torch.empty((nbl2, 8), dtype=torch.uint8, device=dev) for _ in range(4)]
+            d_o64b = [torch.empty((nbl2, 64), dtype=torch.uint8, device=dev) for _ in range(4)]
+            for name, fn, bpb in (("etc1s_to_etc1_4Mi_blocks", lambda k: lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx2[k].data_ptr(), nbl2, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, d_o8b[k].data_ptr(), None, sp), 12),
+                                  ("etc1s_to_rgba32_4Mi_blocks", lambda k: lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx2[k].data_ptr(), None, 2048, 2048, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, d_o64b[k].data_ptr(), None, sp), 68)):
+                for k in range(4):
+                    fn(k)
+                torch.cuda.synchronize()
+                e0.record(stream)
+                reps = 32
+                for i in range(reps):
+                    fn(i % 4)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ts = e0.elapsed_time(e1) / 1e3 / reps
+                extra[name] = {"gb_s": round(bpb * nbl2 / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3), "mblocks_s": round(nbl2 / ts / 1e6, 1),
+                               "bytes_per_block": bpb, "blocks": nbl2, "frac_of_hbm_peak": round(bpb * nbl2 / ts / 1e9 / HBM_PEAK_GBS, 3)}
+            del d_idx2, d_o8b, d_o64b
         except Exception as e:  # secondary rows must never break the headline line
             extra["etc1s_error"] = repr(e)
         # config 4 end to end: a .basis ETC1S file (16 slices x 16 384 blocks) through read_to_rgba -- host BasisLZ decode of
@@ -763,6 +824,20 @@ def run_atlas4096(env):
                                                 "mblocks_s": round(16 * 16384 / file_s / 1e6, 1),
                                                 "ms_slice_by_slice_host_decode_only": round(seq_s * 1e3, 3),
                                                 "note": "whole-file API: parse + CRC + BasisLZ decode of all slices on the host cores + GPU decode + download"}
+            # config 4 as stated: ONE slice of 512 x 512 blocks (the entropy decode of a single slice is serial: one host core)
+            fone, _, _ = bb.etc1s_file(np.random.default_rng(45), [(512, 512)], n_codebook=4096)
+            one_out = ctx.host_alloc(bu.read_query(_lib.READ_RGBA, fone)[1])
+            bu.read_to_rgba(fone, ctx, out=one_out)
+            times = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                bu.read_to_rgba(fone, ctx, out=one_out)
+                times.append(time.perf_counter() - t0)
+            one_s = sorted(times)[len(times) // 2]
+            ctx.host_free(one_out)
+            extra["etc1s_file_one_512x512_slice_read_to_rgba"] = {"blocks": 512 * 512, "file_bytes": len(fone), "ms_per_file": round(one_s * 1e3, 3),
+                                                                  "mblocks_s": round(512 * 512 / one_s / 1e6, 1),
+                                                                  "note": "BASELINE config 4 at its stated size through the whole-file API; host BasisLZ decode dominates"}
         except Exception as e:
             extra["etc1s_file_error"] = repr(e)
         # configs 1/2 through the whole-file API: a .basis UASTC file holding the 4096x4096 atlas -> read_to_bc7

@@ -103,7 +103,10 @@ bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16]
 /* Same work as the two slice entry points above on memory already resident in HBM.
  *   d_in            n_blocks * 16 bytes, 16-byte aligned
  *   d_out           n_blocks * block_bytes, 16-byte aligned (8 for ETC1)
- *   blocks_per_row  only read for BU_TARGET_RGBA32 (image pitch).  For RGBA32 n_blocks must be a whole number of
+ *   blocks_per_row  the width of the slice's block grid; 0 = unknown (block-linear targets only).  REQUIRED for BU_TARGET_RGBA32
+ *                   (image pitch).  For the block-linear targets it never changes a byte of the result; a multiple of 64 (at
+ *                   least 128) over whole rows of 64 x 16-block tiles lets the kernels sort rectangles of the image instead of
+ *                   strips of 1024 consecutive blocks (faster on real, mode-coherent textures).  For RGBA32 n_blocks must be a whole number of
  *                   block rows (n_blocks % blocks_per_row == 0, else BU_ERR_ARGUMENT): the four pixel rows of a
  *                   block row are stored at the full image pitch, so a ragged last row would be written past
  *                   64 * n_blocks bytes (uastc.rs:95 sizes the image the same way and would panic there).
@@ -114,6 +117,16 @@ bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16]
  * Returns launch/argument errors only; block errors arrive through d_status. */
 bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
                                     size_t blocks_per_row, uint64_t block_index_base, uint64_t* d_status, void* stream);
+/* A loop over independent slices (the per-slice loops of basis.rs:246-257) as ONE call: slice i = n_blocks[i] blocks at d_in[i]
+ * -> d_out[i], block indices numbered from index_base[i] (NULL: slices numbered back to back from 0).  The slices must not
+ * depend on each other (no output aliasing an input); the call starts when `stream` reaches it and `stream` continues when
+ * every slice is done.  Slices that are contiguous in memory, in order, are merged into one launch (the fastest form: one
+ * launch over 64 x 65 536 blocks takes 37 us where 64 launches on one stream take 300); the remaining launches are spread
+ * over context-owned streams so that small slices, which fill only a fraction of the chip each, run side by side.
+ * RGBA32: every slice uses the same blocks_per_row. */
+bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
+                                          const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
+                                          const uint64_t* index_base, uint64_t* d_status, void* stream);
 
 /* value a status word must hold before the launches that report into it (all ones) */
 #define BU_STATUS_WORD_CLEAR 0xFFFFFFFFFFFFFFFFull

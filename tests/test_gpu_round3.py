@@ -194,3 +194,58 @@ def test_etc1s_kernels_with_codebooks_staged_in_lds(ctx, oracle, n_ep, n_sel):
         with pytest.raises(BasisuError) as e:
             call()
         assert e.value.status == _lib.ERR_INDEX_RANGE and e.value.first_bad_block == 400_000
+
+
+def test_batch_entry_point_merges_contiguous_slices_and_fans_out_the_rest(ctx, golden):
+    """bu_uastc_transcode_batch_device: a loop over independent slices in one call.  Contiguous slices (one launch), slices in
+    separate allocations (side by side on context streams), a mix with an empty slice, RGBA32 slices of one pitch -- same bytes
+    as slice-by-slice calls, block errors numbered through the whole batch (basis.rs:246-257)."""
+    import torch
+
+    from basisu_rs_amd import BasisuError
+
+    lib = _lib.load()
+    sizes = [4096, 65536, 0, 1024, 70000, 8]
+    idx = [synth.gold_indices(n, seed=500 + k) for k, n in enumerate(sizes)]
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n_s = len(sizes)
+    VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+
+    def run(target, bb, ins, outs, bpr=0, status=None):
+        st = lib.bu_uastc_transcode_batch_device(ctx.handle, target, n_s, VP(*[t.data_ptr() if t.numel() else None for t in ins]), SZ(*sizes),
+                                                 VP(*[t.data_ptr() if t.numel() else None for t in outs]), bpr, None,
+                                                 ctypes.c_void_p(status.data_ptr()) if status is not None else None, sp)
+        assert st == 0
+        torch.cuda.synchronize()
+
+    # (a) separate allocations
+    ins = [torch.from_numpy(golden["uastc"][i].copy()).cuda() if len(i) else torch.empty((0, 16), dtype=torch.uint8, device="cuda") for i in idx]
+    for name, target, bb in (("bc7", _lib.BC7, 16), ("etc1", _lib.ETC1, 8)):
+        outs = [torch.zeros((n, bb), dtype=torch.uint8, device="cuda") for n in sizes]
+        run(target, bb, ins, outs)
+        for k in range(n_s):
+            assert (outs[k].cpu().numpy() == golden[name][idx[k]]).all(), (name, k)
+    # (b) one contiguous buffer cut into the same slices: merged into a single launch
+    cat_in = torch.cat(ins)
+    cat_out = torch.zeros((sum(sizes), 16), dtype=torch.uint8, device="cuda")
+    ofs = np.concatenate([[0], np.cumsum(sizes)])
+    run(_lib.BC7, 16, [cat_in[ofs[k]:ofs[k + 1]] for k in range(n_s)], [cat_out[ofs[k]:ofs[k + 1]] for k in range(n_s)])
+    assert (cat_out.cpu().numpy() == golden["bc7"][np.concatenate(idx)]).all()
+    # (c) a failing block in slice 4 and one in slice 1: the lower batch-wide index is reported
+    bad = [t.clone() for t in ins]
+    bad[4][17, 0] = 69
+    bad[1][60000, 0] = 69
+    st = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(st)
+    run(_lib.BC7, 16, bad, [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for n in sizes], status=st)
+    with pytest.raises(BasisuError) as e:
+        ctx.status_word_check(int(st.item()))
+    assert e.value.first_bad_block == 4096 + 60000
+    # (d) RGBA32: whole block rows of one pitch per slice
+    bpr = 8
+    r_out = [torch.zeros((n // bpr * 4, bpr * 16), dtype=torch.uint8, device="cuda") for n in sizes]
+    run(_lib.RGBA32, 64, ins, r_out, bpr=bpr)
+    for k, n in enumerate(sizes):
+        if n:
+            got = r_out[k].cpu().numpy().reshape(n // bpr, 4, bpr, 16).transpose(0, 2, 1, 3).reshape(n, 64)
+            assert (got == golden["rgba"][idx[k]]).all(), k
