@@ -344,8 +344,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             const int i = k * WGS + (int)tid;
             tv[k] = i < TVT ? tsrc[tdst(i)] : make_uint4(0, 0, 0, 0);
         }
-        static_assert(offsetof(BuTables, key_lut) % 4 == 0 && sizeof(T.key_lut) == 128, "key_lut is staged as 32 dwords");
-        if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut)[tid] = reinterpret_cast<const uint32_t*>(tables->t.key_lut)[tid];
+        static_assert(offsetof(BuTables, key_lut) % 4 == 0 && sizeof(T.key_lut[0]) == 128, "the target's key_lut is staged as 32 dwords");
+        if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut[TARGET])[tid] = reinterpret_cast<const uint32_t*>(tables->t.key_lut[TARGET])[tid];
     }
     bool tables_staged = !SPLIT;
     if (tid < 64) (&cnt[0][0])[tid] = 0;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             const bool valid = RECT || (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid));  // (RECT: whole tiles only)
-            key[j] = valid ? T.key_lut[v[j].x & 127u] : 31u;
+            key[j] = valid ? T.key_lut[TARGET][v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
         if (uniform) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
             if (active) {
                 switch (r) {  // the run number IS the sort key: run k holds mode BU_COST_ORDER[k] (run 19: invalid mode codes)
 #define BU_CASE(k) \
-    case k: st = bu_block_mode<TARGET, BU_COST_ORDER[k]>(T, b, o); break;
+    case k: st = bu_block_mode<TARGET, BU_COST_ORDER[TARGET][k]>(T, b, o); break;
                     BU_CASE(0) BU_CASE(1) BU_CASE(2) BU_CASE(3) BU_CASE(4) BU_CASE(5) BU_CASE(6) BU_CASE(7) BU_CASE(8) BU_CASE(9)
                     BU_CASE(10) BU_CASE(11) BU_CASE(12) BU_CASE(13) BU_CASE(14) BU_CASE(15) BU_CASE(16) BU_CASE(17) BU_CASE(18)
 #undef BU_CASE

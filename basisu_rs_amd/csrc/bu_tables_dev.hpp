@@ -76,9 +76,15 @@ static_assert(31u * BU_Q_M < (1u << 24), "the quantiser runs on v_mad_u32_u24");
 // (bu_table_range below): every workgroup copies its tables from L2 into LDS, and with four workgroups per CU on
 // 1024-block tiles the whole 9.3 KiB blob would be more than half of the 16 KiB of payload the workgroup moves.
 //   [BC7 only][common front-end][texel unpack: RGBA32, ETC][ASTC only][ETC only]
-// Modes by descending length of their code path (BC7 VALU counts, tools/exp/mode_isa.py): the mode-sorted kernel lays the
-// runs out in this order so that dynamically scheduled chunks end with the cheap ones.  Entry 19 = invalid mode code.
-constexpr uint8_t BU_COST_ORDER[20] = {3, 9, 4, 16, 2, 7, 12, 1, 11, 6, 18, 5, 10, 14, 0, 8, 17, 13, 15, 19};
+// Modes by descending cost of their code path, per target (tools/exp/mode_isa.py): the mode-sorted kernel lays the runs out in
+// this order so that dynamically scheduled chunks end with the cheap ones.  Entry 19 = invalid mode code.
+constexpr uint8_t BU_COST_ORDER[5][20] = {  // [target: ASTC, BC7, ETC1, ETC2, RGBA32], est. SIMD clocks of round 3's paths
+    {3, 4, 7, 11, 12, 10, 9, 0, 2, 6, 18, 13, 14, 5, 1, 16, 17, 15, 8, 19},
+    {4, 7, 9, 11, 12, 3, 16, 6, 18, 2, 5, 10, 14, 1, 0, 17, 13, 8, 15, 19},
+    {3, 2, 4, 7, 18, 6, 9, 0, 11, 12, 10, 5, 16, 14, 1, 13, 15, 17, 8, 19},
+    {12, 10, 9, 15, 11, 16, 14, 13, 3, 2, 17, 4, 7, 6, 18, 0, 5, 1, 8, 19},
+    {2, 3, 12, 10, 11, 9, 18, 4, 7, 0, 6, 5, 14, 13, 16, 17, 15, 1, 8, 19},
+};
 
 // The BC7 packer's own tables (bu_uastc_bc7.hpp).  They sit IN FRONT of the common blob, in device memory and in the LDS of the
 // BC7 kernels alike (BuTablesAll), so that only BC7 reserves and stages them; bu_bc7_tables() steps back from the common blob.
@@ -112,7 +118,7 @@ struct BuTables {
     uint16_t quint3[128];  // 7-bit group -> 3 quints, digit i in bits [3i,3i+3)  (uastc.rs:629-655)
     uint8_t deq[504];      // endpoint dequantisation, ranges 7,8,11,12,13,18,19  (uastc.rs:585-614)
     uint8_t mode_lut[128];    // uastc.rs:560-577
-    uint8_t key_lut[128];     // sort key of the mode-sorted kernel: position of the block's mode in BU_COST_ORDER (19 = invalid code)
+    uint8_t key_lut[5][128];  // sort key of the mode-sorted kernel, per target: position of the block's mode in BU_COST_ORDER[target] (19 = invalid code)
     alignas(16) BuPart part[61];  // partition records (every target but BC7, which reads part7: last of the group, outside BC7's range)
     // ---- texel unpack (RGBA32, ETC1, ETC2) ----
     alignas(16) uint32_t wpack[64];  // raw weight -> (256 - 4w) | 4w << 16 with w = unquant_weights (uastc.rs:697-719); offset 2^bits - 2
@@ -329,9 +335,11 @@ static inline void bu_build_tables(BuTablesAll* all)
     }
     for (int i = 0; i < 128; i++) t->mode_lut[i] = BU_MODE_LUT[i];
     for (int i = 0; i < 128; i++) {
-        t->key_lut[i] = 19;
-        for (int k = 0; k < 20; k++)
-            if (BU_COST_ORDER[k] == BU_MODE_LUT[i]) t->key_lut[i] = (uint8_t)k;
+        for (int tg = 0; tg < 5; tg++) {
+            t->key_lut[tg][i] = 19;
+            for (int k = 0; k < 20; k++)
+                if (BU_COST_ORDER[tg][k] == BU_MODE_LUT[i]) t->key_lut[tg][i] = (uint8_t)k;
+        }
     }
     for (int i = 0; i < 30; i++) {
         uint64_t m = 0;
