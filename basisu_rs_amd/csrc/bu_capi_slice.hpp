@@ -196,23 +196,54 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
     }
     if (runs.empty()) return BU_OK;
     if (runs.size() == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s);
-    // several launches: side by side on up to four context-owned streams, forked from and joined back into `stream`
+    // several runs at unrelated addresses: ONE launch over a per-tile descriptor table (kernel layout MULTI).  Launching them one
+    // by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices of 65 536 blocks: 290 us on one
+    // stream, 230-260 us on 2-8, profiles/r03_small_slices_streams_vs_one_launch.txt).
+    std::vector<BuTileDesc> descs;
+    for (const Run& r : runs) {
+        if (r.n > ((size_t)1 << 32) - 1024) return BU_ERR_ARGUMENT;  // (a tile's first block is a 32-bit index inside its slice)
+        for (size_t first = 0; first < r.n; first += 1024)
+            descs.push_back(BuTileDesc{reinterpret_cast<const uint4*>(r.in), r.out, (uint32_t)first, (uint32_t)(r.n - first < 1024 ? r.n - first : 1024), r.base});
+    }
+    const size_t n_tiles = descs.size();
+    if (n_tiles > 65536) {  // beyond one launch's tile numbering: fall back to a launch per run (large slices: the launch cost no longer matters)
+        for (const Run& r : runs) {
+            bu_status st = bu_launch_uastc(ctx, target, r.in, r.n, r.out, blocks_per_row, r.base, d_status, s);
+            if (st) return st;
+        }
+        return BU_OK;
+    }
     BU_HIP(ctx, hipSetDevice(ctx->device));
-    const int lanes = runs.size() < 4 ? (int)runs.size() : 4;
-    for (int i = 0; i < lanes; i++)
-        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
-    BuDrain drain(ctx);
-    BU_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    for (int i = 0; i < lanes; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
-    for (size_t k = 0; k < runs.size(); k++) {
-        bu_status st = bu_launch_uastc(ctx, target, runs[k].in, runs[k].n, runs[k].out, blocks_per_row, runs[k].base, d_status, ctx->extra_streams[k % lanes]);
-        if (st) return st;
+    void* d_desc = nullptr;
+    BU_HIP(ctx, hipMallocAsync(&d_desc, n_tiles * sizeof(BuTileDesc), s));  // stream-ordered: freed behind the kernel, no host synchronisation
+    hipError_t e = hipMemcpyAsync(d_desc, descs.data(), n_tiles * sizeof(BuTileDesc), hipMemcpyHostToDevice, s);  // pageable source: staged before the call returns
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(d_desc, s);
+        return bu_fail(ctx, e, "hipMemcpyAsync (tile descriptors)");
     }
-    for (int i = 0; i < lanes; i++) {
-        BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[i]));
-        BU_HIP(ctx, hipStreamWaitEvent(s, ctx->ev1, 0));
+    unsigned long long* stw = reinterpret_cast<unsigned long long*>(d_status);
+    const uint4* din = static_cast<const uint4*>(d_desc);
+    const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
+#define BU_GO_MULTI(T)                                                                                                                    \
+    do {                                                                                                                                  \
+        if (one_per_cu)                                                                                                                   \
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 1, 1, false, false, 0, BU_LAYOUT_MULTI>), dim3((unsigned)n_tiles), dim3(1024), 0, s, din, \
+                               nullptr, (unsigned)(n_tiles * 1024), (unsigned)blocks_per_row, 0ull, stw, ctx->d_tables, 0u, 1024u BU_STAMP_PASS); \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0, BU_LAYOUT_MULTI>), dim3((unsigned)n_tiles), dim3(512), 0, s, din,   \
+                               nullptr, (unsigned)(n_tiles * 1024), (unsigned)blocks_per_row, 0ull, stw, ctx->d_tables, 0u, 1024u BU_STAMP_PASS); \
+    } while (0)
+    switch (target) {
+    case BU_TARGET_ASTC: BU_GO_MULTI(BU_TGT_ASTC); break;
+    case BU_TARGET_BC7: BU_GO_MULTI(BU_TGT_BC7); break;
+    case BU_TARGET_ETC1: BU_GO_MULTI(BU_TGT_ETC1); break;
+    case BU_TARGET_ETC2: BU_GO_MULTI(BU_TGT_ETC2); break;
+    default: BU_GO_MULTI(BU_TGT_RGBA); break;
     }
-    drain.armed = false;
+#undef BU_GO_MULTI
+    e = hipGetLastError();
+    (void)hipFreeAsync(d_desc, s);
+    if (e != hipSuccess) return bu_fail(ctx, e, "multi-slice launch");
     return BU_OK;
 }
 

@@ -229,7 +229,19 @@ struct BuBigCfg<BU_TGT_ASTC> {
 // sort works on the index inside the tile).  A compile-time variant: as a run-time switch the extra index arithmetic cost the
 // strip path 4 % (round 2).
 constexpr unsigned BU_RECT_W = 64;
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, bool RECT = false>
+// MULTI (LAYOUT 2): the launch covers SEVERAL slices at unrelated addresses -- `in` points at one BuTileDesc per tile (the slice's
+// input and output, the tile's first block inside the slice, how many blocks it holds, the slice's block-index base) instead of
+// at blocks; tiles never straddle slices.  A loop over small slices becomes one launch (bu_uastc_transcode_batch_device).
+struct BuTileDesc {
+    const uint4* in;  // the SLICE's first block
+    void* out;        // the slice's output
+    uint32_t first;   // index of the tile's first block inside the slice
+    uint32_t n;       // blocks in this tile (1..tile size)
+    uint64_t base;    // block-index base of the slice (status words)
+};
+static_assert(sizeof(BuTileDesc) == 32, "descriptor layout is shared with the host code");
+enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
@@ -259,6 +271,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // lives IN row 0 of that output tile: a lane reads its block from slot s and later overwrites exactly slot s with
     // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
     // which is what lets two workgroups share a CU.
+    constexpr bool RECT = LAYOUT == BU_LAYOUT_RECT, MULTI = LAYOUT == BU_LAYOUT_MULTI;
+    static_assert(!MULTI || (!PREFETCH && !DIRECT), "the multi-slice layout is compiled for the plain one-tile-at-a-time shapes");
     constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
     static_assert(!BU_ALIAS || bu_lds_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
@@ -305,6 +319,20 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // validity tests below fold away
     auto has_block = [&](uint32_t k) { return RECT || k < 20u; };
     unsigned tile = blockIdx.x;
+    // MULTI: the current tile's descriptor (wave-uniform: scalar loads); every other layout addresses the one slice of the launch
+    BuTileDesc td = {in, out, 0u, 0u, base};
+    auto load_desc = [&](unsigned t) {
+        if constexpr (MULTI) {
+            if (t < n_tiles) td = reinterpret_cast<const BuTileDesc*>(in)[t];
+        }
+    };
+    load_desc(tile);
+    // block l of tile t: where it is loaded from, whether it exists
+    auto blk_src = [&](unsigned t, unsigned l) { return MULTI ? td.in + (td.first + l) : in + gidx(t, l); };
+    auto blk_valid = [&](unsigned t, unsigned l) {
+        if constexpr (MULTI) return t < n_tiles && l < td.n;
+        else return RECT ? t < n_tiles : (t < n_tiles && gidx(t, l) < n_blocks && in_tile(l));
+    };
     // Table staging.  The staged 16-byte pieces of the LDS image are numbered 0..TVT-1: BC7's own tables, then the target's one or
     // two ranges of the common blob; piece i sits at t_store[tdst(i)] and comes from the same index of the image's source in device
     // memory.  Every thread issues ALL its table loads back to back (round 2 ran a load / wait / store loop: a second L2 round
@@ -328,10 +356,8 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     }
     uint4 v[BU_BPT];
 #pragma unroll
-    for (int j = 0; j < BU_BPT; j++) {
-        const unsigned idx = gidx(tile, j * BU_WG + tid);
-        v[j] = (RECT || (tile < n_tiles && idx < n_blocks && in_tile(j * BU_WG + tid))) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
-    }
+    for (int j = 0; j < BU_BPT; j++)
+        v[j] = (RECT || blk_valid(tile, j * BU_WG + tid)) ? bu_ld_stream(blk_src(tile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
     if constexpr (!SPLIT) {
 #pragma unroll
         for (int k = 0; k < TVN; k++) {
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         bool uniform = true;
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
-            const bool valid = RECT || (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid));  // (RECT: whole tiles only)
+            const bool valid = RECT || (MULTI ? (unsigned)(j * BU_WG) + tid < td.n : (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid)));  // (RECT: whole tiles only)
             key[j] = valid ? T.key_lut[TARGET][v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
@@ -417,8 +443,7 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
-                const unsigned idx = gidx(ntile, j * BU_WG + tid);
-                vn[j] = (ntile < n_tiles && (RECT || (idx < n_blocks && in_tile(j * BU_WG + tid)))) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
+                vn[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
             }
         }
         BU_STAMP(4)
@@ -494,7 +519,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 if (has_block(key[j])) {
-                    const unsigned idx = gidx(tile, j * BU_WG + tid);
+                    const unsigned idx = MULTI ? td.first + j * BU_WG + tid : gidx(tile, j * BU_WG + tid);  // (MULTI: inside the tile's slice)
+                    void* const out = td.out;                  // (the launch's `out` unless MULTI)
+                    const unsigned long long base = td.base;
                     if constexpr (INBLOCK) {
                         uint4 r = sblk[dest[j]];
                         if ((r.x & 0xFFu) == 0u) {  // no valid block of these formats starts with a zero byte: word 3 is the status
@@ -533,11 +560,9 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
         } else {
+            load_desc(ntile);
 #pragma unroll
-            for (int j = 0; j < BU_BPT; j++) {
-                const unsigned idx = gidx(ntile, j * BU_WG + tid);
-                v[j] = (ntile < n_tiles && (RECT || (idx < n_blocks && in_tile(j * BU_WG + tid)))) ? bu_ld_stream(in + idx) : make_uint4(0, 0, 0, 0);
-            }
+            for (int j = 0; j < BU_BPT; j++) v[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
         }
         // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only
         // after its reads of this tile's results have completed

@@ -241,6 +241,23 @@ def test_batch_entry_point_merges_contiguous_slices_and_fans_out_the_rest(ctx, g
     with pytest.raises(BasisuError) as e:
         ctx.status_word_check(int(st.item()))
     assert e.value.first_bad_block == 4096 + 60000
+    # (c2) the same through a target that keeps its statuses in a byte per block (ETC2), and a batch of more tiles than CUs
+    st.fill_(0)
+    ctx.status_word_reset(st)
+    run(_lib.ETC2, 16, bad, [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for n in sizes], status=st)
+    with pytest.raises(BasisuError) as e:
+        ctx.status_word_check(int(st.item()))
+    assert e.value.first_bad_block == 4096 + 60000
+    many = 300  # 300 slices of 3 000 blocks = 900 tiles, every slice in its own allocation (tiles of 1024, 1024, 952 blocks)
+    m_idx = [synth.gold_indices(3000, seed=9000 + k) for k in range(many)]
+    m_in = [torch.from_numpy(golden["uastc"][i].copy()).cuda() for i in m_idx]
+    m_out = [torch.zeros((3000, 16), dtype=torch.uint8, device="cuda") for _ in range(many)]
+    VPm, SZm = ctypes.c_void_p * many, ctypes.c_size_t * many
+    assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.ASTC, many, VPm(*[t.data_ptr() for t in m_in]), SZm(*([3000] * many)),
+                                               VPm(*[t.data_ptr() for t in m_out]), 0, None, None, sp) == 0
+    torch.cuda.synchronize()
+    for k in range(many):
+        assert (m_out[k].cpu().numpy() == golden["astc"][m_idx[k]]).all(), k
     # (d) RGBA32: whole block rows of one pitch per slice
     bpr = 8
     r_out = [torch.zeros((n // bpr * 4, bpr * 16), dtype=torch.uint8, device="cuda") for n in sizes]
