@@ -28,7 +28,18 @@ for seed in range(SEED0, SEED0 + int(os.environ.get("FUZZ_SEEDS", 4))):
                     assert e.first_bad_block == bad[0], (t, e.first_bad_block, bad[0])
                 use = blocks.copy(); use[bad] = synth.atlas_rand(1, seed=1)[0]
                 want, st2 = o.batch(t, use); assert (st2 == 0).all()
-            if t == "rgba":
+            if os.environ.get("FUZZ_RECT"):  # device entry point with the block grid given: the rectangular-tile kernels (BC7, ASTC, RGBA32)
+                import torch
+                d_in = torch.from_numpy(use).cuda()
+                if t == "rgba":
+                    d_out = torch.empty((n // 1024 * 4, 1024 * 16), dtype=torch.uint8, device="cuda")
+                    ctx.transcode_device(_lib.RGBA32, d_in, n, d_out, blocks_per_row=1024)
+                    got = np.ascontiguousarray(d_out.cpu().numpy().reshape(n // 1024, 4, 1024, 16).transpose(0, 2, 1, 3)).reshape(n, 64)
+                else:
+                    d_out = torch.empty((n, _lib.BLOCK_BYTES[FMT[t]]), dtype=torch.uint8, device="cuda")
+                    ctx.transcode_device(FMT[t], d_in, n, d_out, blocks_per_row=1024)
+                    got = d_out.cpu().numpy()
+            elif t == "rgba":
                 img = ctx.decode_to_rgba(use, 1024).reshape(n // 1024, 4, 1024, 16)
                 got = np.ascontiguousarray(img.transpose(0, 2, 1, 3)).reshape(n, 64)
             else:
