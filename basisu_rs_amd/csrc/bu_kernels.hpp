@@ -258,10 +258,13 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     // the gaps: BC7 10.51 -> 10.2 us, ASTC 9.74 -> 9.47, RGBA32 20.4 -> 19.95 in an A/B run.  Speed only: any placement is correct.
     // cus = 0 switches it off: RGBA32 launches in which the workgroups do not all walk the same number of tiles (786 432
     // blocks: the one-tile workgroups of the second generation would run ahead of the two-tile ones, 15.75 against 14.24 us).
+    // Round 3, on the leaner kernels: generation priorities 0, 3, 2, 1 beat 0, 1, 2, 3 for BC7 (9.13 -> 8.96 us) and ASTC (9.0 -> 8.8),
+    // not for RGBA32 (15.85 -> 16.0); no priorities 9.14 / 9.04 / 17.4 (profiles/r03_ab_wave_priorities.txt).
     if (cus != 0) {  // (comparisons, not blockIdx / cus: a scalar division is ~25 instructions in front of the first load)
-        if (blockIdx.x >= 3 * cus) __builtin_amdgcn_s_setprio(3);
+        constexpr bool ROT = TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC;
+        if (blockIdx.x >= 3 * cus) __builtin_amdgcn_s_setprio(ROT ? 1 : 3);
         else if (blockIdx.x >= 2 * cus) __builtin_amdgcn_s_setprio(2);
-        else if (blockIdx.x >= cus) __builtin_amdgcn_s_setprio(1);
+        else if (blockIdx.x >= cus) __builtin_amdgcn_s_setprio(ROT ? 3 : 1);
     }
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ uint4 t_store[bu_lds_table_bytes(TARGET) / 16];  // the blob as far as TARGET reads it (BC7: its own tables in front)
