@@ -76,3 +76,12 @@ def test_oracle_mt_driver_matches_sequential(golden, oracle):
     out = np.zeros_like(seq)
     st = oracle.lib.bu_oracle_transcode_mt(1, blocks.ctypes.data, blocks.size, out.ctypes.data, 4)
     assert st == 0 and (out == seq).all()
+
+
+def test_oracle_bit_io_reproduces_the_reference_unit_tests(oracle):
+    """the reference's unit tests of its bit reader / writers (bitreader.rs:63-100, bitwriter.rs:118-225: 16 patterns x every
+    (offset, length) below 32, four procedures) run on the oracle's rd_* / wr_* / wrr_* restatements: 81 920 checks, no mismatch"""
+    import ctypes
+
+    oracle.lib.bu_oracle_selftest_bitio.restype = ctypes.c_uint64
+    assert oracle.lib.bu_oracle_selftest_bitio() == 0
