@@ -52,7 +52,7 @@ struct BuPart7 {
     uint32_t w3;   // 3-bit weights (UASTC mode 2, patterns [0,30)): [0:6) 3 * ua + 2 (the UASTC anchor's MSB), [6:12) 3 * a1 + 2 (BC7's)
 };
 static_assert(sizeof(BuPart7) == 16, "BuPart7 must be 16 bytes");
-struct BuU2 {
+struct alignas(8) BuU2 {
     uint32_t x, y;
 };
 struct alignas(16) BuU4 {

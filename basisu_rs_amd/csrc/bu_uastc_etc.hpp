@@ -305,34 +305,34 @@ BU_DEV int bu_block_etc(const BuTables& T, const BuBlk& b, uint32_t out[4])
             nthr[sb][1] = (uint32_t)((int32_t)n12 >> 1);
             nthr[sb][2] = (uint32_t)((int32_t)n23 >> 1);
         }
-        // the top-right and bottom-left 2x2 quadrants change half with the flip bit: pick their thresholds once.
-        // Threshold 2 is kept as its distance from threshold 0: luma - thr2 = (luma - thr0) + (thr0 - thr2), an add instead of a dot4
-        uint32_t nthq[4][3];
-        BU_UNROLL
-        for (int k = 0; k < 3; k++) {
-            const uint32_t n0 = k == 2 ? nthr[0][2] - nthr[0][0] : nthr[0][k], n1 = k == 2 ? nthr[1][2] - nthr[1][0] : nthr[1][k];
-            nthq[0][k] = n0;
-            nthq[1][k] = f ? n0 : n1;  // x >= 2, y < 2
-            nthq[2][k] = f ? n1 : n0;  // x < 2, y >= 2
-            nthq[3][k] = n1;
-        }
         // sel = #thresholds <= luma; ETC1 code [3,2,0,1][sel]: high bit = sel < 2 = (luma < thr1), low bit = sel == 0 or
-        // sel == 3 = NOT (luma < thr0 xor luma < thr2) (the thresholds are monotone).  Texels are visited in descending
-        // pixel id (x*4 + y, etc.rs:376-392) and one v_alignbit_b32 per plane shifts the sign bit in from the right.
+        // sel == 3 = NOT (luma < thr0 xor luma < thr2) (the thresholds are monotone).  Two texels per instruction from the luma
+        // on: rel = luma - thr1, saturated to i16 (v_cvt_pk_i16_i32), keeps its sign, and the outer thresholds are at most
+        // (luma(+183) - luma(-47)) / 2 + 1 = 29 441 away from the middle one, so rel + (thr1 - thr0) and rel + (thr1 - thr2) with
+        // signed saturation (v_pk_add_i16 clamp) have the signs of luma - thr0 and luma - thr2 whatever was cut off.
+        // A word pairs pixel id k (x < 2) with k + 8 (x + 2, same row): the sign bytes of rel and of the xnor are the bits of
+        // pixel k / k + 8 in the high / low plane, one v_perm lines the four up in the block's byte order (ids 8..15 of the high
+        // plane first, etc.rs:376-392) and a shift + v_bfi per pair files them under the bits already there -- 70 instructions
+        // where round 2 spent 96 (two dot4, add, xor, two v_alignbit per texel).
+        // The top-right and bottom-left 2x2 quadrants change half with the flip bit: a row pair's two lanes take their
+        // thresholds from half 0 | half 0 (flipped rows 0-1), half 1 | half 1 (flipped rows 2-3) or half 0 | half 1.
         constexpr uint32_t LW = 54u | (183u << 8) | (19u << 16);
-        uint32_t msbp = 0, lsbx = 0;
+        const uint32_t da0 = nthr[0][0] - nthr[0][1], da1 = nthr[1][0] - nthr[1][1];  // thr1 - thr0 >= 0
+        const uint32_t db0 = nthr[0][2] - nthr[0][1], db1 = nthr[1][2] - nthr[1][1];  // thr1 - thr2 <= 0
+        const uint32_t da01 = bu_perm(da1, da0, 0x05040100u), db01 = bu_perm(db1, db0, 0x05040100u);
+        const uint32_t dpa[2] = {f ? bu_perm(da0, da0, 0x05040100u) : da01, f ? bu_perm(da1, da1, 0x05040100u) : da01};
+        const uint32_t dpb[2] = {f ? bu_perm(db0, db0, 0x05040100u) : db01, f ? bu_perm(db1, db1, 0x05040100u) : db01};
+        const uint32_t n1q[4] = {nthr[0][1], f ? nthr[0][1] : nthr[1][1], f ? nthr[1][1] : nthr[0][1], nthr[1][1]};  // by quadrant
+        uint32_t planes = 0;
         BU_UNROLL
-        for (int pid = 15; pid >= 0; pid--) {
-            const int xx = pid >> 2, y = pid & 3;
-            const int q = ((y >> 1) << 1) | (xx >> 1);
-            const uint32_t t = px[y * 4 + xx];
-            const uint32_t d0 = bu_udot4(t, LW, nthq[q][0]), d1 = bu_udot4(t, LW, nthq[q][1]), d2 = d0 + nthq[q][2];
-            msbp = bu_alignbit(msbp, d1, 31);       // (msbp << 1) | (luma < thr1)
-            lsbx = bu_alignbit(lsbx, d0 ^ d2, 31);  // (lsbx << 1) | (lt0 ^ lt2)
+        for (int k = 0; k < 8; k++) {
+            const int xx = k >> 2, y = k & 3, g = y >> 1;
+            const uint32_t rel = bu_cvt_pk_i16((int32_t)bu_udot4(px[y * 4 + xx], LW, n1q[2 * g]), (int32_t)bu_udot4(px[y * 4 + xx + 2], LW, n1q[2 * g + 1]));
+            const uint32_t mid = ~(bu_pk_add_i16_sat(rel, dpa[g]) ^ bu_pk_add_i16_sat(rel, dpb[g]));  // sign = NOT (lt0 xor lt2)
+            const uint32_t four = bu_perm(mid, rel, 0x05070103u);  // bit 7 of: high plane id k + 8, id k, low plane id k + 8, id k
+            planes = k == 0 ? four : bu_bfi(0x80808080u, four, planes >> 1);
         }
-        const uint32_t lsbp = ~lsbx & 0xFFFFu;
-        msbp &= 0xFFFFu;
-        col[1] = ((msbp >> 8) & 0xFFu) | ((msbp & 0xFFu) << 8) | (((lsbp >> 8) & 0xFFu) << 16) | ((lsbp & 0xFFu) << 24);
+        col[1] = planes;  // bit j of byte 0 / 1 / 2 / 3 = high plane id 8 + j / id j / low plane id 8 + j / id j
         return BU_ST_OK;
     }
 }

@@ -297,6 +297,34 @@ BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 #endif
 }
 
+// two i32 -> two i16 with signed saturation, the first in the low half (v_cvt_pk_i16_i32)
+BU_DEV uint32_t bu_cvt_pk_i16(int32_t lo, int32_t hi)
+{
+#if defined(__HIPCC__)
+    typedef short bu_s2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi));
+#else
+    const int32_t a = lo < -32768 ? -32768 : (lo > 32767 ? 32767 : lo), b = hi < -32768 ? -32768 : (hi > 32767 ? 32767 : hi);
+    return ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+#endif
+}
+// i16 lanes, a + b with signed saturation (v_pk_add_i16 ... clamp)
+BU_DEV uint32_t bu_pk_add_i16_sat(uint32_t a, uint32_t b)
+{
+#if defined(__HIPCC__)
+    typedef short bu_s2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(bu_s2, a), __builtin_bit_cast(bu_s2, b)));
+#else
+    uint32_t r = 0;
+    for (int k = 0; k < 2; k++) {
+        int32_t v = (int32_t)(int16_t)(a >> (16 * k)) + (int32_t)(int16_t)(b >> (16 * k));
+        v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+        r |= ((uint32_t)v & 0xFFFFu) << (16 * k);
+    }
+    return r;
+#endif
+}
+
 // (a & m) | (b & ~m)  (v_bfi_b32)
 BU_DEV uint32_t bu_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
