@@ -64,6 +64,76 @@ def pmc_traffic():
         return None
 
 
+def pmc_child():
+    """`bench.py --pmc-child`: the program rocprofv3's counter passes run (live_traffic): the shipped BC7 kernel once over each of
+    24 cold A-gold atlases of the headline size, nothing else"""
+    import torch
+
+    from basisu_rs_amd import Context, _lib, synth
+
+    ctx = Context(0)
+    g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+    dev = torch.device("cuda", 0)
+    gu = torch.from_numpy(g["uastc"]).to(dev)
+    ins, outs = [], []
+    for k in range(24):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(k + 1)
+        ins.append(gu[torch.randint(0, 608, (N_BLOCKS,), device=dev, generator=gen)].contiguous())
+        outs.append(torch.empty((N_BLOCKS, 16), dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    for k in range(24):
+        ctx.transcode_device(_lib.BC7, ins[k], N_BLOCKS, outs[k], blocks_per_row=NBX)
+    torch.cuda.synchronize()
+    ctx.close()
+
+
+def live_traffic(timeout_s=150):
+    """HBM bytes per launch of the BC7 kernel MEASURED IN THIS RUN: two child rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE,
+    then WRITE_SIZE: separate passes, nothing but --kernel-trace beside --pmc, the program directly after `--`) over
+    `bench.py --pmc-child`, run before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB; gfx950 reports half of
+    a wide coalesced read stream (MI355X_MICROARCH.md, HBM section): bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.
+    Returns (bytes, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled"
+    vals, t0 = {}, time.time()
+    work = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and "bu_uastc_sorted_kernel<1," in row["Kernel_Name"].replace("(int)", ""):
+                        got.append(float(row["Counter_Value"]))
+            if len(got) < 8:
+                return None, "rocprofv3 --pmc %s reported %d launches of the BC7 kernel" % (counter, len(got))
+            vals[counter] = sum(got) / len(got)
+            vals[counter + "_n"] = len(got)
+    except Exception as e:  # a timeout, a CSV layout this parser does not know: the committed passes stand in (pmc_traffic)
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    nbytes = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    return nbytes, ("measured in this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over `bench.py --pmc-child` "
+                    "(%d + %d launches of this kernel on cold atlases; (2 x FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 read correction of "
+                    "MI355X_MICROARCH.md; %.0f s)" % (vals["FETCH_SIZE_n"], vals["WRITE_SIZE_n"], time.time() - t0))
+
+
 def cpu_baseline(golden, idx, budget_s=12.0):
     """oracle timed on the host: 1 thread and all hardware threads, bounded sample"""
     from oracle.pyoracle import Oracle
@@ -139,10 +209,22 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the verified, timed headline launches (no context rows, no CPU leg): the command profiled with rocprofv3, "
                          "so that its per-kernel average is the average of exactly the timed launches")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two child rocprofv3 counter passes that measure roofline.traffic (N = 1 only; ~1 min); the committed passes "
+                         "under profiles/ are quoted instead")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.pmc_child:
+        pmc_child()
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)  # does not return
+    # roofline.traffic, measured: the counter passes are child processes, started before this process touches the GPU
+    live = (None, "not requested")
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "atlas4096" and not args.headline_only and not args.no_live_traffic
+            and os.environ.get("BENCH_FORCE_DIST") != "1"):
+        live = live_traffic()
 
     # stdout carries exactly ONE line, the JSON result of rank 0: libraries print banners there (RCCL's version block lands
     # in the C stdio buffer and is flushed at exit, i.e. BEHIND a Python print when stdout is a pipe), so file descriptor 1
@@ -178,6 +260,7 @@ def main():
     env = Env()
     env.json_fd = json_fd
     env.args, env.torch, env.dist = args, torch, dist
+    env.live_traffic = live
     env.rank, env.world, env.local_rank, env.use_dist = rank, world, local_rank, use_dist
     env.ctx = Context(local_rank)
     env.lib = _lib.load()
@@ -916,7 +999,13 @@ def run_atlas4096(env):
     tr = pmc_traffic()
     if tr:
         line["roofline"]["traffic"] = tr[0]
-        line["roofline"]["traffic_source"] = tr[1] + " (committed rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this kernel; not measured in this run)"
+        line["roofline"]["traffic_source"] = tr[1] + " (committed rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this kernel; not measured in this run: " + env.live_traffic[1] + ")"
+    if env.live_traffic[0] is not None:
+        line["roofline"]["traffic"] = env.live_traffic[0]
+        line["roofline"]["traffic_source"] = env.live_traffic[1]
+        if tr:
+            line["roofline"]["traffic_committed"] = {"bytes": tr[0], "source": tr[1]}
+    if tr:
         if tr[2]:
             # the limiter DESIGN.md section 6 measures: vector-ALU instruction issue.  Peak = SIMDs x shader clock / 4.2 clk per
             # wave64 instruction (the issue cost of the slow instruction forms, tools/exp/opbench.hip; the clock is the 2.35 GHz

@@ -182,3 +182,18 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     assert cmd[-8:] == ["--gpus", "8", "--steps", "7", "--warmup", "3", "--config", "array512"] and cmd[-9].endswith("bench.py")
     assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") not in (None, "0")
     assert d["parent_initialised_cuda"] is False  # the parent only counted devices: nothing that a child could not re-do
+
+
+def test_bench_live_traffic_falls_back_without_a_gpu():
+    """bench.py measures roofline.traffic with two child rocprofv3 counter passes; where they cannot run (no GPU here, no
+    rocprofv3, a run that is itself profiled) it must return a reason, not raise -- the committed passes are quoted then."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    got = bench.live_traffic(timeout_s=120)
+    assert got[0] is None and isinstance(got[1], str) and got[1]
+    os.environ["ROCPROF_TEST_MARKER"] = "1"  # a profiled run never starts a nested profiler
+    try:
+        assert bench.live_traffic() in ((None, "this run is itself being profiled"), (None, "rocprofv3 not on PATH"))
+    finally:
+        del os.environ["ROCPROF_TEST_MARKER"]
