@@ -196,54 +196,56 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
     }
     if (runs.empty()) return BU_OK;
     if (runs.size() == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s);
-    // several runs at unrelated addresses: ONE launch over a per-tile descriptor table (kernel layout MULTI).  Launching them one
-    // by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices of 65 536 blocks: 290 us on one
-    // stream, 230-260 us on 2-8, profiles/r03_small_slices_streams_vs_one_launch.txt).
-    std::vector<BuTileDesc> descs;
-    for (const Run& r : runs) {
-        if (r.n > ((size_t)1 << 32) - 1024) return BU_ERR_ARGUMENT;  // (a tile's first block is a 32-bit index inside its slice)
-        for (size_t first = 0; first < r.n; first += 1024)
-            descs.push_back(BuTileDesc{reinterpret_cast<const uint4*>(r.in), r.out, (uint32_t)first, (uint32_t)(r.n - first < 1024 ? r.n - first : 1024), r.base});
-    }
-    const size_t n_tiles = descs.size();
-    if (n_tiles > 65536) {  // beyond one launch's tile numbering: fall back to a launch per run (large slices: the launch cost no longer matters)
-        for (const Run& r : runs) {
-            bu_status st = bu_launch_uastc(ctx, target, r.in, r.n, r.out, blocks_per_row, r.base, d_status, s);
-            if (st) return st;
-        }
-        return BU_OK;
-    }
+    // several runs at unrelated addresses: ONE launch per BU_MULTI_RUNS runs, the run table in the kernel arguments (kernel layout
+    // MULTI).  Launching the runs one by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices
+    // of 65 536 blocks: 290 us on one stream, 230-260 us on 2-8, profiles/r03_small_slices_streams_vs_one_launch.txt).
+    for (const Run& r : runs)
+        if (r.n > ((size_t)1 << 32) - 1024) return BU_ERR_ARGUMENT;  // (a tile's first block is a 32-bit index inside its run)
     BU_HIP(ctx, hipSetDevice(ctx->device));
-    void* d_desc = nullptr;
-    BU_HIP(ctx, hipMallocAsync(&d_desc, n_tiles * sizeof(BuTileDesc), s));  // stream-ordered: freed behind the kernel, no host synchronisation
-    hipError_t e = hipMemcpyAsync(d_desc, descs.data(), n_tiles * sizeof(BuTileDesc), hipMemcpyHostToDevice, s);  // pageable source: staged before the call returns
-    if (e != hipSuccess) {
-        (void)hipFreeAsync(d_desc, s);
-        return bu_fail(ctx, e, "hipMemcpyAsync (tile descriptors)");
-    }
     unsigned long long* stw = reinterpret_cast<unsigned long long*>(d_status);
-    const uint4* din = static_cast<const uint4*>(d_desc);
-    const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
-#define BU_GO_MULTI(T)                                                                                                                    \
-    do {                                                                                                                                  \
-        if (one_per_cu)                                                                                                                   \
-            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 1024, 1, 1, false, false, 0, BU_LAYOUT_MULTI>), dim3((unsigned)n_tiles), dim3(1024), 0, s, din, \
-                               nullptr, (unsigned)(n_tiles * 1024), (unsigned)blocks_per_row, 0ull, stw, ctx->d_tables, 0u, 1024u BU_STAMP_PASS); \
-        else                                                                                                                              \
-            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, 512, 2, 1, false, false, 0, BU_LAYOUT_MULTI>), dim3((unsigned)n_tiles), dim3(512), 0, s, din,   \
-                               nullptr, (unsigned)(n_tiles * 1024), (unsigned)blocks_per_row, 0ull, stw, ctx->d_tables, 0u, 1024u BU_STAMP_PASS); \
+    for (size_t r0 = 0; r0 < runs.size();) {
+        BuRunTable tb;
+        size_t k = 0, n_tiles = 0;
+        for (; r0 + k < runs.size() && k < BU_MULTI_RUNS; k++) {
+            const Run& r = runs[r0 + k];
+            const size_t t = (r.n + 1023) / 1024;
+            if (n_tiles + t >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
+            tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, 0u};
+            tb.first_tile[k] = (uint32_t)n_tiles;
+            n_tiles += t;
+        }
+        if (k <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
+            bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s);
+            if (st) return st;
+            r0 += 1;
+            continue;
+        }
+        for (size_t i = k; i < BU_MULTI_RUNS + 32; i++) tb.first_tile[i] = 0xFFFFFFFFu;
+        for (size_t i = k; i < BU_MULTI_RUNS; i++) tb.run[i] = BuRunDesc{nullptr, nullptr, 0, 0u, 0u};
+        const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
+        const size_t cap = (size_t)ctx->cu_count * 7;  // beyond seven workgroups per CU they walk the tiles (as bu_launch_uastc)
+        const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
+#define BU_GO_MULTI(T)                                                                                                                      \
+    do {                                                                                                                                    \
+        if (one_per_cu)                                                                                                                     \
+            hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw,     \
+                               ctx->d_tables BU_STAMP_PASS);                                                                                \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw,       \
+                               ctx->d_tables BU_STAMP_PASS);                                                                                \
     } while (0)
-    switch (target) {
-    case BU_TARGET_ASTC: BU_GO_MULTI(BU_TGT_ASTC); break;
-    case BU_TARGET_BC7: BU_GO_MULTI(BU_TGT_BC7); break;
-    case BU_TARGET_ETC1: BU_GO_MULTI(BU_TGT_ETC1); break;
-    case BU_TARGET_ETC2: BU_GO_MULTI(BU_TGT_ETC2); break;
-    default: BU_GO_MULTI(BU_TGT_RGBA); break;
-    }
+        switch (target) {
+        case BU_TARGET_ASTC: BU_GO_MULTI(BU_TGT_ASTC); break;
+        case BU_TARGET_BC7: BU_GO_MULTI(BU_TGT_BC7); break;
+        case BU_TARGET_ETC1: BU_GO_MULTI(BU_TGT_ETC1); break;
+        case BU_TARGET_ETC2: BU_GO_MULTI(BU_TGT_ETC2); break;
+        default: BU_GO_MULTI(BU_TGT_RGBA); break;
+        }
 #undef BU_GO_MULTI
-    e = hipGetLastError();
-    (void)hipFreeAsync(d_desc, s);
-    if (e != hipSuccess) return bu_fail(ctx, e, "multi-slice launch");
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return bu_fail(ctx, e, "multi-run launch");
+        r0 += k;
+    }
     return BU_OK;
 }
 

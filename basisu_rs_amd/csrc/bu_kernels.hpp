@@ -214,6 +214,7 @@ struct BuBigCfg<BU_TGT_ASTC> {
 #define BU_STAMP(k)
 #define BU_STAMP_ARG
 #define BU_STAMP_PASS
+#define BU_STAMP_FWD
 #define BU_STAMP_DECL
 #define BU_STAMP_NEXT
 #endif
@@ -229,22 +230,39 @@ struct BuBigCfg<BU_TGT_ASTC> {
 // sort works on the index inside the tile).  A compile-time variant: as a run-time switch the extra index arithmetic cost the
 // strip path 4 % (round 2).
 constexpr unsigned BU_RECT_W = 64;
-// MULTI (LAYOUT 2): the launch covers SEVERAL slices at unrelated addresses -- `in` points at one BuTileDesc per tile (the slice's
-// input and output, the tile's first block inside the slice, how many blocks it holds, the slice's block-index base) instead of
-// at blocks; tiles never straddle slices.  A loop over small slices becomes one launch (bu_uastc_transcode_batch_device).
-struct BuTileDesc {
-    const uint4* in;  // the SLICE's first block
-    void* out;        // the slice's output
-    uint32_t first;   // index of the tile's first block inside the slice
-    uint32_t n;       // blocks in this tile (1..tile size)
-    uint64_t base;    // block-index base of the slice (status words)
+// MULTI (LAYOUT 2): the launch covers SEVERAL runs of blocks at unrelated addresses (slices of a texture array in separate
+// allocations); tiles never straddle runs.  The run table travels IN THE KERNEL ARGUMENTS (bu_uastc_multi_kernel: no device
+// buffer, no copy, nothing to free behind the launch): per run its input, output, block-index base, size and the number of its
+// first tile.  A workgroup finds the run of tile t by comparing t with 64 first-tile numbers at a time (one vector load and a
+// ballot per wave) and reads that run's record with scalar loads.  A loop over small slices becomes one launch
+// (bu_uastc_transcode_batch_device); more than BU_MULTI_RUNS runs go out as several launches.
+struct BuRunDesc {
+    const uint4* in;  // the run's first block
+    void* out;        // its output
+    uint64_t base;    // block-index base of the run (status words)
+    uint32_t n;       // blocks in the run
+    uint32_t pad;
 };
-static_assert(sizeof(BuTileDesc) == 32, "descriptor layout is shared with the host code");
+constexpr unsigned BU_MULTI_RUNS = 96;
+struct BuRunTable {
+    BuRunDesc run[BU_MULTI_RUNS];
+    uint32_t first_tile[BU_MULTI_RUNS + 32];  // ascending; entries past the last run hold 0xFFFFFFFF (128 entries: two 64-lane loads)
+};
+static_assert(sizeof(BuRunDesc) == 32 && sizeof(BuRunTable) <= 3968, "the run table must fit the 4 KiB of kernel arguments beside the other parameters");
+// the tile the kernel is working on: its run's addresses, where it starts inside the run, how many blocks it holds
+struct BuTileDesc {
+    const uint4* in;
+    void* out;
+    uint32_t first;
+    uint32_t n;
+    uint64_t base;
+};
 enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
 template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP>
-__global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
-                                                                unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
+__device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
+                                                     unsigned bpr, unsigned long long base, unsigned long long* status,
+                                                     const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
+                                                     const BuRunTable* __restrict__ runs BU_STAMP_ARG)
 {
     BU_STAMP_DECL
     BU_STAMP(0)
@@ -326,7 +344,19 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     BuTileDesc td = {in, out, 0u, 0u, base};
     auto load_desc = [&](unsigned t) {
         if constexpr (MULTI) {
-            if (t < n_tiles) td = reinterpret_cast<const BuTileDesc*>(in)[t];
+            if (t < n_tiles) {
+                // runs 0..r start at or before tile t: r = (number of first-tile entries <= t) - 1; the unused entries are ~0
+                uint32_t r = 0;
+#pragma unroll
+                for (unsigned c = 0; c < BU_MULTI_RUNS + 32; c += 64) {
+                    const uint32_t cnt = (uint32_t)__popcll(__ballot(runs->first_tile[c + lane] <= t));
+                    if (cnt) r = c + cnt - 1u;
+                }
+                r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+                const BuRunDesc rd = runs->run[r];
+                const uint32_t first = (t - runs->first_tile[r]) * (uint32_t)BU_TILE, left = rd.n - first;
+                td = BuTileDesc{rd.in, rd.out, first, left < (uint32_t)BU_TILE ? left : (uint32_t)BU_TILE, rd.base};
+            }
         }
     };
     load_desc(tile);
@@ -572,6 +602,25 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
         BU_STAMP(8)
         BU_STAMP_NEXT
     }
+}
+
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP>
+__global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
+                                                                unsigned bpr, unsigned long long base, unsigned long long* status,
+                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
+{
+    static_assert(LAYOUT != BU_LAYOUT_MULTI, "several runs per launch: bu_uastc_multi_kernel");
+    bu_uastc_sorted_body<TARGET, WGS, BPT, MINW, PREFETCH, DIRECT, SKEW, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr BU_STAMP_FWD);
+}
+
+// several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value)
+template <int TARGET, int WGS, int BPT>
+__global__ __launch_bounds__(WGS, 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
+                                                             const BuTablesAll* __restrict__ tables BU_STAMP_ARG)
+{
+    static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");
+    bu_uastc_sorted_body<TARGET, WGS, BPT, 1, false, false, 0, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u,
+                                                                                &table BU_STAMP_FWD);
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into

@@ -120,11 +120,12 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
 /* A loop over independent slices (the per-slice loops of basis.rs:246-257) as ONE call: slice i = n_blocks[i] blocks at d_in[i]
  * -> d_out[i], block indices numbered from index_base[i] (NULL: slices numbered back to back from 0).  The slices must not
  * depend on each other (no output aliasing an input); the call starts when `stream` reaches it and `stream` continues when
- * every slice is done.  The whole batch is ONE kernel launch: slices that are contiguous in memory, in order, are merged, and
- * slices at unrelated addresses are walked through a per-tile descriptor table (uploaded on `stream`, stream-ordered
- * allocation) -- 64 slices of 65 536 blocks take ~30-40 us where 64 launches take 290 us on one stream and 230-260 us on
- * two to eight: a loop of launches is bound by the host's ~4 us per launch, not by the GPU.  Small batches (a 1-slice "batch")
- * cost what bu_uastc_transcode_device costs.  RGBA32: every slice uses the same blocks_per_row. */
+ * every slice is done.  Slices that are contiguous in memory, in order, are merged into runs; one run is the plain launch, and
+ * up to 96 runs at unrelated addresses are ONE kernel launch with the run table in its kernel arguments (nothing is allocated,
+ * copied or freed behind the call; longer batches go out as one launch per 96 runs) -- 64 slices of 65 536 blocks in separate
+ * allocations take ~46 us call + synchronize where 64 launches take 290 us on one stream and 230-260 us on two to eight: a loop
+ * of launches is bound by the host's ~4 us per launch, not by the GPU.  Small batches (a 1-slice "batch") cost what
+ * bu_uastc_transcode_device costs.  RGBA32: every slice uses the same blocks_per_row. */
 bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
                                           const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
                                           const uint64_t* index_base, uint64_t* d_status, void* stream);

@@ -266,3 +266,55 @@ def test_batch_entry_point_merges_contiguous_slices_and_fans_out_the_rest(ctx, g
         if n:
             got = r_out[k].cpu().numpy().reshape(n // bpr, 4, bpr, 16).transpose(0, 2, 1, 3).reshape(n, 64)
             assert (got == golden["rgba"][idx[k]]).all(), k
+
+
+@pytest.mark.gpu
+def test_batch_of_separate_allocations_replays_from_a_hip_graph(ctx, golden):
+    """The multi-run launch carries its run table in the kernel arguments (no upload, no stream-ordered allocation), so a batch over
+    slices in separate allocations is capturable like the single-slice entry point: capture, change the inputs, replay, compare."""
+    import torch
+
+    lib = _lib.load()
+    sizes = [3000, 1024, 20000, 64, 5000]
+    n_s = len(sizes)
+    VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    ins = [torch.empty((n, 16), dtype=torch.uint8, device="cuda") for n in sizes]
+    outs = [torch.empty((n, 16), dtype=torch.uint8, device="cuda") for n in sizes]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.Stream()
+
+    def fill(seed):
+        idx = [torch.from_numpy(synth.gold_indices(n, seed=seed + k)).cuda() for k, n in enumerate(sizes)]
+        for t, i in zip(ins, idx):
+            t.copy_(gu[i])
+        return idx
+
+    def call():
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.ASTC, n_s, VP(*[t.data_ptr() for t in ins]), SZ(*sizes), VP(*[t.data_ptr() for t in outs]), 0,
+                                                   None, ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(s.cuda_stream)) == 0
+
+    fill(900)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ctx.status_word_reset(status, stream=s)
+        call()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ctx.status_word_reset(status, stream=s)
+        call()
+    for seed in (910, 920):
+        idx = fill(seed)
+        for t in outs:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+        for k in range(n_s):
+            assert (outs[k].cpu().numpy() == golden["astc"][idx[k].cpu().numpy()]).all(), k
+    ins[2][123, 0] = 69  # block 3000 + 1024 + 123 of the batch
+    g.replay()
+    torch.cuda.synchronize()
+    assert (int(status.item()) & 0xFFFFFFFFFFFFFFFF) >> 8 == 3000 + 1024 + 123

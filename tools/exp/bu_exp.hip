@@ -3,6 +3,7 @@
 // in-kernel stamps (diagnostic build only): s_memrealtime (100 MHz) is too coarse; s_memtime = shader clock
 #define BU_STAMP_ARG , unsigned long long* __restrict__ stamps
 #define BU_STAMP_PASS , (unsigned long long*)nullptr
+#define BU_STAMP_FWD , stamps
 #define BU_STAMP(k)                                                                                   \
     if (stamps && (threadIdx.x & 63u) == 0) {                                                         \
         unsigned long long t_;                                                                        \

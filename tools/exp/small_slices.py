@@ -35,3 +35,11 @@ ms = ctypes.c_float(0)
 one_in, one_out = (ctypes.c_void_p * 1)(cat_in.data_ptr()), (ctypes.c_void_p * 1)(cat_out.data_ptr())
 for _ in range(3): lib.bu_time_uastc_launches(ctx.handle, _lib.BC7, one_in, one_out, 1, 0, ns * nbs, 256, 8, None, sp, ctypes.byref(ms))
 print("one launch over the concatenation: %.1f us" % (ms.value / 8 * 1e3))
+def one():
+    assert lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(cat_in.data_ptr()), ns * nbs, ctypes.c_void_p(cat_out.data_ptr()), 256, 0, None, sp) == 0
+for _ in range(3): one()
+torch.cuda.synchronize()
+best = 1e9
+for _ in range(5):
+    t0 = time.perf_counter(); one(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+print("one launch over the concatenation, call + synchronize (as the batch row): %.1f us" % (best * 1e6))
