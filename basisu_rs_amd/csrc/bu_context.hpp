@@ -80,8 +80,13 @@ size_t bu_balanced_tile(size_t max_tile, size_t n_blocks, size_t slots, bool dyn
     return t < 64 ? 64 : (t > max_tile ? max_tile : t);
 }
 
-// targets whose 1024-block tile shapes are also compiled with rectangular tiles (bu_uastc_sorted_kernel, RECT)
-constexpr bool bu_rect_compiled(int target) { return target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA; }
+// shapes that are also compiled with rectangular tiles (bu_uastc_sorted_kernel, RECT): the 1024-block tiles (64 x 16 blocks) of
+// BC7, ASTC and RGBA32, the 4096-block tiles (64 x 64) of ETC1 and ETC2
+constexpr bool bu_rect_compiled(int target, int tile)
+{
+    return tile == 1024 ? (target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA)
+                        : (tile == 4096 && (target == BU_TGT_ETC1 || target == BU_TGT_ETC2));
+}
 
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
@@ -108,17 +113,21 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
             const unsigned long long pbase = base + done;
             // Rectangular tiles (kernel, RECT): the caller told us the block grid (blocks_per_row), it is a multiple of 64 wide and
-            // the piece is whole rows of 64 x 16-block tiles.  Compiled for the fixed 1024-block tile shapes of BC7, ASTC and
-            // RGBA32; ETC1 / ETC2 (run-time tile size) keep strips.
-            constexpr size_t RW = BU_RECT_W, RH = 1024 / BU_RECT_W;
+            // the piece is whole rows of 64 x 16-block tiles (BC7, ASTC, RGBA32: the fixed 1024-block shapes) or of 64 x 64-block
+            // tiles (ETC1 / ETC2: the 4096-block shape, when the balanced tile size is the full 4096 anyway).
+            constexpr size_t RW = BU_RECT_W;
             // (one tile per row, blocks_per_row == 64: the strip IS the rectangle)
-            const bool rect = grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21) && nb % (RH * bpr) == 0 &&
-                              (n_blocks <= piece || piece % (RH * bpr) == 0);
-            const unsigned rect_magic = rect ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
+            auto rect_ok = [&](size_t rh) {
+                return grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21) && nb % (rh * bpr) == 0 &&
+                       (n_blocks <= piece || piece % (rh * bpr) == 0);
+            };
+            const bool rect = rect_ok(1024 / RW), rect64 = rect_ok(4096 / RW);
+            const unsigned rect_magic = (rect || rect64) ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
 #define BU_GO(T, W, B, MINW, PF, DIR, SK, GRID, CUS, TRT)                                                                                       \
     do {                                                                                                                                        \
-        if (bu_rect_compiled(T) && rect && (size_t)(W) * (B) == 1024)                                                                           \
-            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, bu_rect_compiled(T)>), dim3(GRID), dim3(W), 0, stream, pin, pout, \
+        constexpr int tile_ = (W) * (B);                                                                                                        \
+        if (bu_rect_compiled(T, tile_) && (tile_ == 1024 ? rect : (rect64 && (TRT) == 4096u)))                                                  \
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, bu_rect_compiled(T, tile_)>), dim3(GRID), dim3(W), 0, stream, pin, pout, \
                                (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, rect_magic BU_STAMP_PASS);                           \
         else                                                                                                                                    \
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, false>), dim3(GRID), dim3(W), 0, stream, pin, pout,          \

@@ -315,7 +315,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // that every CU gets the same number of equal tiles (`tile_rt` <= BU_TILE, a multiple of 64); threads past the end of
     // a shorter tile sit out like threads past the end of the slice.  Every other shape passes tile_rt = BU_TILE and
     // compiles to what it was.
-    constexpr bool DYN_TILE = (TARGET == BU_TGT_ETC1 || TARGET == BU_TGT_ETC2) && BU_TILE == 4096;
+    constexpr bool DYN_TILE = (TARGET == BU_TGT_ETC1 || TARGET == BU_TGT_ETC2) && BU_TILE == 4096 && LAYOUT != BU_LAYOUT_RECT;
     const unsigned tile_blocks = DYN_TILE ? tile_rt : (unsigned)BU_TILE;
     const unsigned n_tiles = (n_blocks + tile_blocks - 1) / tile_blocks;  // 32-bit indices: the host splits launches above 2^26 blocks
     auto in_tile = [&](unsigned l) { return !DYN_TILE || l < tile_blocks; };

@@ -94,20 +94,23 @@ def test_window_timing_helper_brackets_exactly_the_timed_launches():
     ctx.close()
 
 
-@pytest.mark.parametrize("target", ["astc", "bc7", "rgba"])
+@pytest.mark.parametrize("target", ["astc", "bc7", "rgba", "etc1", "etc2"])
 def test_rectangular_tiles_on_both_sides_of_the_selection(golden, target):
     """the launcher takes the RECT kernels when blocks_per_row is a multiple of 64 (at least 128) and the slice is whole rows of
-    64 x 16-block tiles, the strip kernels otherwise: same bytes either way, and the same first-error index (uastc.rs:157-165)"""
+    64 x 16-block tiles (ETC1 / ETC2: of 64 x 64-block tiles, on the 4096-block shape of large slices), the strip kernels otherwise:
+    same bytes either way, and the same first-error index (uastc.rs:157-165)"""
     import torch
 
     from basisu_rs_amd import BasisuError, Context
 
     ctx = Context(0)
-    t, bb = {"astc": (_lib.ASTC, 16), "bc7": (_lib.BC7, 16), "rgba": (_lib.RGBA32, 64)}[target]
+    t, bb = {"astc": (_lib.ASTC, 16), "bc7": (_lib.BC7, 16), "rgba": (_lib.RGBA32, 64), "etc1": (_lib.ETC1, 8), "etc2": (_lib.ETC2, 16)}[target]
     # (blocks per row, block rows): rect 1 and 2 tiles per row, several tile rows, one big enough for every launch shape;
     # strip: ragged rows of tiles, width not a multiple of 32, and the block-linear call without a grid (blocks_per_row 0)
     shapes = [(128, 16, True), (128, 64, True), (192, 32, True), (1024, 512, True), (1024, 1024, True), (128, 63, False), (64, 64, False),
               (96, 64, False), (0, 4096, False)]
+    if target in ("etc1", "etc2"):  # the 4096-block shape starts above 3 Ki blocks per CU; 1088 rows balance to 2176-block tiles (strips)
+        shapes += [(2048, 1024, True), (512, 2048, True), (1024, 1088, False), (1024, 1056, False)]
     for bpr, rows, rect in shapes:
         n = (bpr or 1) * rows
         idx = synth.gold_indices(n, seed=31 + bpr + rows)
