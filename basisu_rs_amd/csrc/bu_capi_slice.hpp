@@ -309,8 +309,9 @@ bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx,
     if (n_blocks == 0) return BU_OK;
     const size_t lds = ((size_t)n_endpoints + n_selectors) * 4;
     if (n_blocks >= BU_ETC1S_STAGED_MIN && lds <= BU_ETC1S_LDS_MAX) {
-        // codebooks in LDS; two workgroups per CU from 2^21 blocks where both fit (2^22 blocks: 15.8 against 17.5 us, 2^20: 7.7 against 6.7)
-        const unsigned per_cu = (n_blocks >= ((size_t)1 << 21) && 2 * lds <= BU_ETC1S_LDS_MAX) ? 2u : 1u;
+        // codebooks in LDS, one persistent workgroup per CU (with four blocks per lane and step in flight a second workgroup only
+        // doubles the staging: 2^21 blocks 8.0 against 9.3 us, 2^22 12.95 / 13.2, 2^24 37.4 / 39.3)
+        const unsigned per_cu = 1u;
         bu_status st = bu_etc1s_lds_attr(ctx, false, lds);
         if (st) return st;
         hipLaunchKernelGGL(bu_etc1s_staged_kernel<false>, dim3((unsigned)ctx->cu_count * per_cu), dim3(1024), lds, static_cast<hipStream_t>(stream), d_idx,

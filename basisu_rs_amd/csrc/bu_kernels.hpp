@@ -809,33 +809,91 @@ __global__ __launch_bounds__(1024) void bu_etc1s_staged_kernel(const uint32_t* _
     uint32_t* s_ep = bu_etc1s_lds;
     uint32_t* s_sel = bu_etc1s_lds + n_ep;
     uint32_t* pal_lut = s_sel + n_sel;
-    for (uint32_t i = threadIdx.x; i < n_ep; i += 1024) s_ep[i] = endpoints[i];
-    for (uint32_t i = threadIdx.x; i < n_sel; i += 1024) s_sel[i] = RGBA ? selectors[i].x : selectors[i].y;
+    const size_t stride = (size_t)gridDim.x * 1024, first = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    // ETC1, index array 8-byte and output 16-byte aligned: FOUR blocks per lane and step, a wave on 256 consecutive blocks -- the
+    // lane's blocks 2L, 2L+1 and 128+2L, 128+2L+1, so that both of its 8-byte index loads and both of its 16-byte result stores
+    // are contiguous across the wave (512 B / 1 KiB per instruction; four CONSECUTIVE blocks per lane make every store
+    // instruction write half of each cache line: 2^22 blocks 16 -> 31 us) -- with the next step's indices already in flight.
+    // The first loads are issued BEFORE the codebooks are staged, so their latency hides behind the staging.
+    const bool vec4 = !RGBA && (reinterpret_cast<uintptr_t>(idx) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    const size_t n256 = vec4 ? n_blocks / 256 : 0, wstride = stride / 64, wfirst = first / 64;  // 256-block chunks; waves
+    const uint2* idx2 = reinterpret_cast<const uint2*>(idx);
+    const unsigned lane = threadIdx.x & 63u;
+    bu_v2u curA = {0, 0}, curB = {0, 0};
+    uint32_t cur = 0, acur = 0;
+    if (vec4) {
+        if (wfirst < n256) {
+            curA = __builtin_nontemporal_load(reinterpret_cast<const bu_v2u*>(idx2 + wfirst * 128 + lane));
+            curB = __builtin_nontemporal_load(reinterpret_cast<const bu_v2u*>(idx2 + wfirst * 128 + 64 + lane));
+        }
+    } else if (first < n_blocks) {
+        cur = __builtin_nontemporal_load(idx + first);
+        if (RGBA && aidx) acur = __builtin_nontemporal_load(aidx + first);
+    }
+    // staging, 16 bytes per load where the source allows (selectors: two 8-byte entries, of which the target keeps 4 bytes each)
+    if ((reinterpret_cast<uintptr_t>(endpoints) & 15u) == 0) {
+        for (uint32_t i = threadIdx.x; i < n_ep / 4; i += 1024) reinterpret_cast<uint4*>(s_ep)[i] = reinterpret_cast<const uint4*>(endpoints)[i];
+        for (uint32_t i = (n_ep & ~3u) + threadIdx.x; i < n_ep; i += 1024) s_ep[i] = endpoints[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < n_ep; i += 1024) s_ep[i] = endpoints[i];
+    }
+    if ((reinterpret_cast<uintptr_t>(selectors) & 15u) == 0 && (n_ep & 1u) == 0) {
+        for (uint32_t i = threadIdx.x; i < n_sel / 2; i += 1024) {
+            const uint4 two = reinterpret_cast<const uint4*>(selectors)[i];
+            reinterpret_cast<uint2*>(s_sel)[i] = RGBA ? make_uint2(two.x, two.z) : make_uint2(two.y, two.w);
+        }
+        if ((n_sel & 1u) && threadIdx.x == 0) s_sel[n_sel - 1] = RGBA ? selectors[n_sel - 1].x : selectors[n_sel - 1].y;
+    } else {
+        for (uint32_t i = threadIdx.x; i < n_sel; i += 1024) s_sel[i] = RGBA ? selectors[i].x : selectors[i].y;
+    }
     if (RGBA && threadIdx.x < 256) pal_lut[threadIdx.x] = tables->t.etc1s_pal[threadIdx.x];
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * 1024;
-    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n_blocks; i += stride) {
-        const uint32_t ix = __builtin_nontemporal_load(idx + i);
+    // basis_lz/mod.rs:163-181 for one block
+    auto etc1_block = [&](uint32_t ix, size_t i) {
         const uint32_t e = ix & 0xFFFFu, sl = ix >> 16;
-        bool bad = e >= n_ep || sl >= n_sel;
+        uint2 o = make_uint2(0, 0);
+        if (e >= n_ep || sl >= n_sel) {
+            bu_report(status, i, BU_ERR_INDEX_RANGE);
+        } else {
+            const uint32_t ep = s_ep[e], inten = ep >> 24;
+            o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
+            o.y = s_sel[sl];
+        }
+        return o;
+    };
+    if (vec4) {
+        for (size_t w = wfirst; w < n256; w += wstride) {
+            const size_t wn = w + wstride;
+            bu_v2u nxtA = {0, 0}, nxtB = {0, 0};
+            if (wn < n256) {
+                nxtA = __builtin_nontemporal_load(reinterpret_cast<const bu_v2u*>(idx2 + wn * 128 + lane));
+                nxtB = __builtin_nontemporal_load(reinterpret_cast<const bu_v2u*>(idx2 + wn * 128 + 64 + lane));
+            }
+            const size_t i0 = w * 256 + 2 * lane;
+            const uint2 a = etc1_block(curA.x, i0), b = etc1_block(curA.y, i0 + 1), c = etc1_block(curB.x, i0 + 128), d = etc1_block(curB.y, i0 + 129);
+            uint4* o4 = reinterpret_cast<uint4*>(out) + w * 128 + lane;
+            bu_st_stream(o4, make_uint4(a.x, a.y, b.x, b.y));
+            bu_st_stream(o4 + 64, make_uint4(c.x, c.y, d.x, d.y));
+            curA = nxtA;
+            curB = nxtB;
+        }
+        // the last n_blocks % 256 blocks
+        const size_t t = 256 * n256 + first;
+        if (t < n_blocks) bu_st_stream(reinterpret_cast<uint2*>(out) + t, etc1_block(__builtin_nontemporal_load(idx + t), t));
+        return;
+    }
+    for (size_t i = first; i < n_blocks; i += stride) {
+        const size_t in = i + stride;
+        uint32_t nxt = 0, anxt = 0;
+        if (in < n_blocks) {
+            nxt = __builtin_nontemporal_load(idx + in);
+            if (RGBA && aidx) anxt = __builtin_nontemporal_load(aidx + in);
+        }
         if constexpr (!RGBA) {
-            uint2 o = make_uint2(0, 0);
-            if (bad) {
-                bu_report(status, i, BU_ERR_INDEX_RANGE);
-            } else {  // basis_lz/mod.rs:163-181
-                const uint32_t ep = s_ep[e], inten = ep >> 24;
-                o.x = ((ep << 3) & 0x00F8F8F8u) | ((((inten << 5) | (inten << 2) | 3u) & 0xFFu) << 24);
-                o.y = s_sel[sl];
-            }
-            bu_st_stream(reinterpret_cast<uint2*>(out) + i, o);
+            bu_st_stream(reinterpret_cast<uint2*>(out) + i, etc1_block(cur, i));
         } else {  // basis_lz/mod.rs:122-146
-            uint32_t ae = 0, as = 0;
-            if (aidx) {
-                const uint32_t ax = __builtin_nontemporal_load(aidx + i);
-                ae = ax & 0xFFFFu;
-                as = ax >> 16;
-                bad = bad || ae >= n_ep || as >= n_sel;
-            }
+            const uint32_t e = cur & 0xFFFFu, sl = cur >> 16, ae = acur & 0xFFFFu, as = acur >> 16;
+            const bool bad = e >= n_ep || sl >= n_sel || (aidx && (ae >= n_ep || as >= n_sel));
             uint32_t px[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) px[k] = 0;
@@ -846,6 +904,8 @@ __global__ __launch_bounds__(1024) void bu_etc1s_staged_kernel(const uint32_t* _
 #pragma unroll
             for (int r = 0; r < 4; r++) bu_st_stream(img + (4 * by + r) * (size_t)nbx + bx, make_uint4(px[4 * r], px[4 * r + 1], px[4 * r + 2], px[4 * r + 3]));
         }
+        cur = nxt;
+        acur = anxt;
     }
 }
 // blocks from which the staged kernel is launched, and the LDS one CU can give a workgroup (160 KiB less a margin)

@@ -199,6 +199,35 @@ def test_etc1s_kernels_with_codebooks_staged_in_lds(ctx, oracle, n_ep, n_sel):
         assert e.value.status == _lib.ERR_INDEX_RANGE and e.value.first_bad_block == 400_000
 
 
+def test_staged_etc1_kernel_on_ragged_sizes_and_unaligned_arrays(ctx, oracle):
+    """the staged ETC1 kernel walks 256-block chunks with 8-byte index loads and 16-byte stores when the arrays are aligned for
+    them and block by block otherwise: sizes that are not multiples of 256, an index array on a 4-byte boundary, an output on an
+    8-byte boundary -- device entry point, same bytes as the oracle (basis_lz/mod.rs:163-181)"""
+    import torch
+
+    from basisu_rs_amd import etc1s_selector_from_rows
+
+    lib = _lib.load()
+    n_ep, n_sel = 4096, 8192
+    ep, rows = synth.etc1s_codebooks(n_ep, n_sel, seed=5)
+    sel = etc1s_selector_from_rows(rows)
+    d_ep = torch.from_numpy(ep.view(np.int32)).cuda()
+    d_sel = torch.from_numpy(sel).cuda()
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n, idx_ofs, out_ofs in (((1 << 19) + 77, 0, 0), ((1 << 19) + 255, 1, 0), ((1 << 19) + 256, 0, 1), ((1 << 20) + 3, 1, 1), (1 << 19, 2, 2)):
+        idx = synth.etc1s_indices(n, n_ep, n_sel, seed=40 + n % 97)
+        want = oracle.etc1s_to_etc1(idx, ep, sel)
+        d_idx = torch.zeros(n + 4, dtype=torch.int32, device="cuda")
+        d_idx[idx_ofs:idx_ofs + n] = torch.from_numpy(idx.view(np.int32)).cuda()
+        d_out = torch.full(((n + 4) * 8,), 0xA5, dtype=torch.uint8, device="cuda")
+        assert lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx.data_ptr() + 4 * idx_ofs, n, d_ep.data_ptr(), n_ep, d_sel.data_ptr(), n_sel,
+                                                  d_out.data_ptr() + 8 * out_ofs, None, sp) == 0
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert (got[8 * out_ofs:8 * (out_ofs + n)].reshape(n, 8) == want.reshape(n, 8)).all(), (n, idx_ofs, out_ofs)
+        assert (got[:8 * out_ofs] == 0xA5).all() and (got[8 * (out_ofs + n):] == 0xA5).all(), "wrote outside the result"
+
+
 def test_batch_entry_point_merges_contiguous_slices_and_fans_out_the_rest(ctx, golden):
     """bu_uastc_transcode_batch_device: a loop over independent slices in one call.  Contiguous slices (one launch), slices in
     separate allocations (side by side on context streams), a mix with an empty slice, RGBA32 slices of one pitch -- same bytes
