@@ -30,9 +30,13 @@ constexpr bool bu_etc_tables_ordered()
 }
 static_assert(bu_etc_tables_ordered(), "EAC / ETC1 modifier tables are not in the order the threshold forms assume");
 
-struct BuPart {  // one UASTC partition pattern (layout documented in bu_tables.h / tools/gen_tables.py)
-    uint32_t upat, bpat;
-    uint16_t seed, uanch, banch;
+struct alignas(16) BuPart {  // one UASTC partition pattern (layout documented in bu_tables.h / tools/gen_tables.py)
+    // (upat, seed and uanch are what every target but BC7 reads: adjacent, so that they arrive in ONE ds_read_b64 -- a ds_read2_b32
+    // of two separate dwords costs 79 clocks per SIMD against 24, tools/exp/ldsbench.hip)
+    uint32_t upat;
+    uint16_t seed, uanch;
+    uint32_t bpat;
+    uint16_t banch;
     uint8_t bpart, perm;
 };
 static_assert(sizeof(BuPart) == 16, "BuPart must be 16 bytes");
@@ -42,7 +46,7 @@ static_assert(sizeof(BuPart) == 16, "BuPart must be 16 bytes");
 // the 3-subset family [30,41) (UASTC mode 3 places whole per-subset endpoint fields with a variable shift, so its subsets keep
 // their UASTC numbers and only the field position knows about BC7's order).  All bit positions are for 2-bit weights
 // (2 * texel + 1 = the weight's MSB) unless stated.
-struct BuPart7 {
+struct alignas(16) BuPart7 {
     uint32_t pat;  // subset of every texel in the record's label, 2 bits per texel, texel 0 low
     uint32_t pos;  // 5-bit fields: [0] uq_lo, [5] uq_hi: MSB positions of the UASTC anchors other than texel 0, ascending (31 = none)
                    //   [10] dq_hi, [15] dq_lo: MSB positions of the BC7 anchors other than texel 0, DEscending (dq_lo 0 = none)
