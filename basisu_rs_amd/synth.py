@@ -104,6 +104,37 @@ def atlas_rand(n_blocks, seed=1):
     return blocks
 
 
+def _fix_pattern_fields(blocks):
+    modes = block_modes(blocks)
+    lo = blocks[:, :8].copy().view("<u8").reshape(-1)
+    for m, (code, tf, pb, count) in _PATTERN_FIELD.items():
+        sel = np.nonzero(modes == m)[0]
+        if sel.size == 0:
+            continue
+        pos = np.uint64(code + tf)
+        mask = np.uint64((1 << pb) - 1)
+        v = ((lo[sel] >> pos) & mask) % np.uint64(count)
+        lo[sel] = (lo[sel] & ~(mask << pos)) | (v << pos)
+    blocks[:, :8] = lo.view(np.uint8).reshape(-1, 8)
+    return blocks
+
+
+def atlas_contrast(n_blocks, seed=1):
+    """valid blocks of extreme contrast: the endpoint region is runs of all-zero and all-one bytes (endpoints at or near 0 and
+    255), the weight region sparse or dense (most texels at one endpoint, a few at the other).  What uniform random bits almost never
+    produce: texels far from their half's average colour -- the clamps of the ETC1 modifier tables, lumas more than 2^15 from the
+    thresholds (the saturating i16 lanes of the GPU's selector stage), EAC tables run into 0 and 255."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    blocks = atlas_rand(n_blocks, seed=seed + 1000)
+    ext = np.where(rng.integers(0, 2, size=(n_blocks, 9), dtype=np.uint8) == 1, 0xFF, 0x00).astype(np.uint8)
+    keep = rng.integers(0, 4, size=(n_blocks, 9)) == 0  # a quarter of the bytes stay random
+    blocks[:, 3:12] = np.where(keep, blocks[:, 3:12], ext)
+    sparse = rng.integers(0, 256, size=(n_blocks, 6), dtype=np.uint8) & rng.integers(0, 256, size=(n_blocks, 6), dtype=np.uint8) & rng.integers(0, 256, size=(n_blocks, 6), dtype=np.uint8)
+    dense = rng.integers(0, 2, size=(n_blocks, 1), dtype=np.uint8) == 1
+    blocks[:, 10:16] = np.where(dense, ~sparse, sparse)
+    return _fix_pattern_fields(blocks)
+
+
 def atlas_err(golden_uastc, n_blocks, bad_at, seed=GOLD_SEED):
     """A-gold with invalid blocks at the given indices: even slots get mode code 69, odd slots an
     out-of-range pattern index (UASTC mode 3 with pattern 15 >= 11)."""

@@ -39,6 +39,14 @@ def test_emul_matches_oracle_on_random_valid_blocks(emul, oracle, target):
 
 
 @pytest.mark.parametrize("target", ALL)
+def test_emul_matches_oracle_on_high_contrast_blocks(emul, oracle, target):
+    """endpoints at the extremes, most texels at one of them (synth.atlas_contrast): the ETC modifier clamps, lumas more than
+    2^15 away from the thresholds (saturating i16 lanes of the selector stage), EAC tables run into 0 / 255"""
+    blocks = synth.atlas_contrast(300_000, seed=17)
+    assert _compare(emul, oracle, target, blocks) == blocks.shape[0]
+
+
+@pytest.mark.parametrize("target", ALL)
 def test_emul_matches_oracle_per_mode_dense(golden, emul, oracle, target):
     """every mode equally: keep a golden block's mode code, randomise everything after it"""
     rng = np.random.default_rng(5)

@@ -67,6 +67,16 @@ def test_random_valid_atlas_matches_oracle(ctx, oracle, target):
     assert (_gpu(ctx, target, blocks, bpr=512) == oo).all()
 
 
+@pytest.mark.parametrize("target", ALL)
+def test_high_contrast_atlas_matches_oracle(ctx, oracle, target):
+    """synth.atlas_contrast: endpoints at 0 / 255, most texels at one of them -- texels far from their ETC half's base colour
+    (etc.rs:160-198 with lumas beyond the i16 range of the GPU's packed selector stage), clamped modifier and EAC tables"""
+    blocks = synth.atlas_contrast(1 << 19, seed=23)
+    oo, ost = oracle.batch(target, blocks)
+    assert (ost == 0).all()
+    assert (_gpu(ctx, target, blocks, bpr=512) == oo).all()
+
+
 def test_error_strings_and_first_error_semantics(ctx, golden):
     from basisu_rs_amd import BasisuError, Decoder, TargetTextureFormat
 
