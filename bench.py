@@ -222,6 +222,8 @@ def main():
         self_launch(args.gpus)  # does not return
     # roofline.traffic, measured: the counter passes are child processes, started before this process touches the GPU
     live = (None, "not requested")
+    import torch  # (pays the cold first import of a fresh box here, before the children are clocked; importing initialises no GPU)
+    assert not torch.cuda.is_initialized()
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "atlas4096" and not args.headline_only and not args.no_live_traffic
             and os.environ.get("BENCH_FORCE_DIST") != "1"):
         live = live_traffic()
