@@ -157,7 +157,9 @@ bu_status bu_host_free(bu_context* ctx, void* ptr);
  * Selector::set_selector does (etc.rs:363-393). */
 void bu_etc1s_selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8]);
 
-/* Decoder::transcode_to_etc1 back-end, closure block_to_etc1 (basis_lz/mod.rs:163-181): 8 B per block */
+/* Decoder::transcode_to_etc1 back-end, closure block_to_etc1 (basis_lz/mod.rs:163-181): 8 B per block.
+ * Any 4-byte-aligned d_idx and 8-byte-aligned d_out work; from 2^19 blocks the codebooks are staged in LDS (when both fit
+ * 152 KiB) and an 8-byte-aligned d_idx with a 16-byte-aligned d_out takes the four-blocks-per-lane path (2^22 blocks: 13 us). */
 bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx, size_t n_blocks,
                                          const uint32_t* d_endpoints, uint32_t n_endpoints, const void* d_selectors,
                                          uint32_t n_selectors, void* d_out, uint64_t* d_status, void* stream);
