@@ -1,4 +1,4 @@
-"""one-off: HIP path vs oracle on millions of random blocks (valid and raw), all targets, statuses included"""
+"""soak checker (run by hand on the GPU box, not collected by pytest): HIP path vs oracle on millions of random blocks (valid and raw), all targets, statuses included"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,12 +1,11 @@
 """ETC1S back-end of the library named by BASISU_HIP_LIB (default: shipped): size sweep of both device entry points on cold-rotated
-index arrays (config-4 codebooks: 4096 endpoints, 8192 selectors); every size verified against the oracle on its first 2^16 blocks"""
+index arrays (config-4 codebooks: 4096 endpoints, 8192 selectors); timing only (parity: tests/test_gpu_round3.py)"""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from basisu_rs_amd import Context, _lib, synth, etc1s_selector_from_rows
-from oracle.pyoracle import Oracle
-ctx = Context(0); lib = _lib.load(); orc = Oracle()
+ctx = Context(0); lib = _lib.load()
 dev = torch.device("cuda", 0)
 N_EP, N_SEL = 4096, 8192
 ep, rows = synth.etc1s_codebooks(N_EP, N_SEL, seed=2)
