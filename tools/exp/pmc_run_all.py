@@ -50,4 +50,15 @@ if not only or "etc1s" in only:
     for k in range(NBUF * REPS):
         lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx[k % NBUF].data_ptr(), None, 512, 512, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o64[k % NBUF].data_ptr(), None, sp)
     torch.cuda.synchronize()
+    del o8, o64, d_idx
+    # the LDS-staged kernels (from 2^19 blocks): 2^22 blocks, 6 cold index arrays
+    nbig, nb6 = 1 << 22, 6
+    d_idx = [torch.from_numpy(synth.etc1s_indices(nbig, 4096, 8192, seed=300 + k).view(np.int32)).to(dev) for k in range(nb6)]
+    o8 = [torch.empty((nbig, 8), dtype=torch.uint8, device=dev) for _ in range(nb6)]
+    o64 = [torch.empty((nbig, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+    for k in range(nb6 * 2 * REPS):
+        lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx[k % nb6].data_ptr(), nbig, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o8[k % nb6].data_ptr(), None, sp)
+    for k in range(nb6 * REPS):
+        lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx[k % nb6].data_ptr(), None, 2048, 2048, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, o64[k % 2].data_ptr(), None, sp)
+    torch.cuda.synchronize()
 print("done")
