@@ -11,9 +11,11 @@ t0 = time.time(); total = 0
 SEED0 = int(os.environ.get("FUZZ_SEED0", 0))
 for seed in range(SEED0, SEED0 + int(os.environ.get("FUZZ_SEEDS", 4))):
     n = 1 << 20
-    for kind in ("valid", "raw"):
+    for kind in os.environ.get("FUZZ_KINDS", "valid,raw").split(","):
         if kind == "valid":
             blocks = synth.atlas_rand(n, seed=500 + seed)
+        elif kind == "contrast":  # endpoints at the extremes, skewed weights (synth.atlas_contrast)
+            blocks = synth.atlas_contrast(n, seed=700 + seed)
         else:
             blocks = np.random.Generator(np.random.PCG64(900 + seed)).integers(0, 256, size=(n, 16), dtype=np.uint8)
         for t in ("astc", "bc7", "etc1", "etc2", "rgba"):
