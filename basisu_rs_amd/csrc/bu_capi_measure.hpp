@@ -8,7 +8,8 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
 {
     if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
     if (n_blocks == 0) return BU_OK;
-    hipLaunchKernelGGL(bu_copy_kernel, dim3(bu_grid_for(n_blocks, ctx->cu_count)), dim3(BU_WG), 0, static_cast<hipStream_t>(stream),
+    const size_t per_wg = (size_t)BU_COPY_WG * BU_COPY_EPT;
+    hipLaunchKernelGGL(bu_copy_kernel, dim3((unsigned)((n_blocks + per_wg - 1) / per_wg)), dim3(BU_COPY_WG), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), n_blocks);
     BU_HIP(ctx, hipGetLastError());
     return BU_OK;

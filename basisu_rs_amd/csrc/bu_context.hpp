@@ -84,6 +84,7 @@ size_t bu_balanced_tile(size_t max_tile, size_t n_blocks, size_t slots, bool dyn
 // BC7, ASTC and RGBA32, the 4096-block tiles (64 x 64) of ETC1 and ETC2
 constexpr bool bu_rect_compiled(int target, int tile)
 {
+    if (target == BU_TGT_BC7 && tile == BuBigCfg<BU_TGT_BC7>::WGS * BuBigCfg<BU_TGT_BC7>::BPT) return true;
     return tile == 1024 ? (target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA)
                         : (tile == 4096 && (target == BU_TGT_ETC1 || target == BU_TGT_ETC2));
 }
@@ -121,12 +122,11 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
                 return grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21) && nb % (rh * bpr) == 0 &&
                        (n_blocks <= piece || piece % (rh * bpr) == 0);
             };
-            const bool rect = rect_ok(1024 / RW), rect64 = rect_ok(4096 / RW);
-            const unsigned rect_magic = (rect || rect64) ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
+            const unsigned rect_magic = (bpr >= 2 * RW && bpr % RW == 0) ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
 #define BU_GO(T, W, B, MINW, PF, DIR, SK, GRID, CUS, TRT)                                                                                       \
     do {                                                                                                                                        \
         constexpr int tile_ = (W) * (B);                                                                                                        \
-        if (bu_rect_compiled(T, tile_) && (tile_ == 1024 ? rect : (rect64 && (TRT) == 4096u)))                                                  \
+        if (bu_rect_compiled(T, tile_) && rect_ok((size_t)tile_ / RW) && ((T) == BU_TGT_BC7 || tile_ == 1024 || (TRT) == 4096u))                \
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, bu_rect_compiled(T, tile_)>), dim3(GRID), dim3(W), 0, stream, pin, pout, \
                                (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, rect_magic BU_STAMP_PASS);                           \
         else                                                                                                                                    \
@@ -147,6 +147,14 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         /* generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per */      \
         /* slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0) */   \
         const unsigned pcus = (btiles <= bcap || btiles % bcap == 0) ? (unsigned)ctx->cu_count : 0u;                                    \
+        if constexpr (C::NT > 1) {                                                                                                      \
+            /* every load up front: exact grids of whole rectangular tiles only */                                                      \
+            if (btiles % C::NT == 0 && btiles / C::NT <= bcap && rect_ok((size_t)C::WGS * C::BPT / RW)) {                               \
+                hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_RECT, C::NT>), dim3((unsigned)(btiles / C::NT)), \
+                                   dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, rect_magic BU_STAMP_PASS); \
+                break;                                                                                                                  \
+            }                                                                                                                           \
+        }                                                                                                                               \
         BU_GO(T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW, (unsigned)(btiles < bcap ? btiles : bcap), pcus, (unsigned)tile_rt); \
     } else if (grid_cap == 0) {                                                                                                         \
         /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \

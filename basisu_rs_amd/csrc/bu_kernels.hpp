@@ -182,13 +182,20 @@ struct BuBigCfg {
     // tile k.  Nothing changes for one tile per workgroup (2^20 blocks: 19.17 / 19.11 us); 2^25 blocks ETC1 516 -> 474 us,
     // ETC2 661 -> 613, BC7 227 -> 213 (0.63 of the HBM peak).  ASTC would cross 64 VGPRs (2^20 blocks: 9.55 -> 12.97 us).
     static constexpr bool PREFETCH = true, DIRECT = false;
-    static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1;
+    static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1, NT = 1;
     static constexpr bool DYN_TILE = true;    // the kernel takes the tile size at run time (bu_balanced_tile)
     static constexpr bool ALL_SIZES = false;  // up to 3 Ki blocks per CU the launcher uses 512 x 2 (1024-block tiles, all resident): bu_launch_uastc
 };
+#ifndef BU_X_WGS
+#define BU_X_WGS 512
+#define BU_X_BPT 2
+#define BU_X_WGPCU 4
+#define BU_X_NT 1
+#endif
 template <>
 struct BuBigCfg<BU_TGT_BC7> {
-    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr int WGS = BU_X_WGS, BPT = BU_X_BPT, WG_PER_CU = BU_X_WGPCU, SKEW = 0, MINW = (BU_X_WGS * BU_X_WGPCU >= 2048 && BU_X_WGS > 512) ? 8 : 1;
+    static constexpr int NT = BU_X_NT;  // tiles a workgroup walks with every load issued up front (launcher: exact grids only)
     static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
     static constexpr bool PREFETCH = true, DIRECT = false;  // 64 VGPRs with the next tile's two loads in flight: still four workgroups per CU
     static constexpr bool DYN_TILE = false;
@@ -197,7 +204,7 @@ template <>
 struct BuBigCfg<BU_TGT_ASTC> {
     static constexpr bool DYN_TILE = false;
     static constexpr bool PREFETCH = true, DIRECT = false;  // round 3: 62 VGPRs with the prefetch (round 2: 67); 2^25 blocks 209.5 -> 198.2 us, 2^20 unchanged
-    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1;
+    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1, NT = 1;
     static constexpr bool ALL_SIZES = true;
 };
 // RGBA32 configuration: 1024-block tiles, two workgroups per CU, 1024 x 1 or 512 x 2 threads x blocks by slice size (bu_launch_uastc)
@@ -258,7 +265,7 @@ struct BuTileDesc {
     uint64_t base;
 };
 enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP>
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1>
 __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                      unsigned bpr, unsigned long long base, unsigned long long* status,
                                                      const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
@@ -278,12 +285,23 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // blocks: the one-tile workgroups of the second generation would run ahead of the two-tile ones, 15.75 against 14.24 us).
     // Round 3, on the leaner kernels: generation priorities 0, 3, 2, 1 beat 0, 1, 2, 3 for BC7 (9.13 -> 8.96 us) and ASTC (9.0 -> 8.8),
     // not for RGBA32 (15.85 -> 16.0); no priorities 9.14 / 9.04 / 17.4 (profiles/r03_ab_wave_priorities.txt).
+#ifdef BU_X_PRIO  // experiment: BU_X_PRIO = priorities of generations 0..3 as four decimal digits, BU_X_STAG1..3 = s_sleep counts in front of the tile loads
+    unsigned bu_gen = 0;
+    if (cus != 0) {
+        bu_gen = blockIdx.x >= 3 * cus ? 3u : (blockIdx.x >= 2 * cus ? 2u : (blockIdx.x >= cus ? 1u : 0u));
+        if (bu_gen == 3) __builtin_amdgcn_s_setprio((BU_X_PRIO) % 10);
+        else if (bu_gen == 2) __builtin_amdgcn_s_setprio((BU_X_PRIO) / 10 % 10);
+        else if (bu_gen == 1) __builtin_amdgcn_s_setprio((BU_X_PRIO) / 100 % 10);
+        else __builtin_amdgcn_s_setprio((BU_X_PRIO) / 1000 % 10);
+    }
+#else
     if (cus != 0) {  // (comparisons, not blockIdx / cus: a scalar division is ~25 instructions in front of the first load)
         constexpr bool ROT = TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC;
         if (blockIdx.x >= 3 * cus) __builtin_amdgcn_s_setprio(ROT ? 1 : 3);
         else if (blockIdx.x >= 2 * cus) __builtin_amdgcn_s_setprio(2);
         else if (blockIdx.x >= cus) __builtin_amdgcn_s_setprio(ROT ? 3 : 1);
     }
+#endif
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ uint4 t_store[bu_lds_table_bytes(TARGET) / 16];  // the blob as far as TARGET reads it (BC7: its own tables in front)
     BuTables& T = *reinterpret_cast<BuTables*>(t_store + bu_lds_front(TARGET) / 16);
@@ -294,6 +312,10 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // which is what lets two workgroups share a CU.
     constexpr bool RECT = LAYOUT == BU_LAYOUT_RECT, MULTI = LAYOUT == BU_LAYOUT_MULTI;
     static_assert(!MULTI || (!PREFETCH && !DIRECT), "the multi-slice layout is compiled for the plain one-tile-at-a-time shapes");
+    // NT > 1: the workgroup walks exactly NT tiles (tile, tile + grid, ...) and issues the loads of ALL of them before anything
+    // else, unconditionally (the launcher guarantees n_tiles == NT * gridDim.x, whole rectangular tiles): tile k's data are
+    // sorted and transcoded while the later tiles' loads are still in flight
+    static_assert(NT == 1 || LAYOUT == BU_LAYOUT_RECT, "tiles loaded up front: rectangular layout, exact grids");
     constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
     static_assert(!BU_ALIAS || bu_lds_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
@@ -374,7 +396,10 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // rest held in registers until the first tile's rank atomics are out (A/B: ETC1 19.45 -> 19.0 us in round 2; tables first
     // 19.2 -> 19.8 in round 3).
     constexpr BuTableRange TR = bu_table_range(TARGET);
-    constexpr bool SPLIT = bu_lds_table_bytes(TARGET) > 16384;
+#ifndef BU_SPLIT_MIN
+#define BU_SPLIT_MIN 16384
+#endif
+    constexpr bool SPLIT = bu_lds_table_bytes(TARGET) > BU_SPLIT_MIN;
     constexpr int TF = (int)bu_lds_front(TARGET) / 16, TV1 = (int)(TR.hi - TR.lo) / 16, TV2 = TR.lo2 < TR.hi2 ? (int)(TR.hi2 - TR.lo2) / 16 : 0;
     constexpr int TVT = TF + TV1 + TV2, TVN = (TVT + WGS - 1) / WGS;
     const uint4* const tsrc = reinterpret_cast<const uint4*>(TARGET == BU_TGT_BC7 ? reinterpret_cast<const void*>(tables) : reinterpret_cast<const void*>(&tables->t));
@@ -387,10 +412,22 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             tv[k] = i < TVT ? tsrc[tdst(i)] : make_uint4(0, 0, 0, 0);
         }
     }
+#if defined(BU_X_PRIO) && defined(BU_X_STAG1)
+    if (bu_gen == 1) __builtin_amdgcn_s_sleep(BU_X_STAG1);
+    else if (bu_gen == 2) __builtin_amdgcn_s_sleep(BU_X_STAG2);
+    else if (bu_gen == 3) __builtin_amdgcn_s_sleep(BU_X_STAG3);
+#endif
     uint4 v[BU_BPT];
 #pragma unroll
     for (int j = 0; j < BU_BPT; j++)
         v[j] = (RECT || blk_valid(tile, j * BU_WG + tid)) ? bu_ld_stream(blk_src(tile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
+    uint4 vq[NT > 1 ? NT - 1 : 1][BU_BPT];
+    if constexpr (NT > 1) {
+#pragma unroll
+        for (int q = 0; q < NT - 1; q++)
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) vq[q][j] = bu_ld_stream(blk_src(tile + (unsigned)(q + 1) * gridDim.x, j * BU_WG + tid));
+    }
     if constexpr (!SPLIT) {
 #pragma unroll
         for (int k = 0; k < TVN; k++) {
@@ -407,6 +444,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut[TARGET])[tid] = reinterpret_cast<const uint32_t*>(tables->t.key_lut[TARGET])[tid];
     }
     bool tables_staged = !SPLIT;
+    BU_STAMP(11)
     if (tid < 64) (&cnt[0][0])[tid] = 0;
     if (tid < 2) next_chunk[tid] = 0;
     __syncthreads();
@@ -428,6 +466,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             key[j] = valid ? T.key_lut[TARGET][v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
+        BU_STAMP(12)
         if (uniform) {
             uint32_t lead[BU_BPT];
 #pragma unroll
@@ -473,7 +512,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         // prefetch the next tile while this one is transcoded
         const unsigned ntile = tile + gridDim.x;
         uint4 vn[BU_BPT];
-        if constexpr (PREFETCH) {
+        if constexpr (PREFETCH && NT == 1) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 vn[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
@@ -482,6 +521,9 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         BU_STAMP(4)
         __syncthreads();  // (2) the sorted tile is complete
         BU_STAMP(5)
+#ifdef BU_X_DYNPRIO
+        __builtin_amdgcn_s_setprio(BU_X_DYNPRIO);
+#endif
         // ---- C: whole chunks, wave-uniform mode ----
         // dynamic chunk scheduling: waves take the next chunk as they free up (one LDS atomic per chunk).  The claim for the
         // FOLLOWING chunk is issued before the current one is transcoded, so its LDS round trip hides under the transcode.
@@ -510,6 +552,12 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             for (int i = 0; i < NO; i++) o[i] = 0;
             int st = BU_ST_BAD_MODE;
             if (active) {
+#ifdef BU_X_REP0  // experiment: no block code (results wrong by construction) -- what the kernel costs around the mode paths
+                if (r < 19u) {
+                    o[0] = b.w[0] | 1u; o[1] = b.w[1]; o[2] = b.w[2]; o[3] = b.w[3];
+                    st = 0;
+                } else
+#endif
                 switch (r) {  // the run number IS the sort key: run k holds mode BU_COST_ORDER[k] (run 19: invalid mode codes)
 #define BU_CASE(k) \
     case k: st = bu_block_mode<TARGET, BU_COST_ORDER[TARGET][k]>(T, b, o); break;
@@ -545,6 +593,9 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             }
         }
         BU_STAMP(6)
+#ifdef BU_X_DYNPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         __syncthreads();  // (3) every result is in LDS
         BU_STAMP(7)
         // ---- D: results leave in original order ----
@@ -589,7 +640,14 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                 }
             }
         }
-        if constexpr (PREFETCH) {
+        if constexpr (NT > 1) {
+#pragma unroll
+            for (int j = 0; j < BU_BPT; j++) v[j] = vq[0][j];
+#pragma unroll
+            for (int q = 0; q + 1 < NT - 1; q++)
+#pragma unroll
+                for (int j = 0; j < BU_BPT; j++) vq[q][j] = vq[q + 1][j];
+        } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
         } else {
@@ -604,13 +662,13 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     }
 }
 
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP>
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
 {
     static_assert(LAYOUT != BU_LAYOUT_MULTI, "several runs per launch: bu_uastc_multi_kernel");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, MINW, PREFETCH, DIRECT, SKEW, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr BU_STAMP_FWD);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, MINW, PREFETCH, DIRECT, SKEW, LAYOUT, NT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr BU_STAMP_FWD);
 }
 
 // several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value)
@@ -681,12 +739,29 @@ __global__ __launch_bounds__(256) void bu_crc16_pieces_kernel(const uint4* __res
     if (threadIdx.x == 0) partial[blockIdx.x] = (uint16_t)(red[0] ^ red[1] ^ red[2] ^ red[3]);
 }
 
-// uint4 -> uint4 copy with the transcoders' launch shape (measurement only)
-__global__ __launch_bounds__(BU_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+// uint4 -> uint4 copy (measurement only): the practical ceiling any 16 B in / 16 B out kernel is compared with.  The shape is the
+// fastest of tools/exp/copy_shapes.hip at 2^20 blocks (profiles/r02_copy_shapes_32MiB.txt): 512 threads, four 16-byte elements per
+// thread issued back to back (all four loads in flight before the first store), nontemporal both ways, one pass per thread --
+// 6.06 us against 7.2 us for one element per thread (fewer, fatter waves shorten the launch ramp).
+constexpr int BU_COPY_WG = 512, BU_COPY_EPT = 4;
+__global__ __launch_bounds__(BU_COPY_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * BU_WG;
-    for (size_t idx = (size_t)blockIdx.x * BU_WG + threadIdx.x; idx < n; idx += stride) bu_st_stream(out + idx, bu_ld_stream(in + idx));  // same streaming hints as the transcoders
-
+    const size_t base = (size_t)blockIdx.x * (BU_COPY_WG * BU_COPY_EPT) + threadIdx.x;
+    uint4 v[BU_COPY_EPT];
+#pragma unroll
+    for (int k = 0; k < BU_COPY_EPT; k++) {
+        const size_t i = base + (size_t)k * BU_COPY_WG;
+        if (i < n) v[k] = bu_ld_stream(in + i);
+    }
+#pragma unroll
+    for (int k = 0; k < BU_COPY_EPT; k++) {
+        const size_t i = base + (size_t)k * BU_COPY_WG;
+        if (i < n) {
+            bu_v4u r;
+            r.x = v[k].x; r.y = v[k].y; r.z = v[k].z; r.w = v[k].w;
+            __builtin_nontemporal_store(r, reinterpret_cast<bu_v4u*>(out + i));
+        }
+    }
 }
 
 // ---- ETC1S back-end ----------------------------------------------------------------------------

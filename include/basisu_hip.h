@@ -298,8 +298,9 @@ bu_status bu_device_free(bu_context* ctx, void* ptr);
 bu_status bu_memcpy(bu_context* ctx, void* dst, const void* src, size_t bytes, int to_device);
 
 /* ---- measurement helpers (bench.py) ------------------------------------------------------------
- * uint4 -> uint4 copy kernel of the same launch shape as the 16 B -> 16 B transcoders: the practical
- * HBM ceiling the roofline fraction is reported next to. */
+ * uint4 -> uint4 copy kernel, 16 B in / 16 B out like the transcoders, in the fastest shape measured for a 4096^2 atlas
+ * (512 threads x 4 elements per thread, nontemporal: profiles/r02_copy_shapes_32MiB.txt): the practical HBM ceiling the
+ * roofline fraction is reported next to. */
 bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blocks, void* d_out, void* stream);
 /* Times `launches` back-to-back launches of one transcode with hipEvents recorded on `stream`
  * around the whole batch (the stream the kernels are launched on).  d_in/d_out are arrays of

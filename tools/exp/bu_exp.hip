@@ -192,6 +192,16 @@ extern "C" bu_status bu_exp_time(bu_context* ctx, int variant, const void* const
                                (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)0, g_stamps);
         } break;
 #undef SV
+        // round 4: rectangular 64-wide tiles (the headline's layout, bpr 1024), NT tiles per workgroup with every load up front
+#define RV(code, W, B, MINW, PF, NT_, GRID)                                                                                                   \
+    case code:                                                                                                                                \
+        hipLaunchKernelGGL((bu_uastc_sorted_kernel<BU_TGT_BC7, W, B, MINW, PF, false, 0, BU_LAYOUT_RECT, NT_>), dim3(GRID), dim3(W), 0, s, in, d_out[k], \
+                           (unsigned)n_blocks, 1024u, 0ull, (unsigned long long*)nullptr, ctx->d_tables, (unsigned)ctx->cu_count, 0x10000000u, g_stamps); \
+        break;
+            RV(60, 512, 2, 1, true, 1, 1024) RV(61, 1024, 1, 8, false, 2, 512) RV(62, 1024, 2, 8, true, 1, 512) RV(63, 1024, 4, 1, true, 1, 256)
+            RV(64, 512, 4, 1, true, 1, 512) RV(65, 1024, 2, 1, false, 2, 256) RV(66, 512, 2, 1, false, 2, 512) RV(67, 512, 1, 1, false, 2, 1024)
+            RV(68, 1024, 1, 1, false, 4, 256)
+#undef RV
         default: return BU_ERR_ARGUMENT;
         }
     }
