@@ -124,6 +124,10 @@ class Context:
         self._check(st, bad)
         return out[: n * 64]
 
+    def block_api_on_device(self, enable):
+        """Per-block API: False (default) = the library's own block code on the calling thread, True = a one-block kernel launch."""
+        self._check(self._lib.bu_block_api_on_device(self._h, 1 if enable else 0))
+
     def _block(self, fn, block, out_bytes):
         a = _as_u8(block)
         if a.size != 16:

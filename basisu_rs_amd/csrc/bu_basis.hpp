@@ -21,6 +21,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/basisu_hip.h"
@@ -36,7 +37,7 @@ class Pool {
     std::condition_variable cv, cv_done;
     std::vector<std::thread> th;
     const std::function<void()>* job = nullptr;
-    unsigned epoch = 0, want = 0, started = 0, running = 0;
+    unsigned epoch = 0, want = 0, started = 0, running = 0, active_helpers = 0;
     bool stop = false;
     int owner_pid = 0;
 
@@ -67,7 +68,22 @@ public:
     // runs f on the calling thread and on up to `helpers` pool threads at once; returns when every copy has returned
     void run(unsigned helpers, const std::function<void()>& f)
     {
-        std::lock_guard<std::mutex> serial(run_m);
+        begin(helpers, f);
+        try {
+            f();
+        } catch (...) {
+            end();
+            throw;
+        }
+        end();
+    }
+    // the two halves of run() for a caller that has something else to do meanwhile (bu_read_to feeds the GPU while pool threads
+    // decode): begin() starts up to `helpers` copies of f on pool threads and returns how many it started (0: no thread could
+    // be had -- the caller must run f itself); end() waits for them.  The pool is reserved from begin() to end(); f must stay
+    // alive until end() returns.
+    unsigned begin(unsigned helpers, const std::function<void()>& f)
+    {
+        run_m.lock();
         const int pid = (int)getpid();
         if (owner_pid != pid) {  // first use, or a forked child (threads do not survive fork: forget them)
             for (std::thread& t : th) t.detach();
@@ -80,6 +96,7 @@ public:
         } catch (...) {  // no more threads to be had (std::system_error): run with the helpers that exist -- every job
             helpers = (unsigned)th.size();  // pulls its items from a shared counter, so fewer copies only means less overlap
         }
+        active_helpers = helpers;
         if (helpers) {
             std::lock_guard<std::mutex> lk(m);
             job = &f;
@@ -89,13 +106,18 @@ public:
             epoch++;
         }
         cv.notify_all();
-        f();
-        if (helpers) {
+        return helpers;
+    }
+    void end()
+    {
+        if (active_helpers) {
             std::unique_lock<std::mutex> lk(m);
             cv_done.wait(lk, [&] { return running == 0; });
             job = nullptr;
             want = 0;
         }
+        active_helpers = 0;
+        run_m.unlock();
     }
     ~Pool()
     {
@@ -346,14 +368,54 @@ public:
             next[bits] = total;
         }
         table_.assign((size_t)1 << max_, 0u);
-        for (size_t sym = 0; sym < sizes.size(); sym++) {
-            const unsigned size = sizes[sym];
-            if (!size) continue;
-            const uint32_t code = next[size]++;
-            uint32_t rev = 0;
-            for (unsigned k = 0; k < size; k++) rev |= ((code >> k) & 1u) << (size - 1 - k);
-            const uint32_t entry = ((uint32_t)sym << 5) | size;
-            for (uint32_t id = rev; id < ((uint32_t)1 << max_); id += (1u << size)) table_[id] = entry;
+        // Kraft sum in units of 2^-max_: above 2^max_ the length set is over-subscribed and entries collide
+        uint64_t kraft = 0;
+        for (int bits = 1; bits <= 16; bits++) kraft += (uint64_t)count[bits] << (max_ >= (unsigned)bits ? max_ - bits : 0);
+        auto rev_code = [](uint32_t code, unsigned size) {  // the low `size` bits of code, reversed
+            uint32_t v = code;
+            v = ((v >> 1) & 0x5555u) | ((v & 0x5555u) << 1);
+            v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2);
+            v = ((v >> 4) & 0x0F0Fu) | ((v & 0x0F0Fu) << 4);
+            v = ((v >> 8) & 0x00FFu) | ((v & 0x00FFu) << 8);
+            return (v & 0xFFFFu) >> (16 - size);
+        };
+        if (kraft > ((uint64_t)1 << max_)) {
+            // over-subscribed (a damaged file): the reference's symbol-order fill, later symbols overwriting earlier ones
+            for (size_t sym = 0; sym < sizes.size(); sym++) {
+                const unsigned size = sizes[sym];
+                if (!size) continue;
+                const uint32_t code = next[size]++;
+                uint32_t rev = 0;
+                for (unsigned k = 0; k < size; k++) rev |= ((code >> k) & 1u) << (size - 1 - k);
+                const uint32_t entry = ((uint32_t)sym << 5) | size;
+                for (uint32_t id = rev; id < ((uint32_t)1 << max_); id += (1u << size)) table_[id] = entry;
+            }
+        } else {
+            // a prefix code: no two symbols share an entry, so the fill order is free.  Symbol by symbol the copies of a code lie
+            // 2^size entries apart -- 32 768 cache-missing stores for a 15-bit selector table (0.1 ms: on the critical path of a
+            // single-slice file).  Grouped by length and walked copy by copy instead, every pass stays inside one window of
+            // 2^size entries.
+            std::vector<uint32_t> ent(sizes.size()), revs(sizes.size());
+            uint32_t first[18] = {0};
+            for (int bits = 1; bits <= 16; bits++) first[bits + 1] = first[bits] + count[bits];
+            uint32_t fill[18];
+            memcpy(fill, first, sizeof(fill));
+            for (size_t sym = 0; sym < sizes.size(); sym++) {
+                const unsigned size = sizes[sym];
+                if (!size) continue;
+                const uint32_t code = next[size]++;
+                const uint32_t at = fill[size]++;
+                revs[at] = rev_code(code, size);
+                ent[at] = ((uint32_t)sym << 5) | size;
+            }
+            for (unsigned size = 1; size <= max_; size++) {
+                const uint32_t a = first[size], b = first[size + 1];
+                if (a == b) continue;
+                for (uint32_t hi = 0; hi < ((uint32_t)1 << (max_ - size)); hi++) {
+                    uint32_t* const win = table_.data() + ((size_t)hi << size);
+                    for (uint32_t k = a; k < b; k++) win[revs[k]] = ent[k];
+                }
+            }
         }
         for (int bits = 0; bits <= 16; bits++)
             if (next[bits] > 65536u) return BU_ERR_BASISLZ;
@@ -368,6 +430,10 @@ public:
         *sym = e >> 5;
         return true;
     }
+
+    // the fast slice loop reads the table directly: entry = symbol << 5 | code_size (0 = no code), index = the next bits() bits
+    const uint32_t* table() const { return table_.data(); }
+    unsigned bits() const { return max_; }
 
 private:
     std::vector<uint32_t> table_;  // symbol << 5 | code_size, indexed by the next max_ bits (LSB first)
@@ -414,6 +480,10 @@ struct BasisLz {
     bool is_video = false;
     std::vector<uint32_t> endpoints;  // r5 | g5<<8 | b5<<16 | inten<<24
     std::vector<uint8_t> selectors;   // 8 B per entry: rows[4], etc1_bytes[4]
+    // Codebook sizes as the slice loop checks them (mod.rs:443-445).  Kept beside the vectors because bu_read_to decodes the
+    // codebooks on another thread WHILE the slices' symbol streams are decoded: the slice loop needs the sizes and the four
+    // Huffman tables (init_tables), never the codebook entries.
+    uint32_t n_endpoints = 0, n_selectors = 0;
 
     // mod.rs:461-516
     bu_status decode_endpoints(size_t num, const uint8_t* p, size_t n)
@@ -476,22 +546,38 @@ struct BasisLz {
         return BU_OK;
     }
 
-    // mod.rs:64-95
-    bu_status init(size_t n_endpoints, size_t n_selectors, const uint8_t* ep, size_t ep_len, const uint8_t* sel, size_t sel_len,
-                   const uint8_t* tables, size_t tables_len, bool video)
+    // mod.rs:77-83: the four tables of the slice loop and the history size
+    bu_status init_tables(size_t n_ep, size_t n_sel, const uint8_t* tables, size_t tables_len, bool video)
     {
         is_video = video;
-        bu_status st = decode_endpoints(n_endpoints, ep, ep_len);
-        if (st) return st;
-        st = decode_selectors(n_selectors, sel, sel_len);
-        if (st) return st;
+        n_endpoints = (uint32_t)n_ep;
+        n_selectors = (uint32_t)n_sel;
         BitReader r(tables, tables_len);
+        bu_status st;
         if ((st = read_huffman_table(r, endpoint_pred))) return st;
         if ((st = read_huffman_table(r, delta_endpoint))) return st;
         if ((st = read_huffman_table(r, selector))) return st;
         if ((st = read_huffman_table(r, history_rle))) return st;
         history_size = r.read(13);
         return BU_OK;
+    }
+    // mod.rs:69-76: both codebooks (errors of the endpoint codebook come first, as in the reference)
+    bu_status init_codebooks(const uint8_t* ep, size_t ep_len, const uint8_t* sel, size_t sel_len)
+    {
+        bu_status st = decode_endpoints(n_endpoints, ep, ep_len);
+        if (st) return st;
+        return decode_selectors(n_selectors, sel, sel_len);
+    }
+    // mod.rs:64-95 in the reference's order: codebooks, then tables
+    bu_status init(size_t n_ep, size_t n_sel, const uint8_t* ep, size_t ep_len, const uint8_t* sel, size_t sel_len,
+                   const uint8_t* tables, size_t tables_len, bool video)
+    {
+        is_video = video;
+        n_endpoints = (uint32_t)n_ep;
+        n_selectors = (uint32_t)n_sel;
+        bu_status st = init_codebooks(ep, ep_len, sel, sel_len);
+        if (st) return st;
+        return init_tables(n_ep, n_sel, tables, tables_len, video);
     }
 
     // mod.rs:585-608
@@ -509,10 +595,217 @@ struct BasisLz {
     }
 
     // mod.rs:188-458: the serial symbol loop.  idx[i] = endpoint_index | selector_index << 16, raster order.
-    bu_status decode_slice(size_t nbx, size_t nby, const uint8_t* data, size_t len, uint32_t* idx) const
+    // A slice's stream is serial, so this loop IS the end-to-end time of a single-slice ETC1S file (BASELINE config 4: 1.86 of
+    // 2.6 ms).  decode_slice_fast is the same state machine written for the host core's pipeline -- one 8-byte window refill per
+    // block, the delta-endpoint code looked up speculatively and consumed by a conditional move (the 4-way predictor switch
+    // mispredicts three times in four on real streams), edge violations and missing codes folded into one sticky flag -- and
+    // decides nothing about errors: whenever the flag is set the exact loop below (decode_slice_exact, the round-1 code, status
+    // for status the oracle's) decodes the slice again from its first bit.
+    // rows_done (optional): the number of complete block rows in idx[], published row by row (release) for a consumer that
+    // works on finished rows while the rest is decoded; only rows free of any irregularity are ever published, and those are
+    // final.  abort (optional): checked between rows; a set flag ends the call with BU_ERR_ARGUMENT (the caller discards it).
+    bu_status decode_slice(size_t nbx, size_t nby, const uint8_t* data, size_t len, uint32_t* idx, std::atomic<uint32_t>* rows_done = nullptr,
+                           const std::atomic<bool>* abort = nullptr) const
+    {
+        if (nbx && nby && decode_slice_fast(nbx, nby, data, len, idx, rows_done, abort)) return BU_OK;
+        if (abort && abort->load(std::memory_order_relaxed)) return BU_ERR_ARGUMENT;
+        return decode_slice_exact(nbx, nby, data, len, idx);
+    }
+
+    // true = the slice decoded without any irregularity and idx[] is complete; false = anything else (idx[] partly written)
+    bool decode_slice_fast(size_t nbx, size_t nby, const uint8_t* data, size_t len, uint32_t* idx, std::atomic<uint32_t>* rows_done = nullptr,
+                           const std::atomic<bool>* abort = nullptr) const
+    {
+        const uint32_t n_ep = n_endpoints, n_sel = n_selectors;
+        const uint32_t hs = history_size;
+        if (n_ep == 0 || n_sel == 0 || n_ep > 65536u || n_sel > 65536u) return false;
+        if (!endpoint_pred.bits() || !delta_endpoint.bits() || !selector.bits() || !history_rle.bits()) return false;
+        const uint32_t *tp = endpoint_pred.table(), *td = delta_endpoint.table(), *ts = selector.table(), *tr = history_rle.table();
+        const uint32_t mp = (1u << endpoint_pred.bits()) - 1u, md = (1u << delta_endpoint.bits()) - 1u, msel = (1u << selector.bits()) - 1u,
+                       mr = (1u << history_rle.bits()) - 1u;
+        // bit window: `have` valid bits in `acc`; refilled to >= 56 once per block (a block consumes at most 16 + 16 + 16 bits outside
+        // the rare escape paths, which refill for themselves); bytes past the end read as zeros (bitreader.rs:45,55)
+        uint64_t acc = 0;
+        unsigned have = 0;
+        size_t pos = 0;
+        auto refill = [&]() __attribute__((always_inline)) {
+            if (pos + 8 <= len) {
+                uint64_t w;
+                memcpy(&w, data + pos, 8);
+                acc |= w << have;
+                pos += (63u - have) >> 3;
+                have |= 56u;
+            } else {
+                while (have <= 56) {
+                    const uint64_t byte = pos < len ? data[pos] : 0;
+                    pos++;
+                    acc |= byte << have;
+                    have += 8;
+                }
+            }
+        };
+        auto take = [&](unsigned n) {
+            const uint32_t v = (uint32_t)(acc & ((1ull << n) - 1ull));
+            acc >>= n;
+            have -= n;
+            return v;
+        };
+        auto vlc_fast = [&](unsigned chunk_bits, uint32_t* out) {
+            uint32_t v = 0;
+            for (unsigned ofs = 0;; ofs += chunk_bits) {
+                if (ofs >= 32) return false;
+                if (have < 16) refill();
+                const uint32_t sy = take(chunk_bits + 1);
+                v |= (sy & ((1u << chunk_bits) - 1u)) << ofs;
+                if (!(sy >> chunk_bits)) break;
+            }
+            *out = v;
+            return true;
+        };
+        std::vector<uint16_t> above_v(nbx + 1, 0), cur_v(nbx + 1, 0);  // [0] = the column left of the slice (never a valid source)
+        std::vector<uint8_t> saved_bits((nbx + 1) / 2, 0);                // per 2-block group: the predictors of the odd row below
+        std::vector<uint16_t> hist(hs ? hs : 1, 0);
+        uint16_t *above = above_v.data() + 1, *cur_row = cur_v.data() + 1;
+        uint32_t rover = hs / 2;
+        const uint32_t rle_sym = (n_sel + hs) & 0xFFFFu;
+        uint32_t sel_rle = 0, pred_repeat = 0, prev_pred_sym = 0, prev_ep = 0, bad = 0;
+        const bool video = is_video;
+        uint32_t* out_row = idx;
+        // one block: predictor `pred`; edge = bit p set where predictor p has no source (checked only on the slice's first row and
+        // column: EDGE = false compiles the test away for the interior).  Returns false where the fast path gives up.
+        auto block = [&](size_t bx, uint32_t pred, uint32_t edge, auto edge_tag) __attribute__((always_inline)) -> bool {
+            if constexpr (decltype(edge_tag)::value) bad |= (edge >> pred) & 1u;
+            // the delta-endpoint code at the window's head is looked up whether or not this block uses it, and consumed by a
+            // conditional move: the predictor is a coin toss to the branch predictor
+            const uint32_t ed = td[(uint32_t)acc & md];
+            const bool is3 = pred == 3;
+            const uint32_t dl = is3 ? (ed & 31u) : 0u;
+            acc >>= dl;
+            have -= dl;
+            uint32_t e3 = ((ed >> 5) + prev_ep) & 0xFFFFu;
+            e3 = e3 >= n_ep ? (e3 - n_ep) & 0xFFFFu : e3;
+            bad |= is3 & (((ed & 31u) == 0u) | (e3 >= n_ep));
+            const uint32_t e01 = (pred & 1) ? above[bx] : prev_ep;
+            const uint32_t e2 = video ? 0u : above[(ptrdiff_t)bx - 1];
+            const uint32_t e = is3 ? e3 : ((pred & 2) ? e2 : e01);  // (copies of earlier, checked indices: < n_ep)
+            cur_row[bx] = (uint16_t)e;
+            prev_ep = e;
+            if (video && pred == 2) {  // previous frame's selector: zero (mod.rs:236-237, 428-431)
+                out_row[bx] = e;
+                return true;
+            }
+            if (sel_rle) {  // inside a run of history entry 0 (mod.rs:380-396): use_index(0) swaps the entry with itself
+                sel_rle--;
+                out_row[bx] = e | ((uint32_t)hist[0] << 16);
+                return true;
+            }
+            const uint32_t es = ts[(uint32_t)acc & msel];
+            bad |= (es & 31u) == 0u;
+            acc >>= (es & 31u);
+            have -= (es & 31u);
+            uint32_t sym = es >> 5, sel;
+            if (sym == rle_sym) {
+                if (hs == 0) return false;
+                if (have < 16) refill();
+                const uint32_t er = tr[(uint32_t)acc & mr];
+                if ((er & 31u) == 0u) return false;
+                acc >>= (er & 31u);
+                have -= (er & 31u);
+                uint32_t run = er >> 5;
+                if (run == 63) {
+                    uint32_t v;
+                    if (!vlc_fast(7, &v)) return false;
+                    run = v;
+                }
+                sel_rle = 3 + run - 1;
+                sym = n_sel;
+            }
+            if (sym >= n_sel) {
+                const uint32_t hi = sym - n_sel;
+                if (hi >= hs) return false;
+                sel = hist[hi];
+                const uint16_t t = hist[hi / 2];  // (hi == 0: swaps entry 0 with itself)
+                hist[hi / 2] = (uint16_t)sel;
+                hist[hi] = t;
+            } else {
+                if (hs) {
+                    hist[rover] = (uint16_t)sym;
+                    rover = rover + 1 == hs ? hs / 2 : rover + 1;
+                }
+                sel = sym;
+            }
+            out_row[bx] = e | (sel << 16);  // (sel: a symbol below n_sel or a history entry, i.e. an earlier such symbol or the initial 0)
+            return true;
+        };
+        // the 8 predictor bits of the 2 x 2 group at an even row: a symbol, or the previous symbol again inside a repeat run
+        auto group_bits = [&](uint32_t* bits) __attribute__((always_inline)) -> bool {
+            if (pred_repeat) {
+                pred_repeat--;
+                *bits = prev_pred_sym;
+                return true;
+            }
+            const uint32_t e0 = tp[(uint32_t)acc & mp];
+            bad |= (e0 & 31u) == 0u;
+            acc >>= (e0 & 31u);
+            have -= (e0 & 31u);
+            const uint32_t sy = e0 >> 5;
+            if (sy == 256) {
+                uint32_t v;
+                if (!vlc_fast(4, &v)) return false;
+                pred_repeat = v + 2;
+                *bits = prev_pred_sym;
+                refill();
+            } else {
+                *bits = sy & 0xFF;
+                prev_pred_sym = sy & 0xFF;
+            }
+            return true;
+        };
+        using Edge = std::integral_constant<bool, true>;
+        using Inner = std::integral_constant<bool, false>;
+        for (size_t by = 0; by < nby; by++) {
+            // predictor p is invalid where bit p of the edge mask is set: 0 (left) in column 0, 1 (above) in row 0, 2 (above-left) in
+            // both -- except in texture video, where 2 means "previous frame" (mod.rs:301-355)
+            const uint32_t row_edge = by == 0 ? (video ? 2u : 6u) : 0u, col_edge = video ? 1u : 5u;
+            const bool even = !(by & 1);
+            out_row = idx + by * nbx;
+            for (size_t bx = 0; bx < nbx; bx += 2) {
+                refill();
+                uint32_t bits;
+                if (even) {
+                    if (!group_bits(&bits)) return false;
+                    saved_bits[bx >> 1] = (uint8_t)(bits >> 4);
+                } else {
+                    bits = saved_bits[bx >> 1];
+                }
+                if (bx == 0 || by == 0) {
+                    if (!block(bx, bits & 3, row_edge | (bx == 0 ? col_edge : 0u), Edge())) return false;
+                    if (bx + 1 < nbx) {
+                        refill();
+                        if (!block(bx + 1, (bits >> 2) & 3, row_edge, Edge())) return false;
+                    }
+                } else {
+                    if (!block(bx, bits & 3, 0u, Inner())) return false;
+                    if (bx + 1 < nbx) {
+                        refill();
+                        if (!block(bx + 1, (bits >> 2) & 3, 0u, Inner())) return false;
+                    }
+                }
+            }
+            if (bad) return false;
+            std::swap(above, cur_row);
+            if (rows_done) {
+                rows_done->store((uint32_t)(by + 1), std::memory_order_release);
+                if (abort && abort->load(std::memory_order_relaxed)) return false;
+            }
+        }
+        return true;
+    }
+
+    bu_status decode_slice_exact(size_t nbx, size_t nby, const uint8_t* data, size_t len, uint32_t* idx) const
     {
         BitReader r(data, len);
-        const uint32_t n_ep = (uint32_t)endpoints.size(), n_sel = (uint32_t)(selectors.size() / 8);
+        const uint32_t n_ep = n_endpoints, n_sel = n_selectors;
         // two rows of per-column state: endpoint index of the row above / pending 4 predictor bits for the row below
         std::vector<uint16_t> above(nbx, 0), cur_row(nbx, 0);
         std::vector<uint8_t> saved_bits(nbx, 0);

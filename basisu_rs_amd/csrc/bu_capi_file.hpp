@@ -67,6 +67,262 @@ static bu_status bu_basislz_decode_impl(const uint8_t* file, size_t len, uint32_
     return st;
 }
 
+
+// ---- streamed ETC1S front door -------------------------------------------------------------------------------------------------
+// A slice's symbol stream is serial (one host core: 1.86 ms of BASELINE config 4's 2.6), and everything else used to queue up in
+// front of and behind it: payload CRC 0.12 ms, codebooks 0.19 ms, upload + kernel + download 0.4 ms.  Here they run BESIDE it:
+//   * the slice loop needs the four Huffman tables and the codebook SIZES, never the codebook entries: the tables are parsed first
+//     (tens of microseconds), then pool threads decode the codebooks, run the payload CRC and decode the slices, all at once;
+//   * the decoders write their indices into a page-locked buffer the kernels read directly over PCIe (no upload), and publish
+//     finished block rows; the calling thread launches the whole-file kernel over each band of finished 64-block units, so the
+//     band's results travel to the (page-locked) output while the next rows are decoded.
+// Errors keep the reference's order: CRC (basis.rs:338-341) before codebooks (mod.rs:69-76) before tables (:77-83) before slices
+// (first failing slice in file order); work already launched for a file that fails is drained and its output discarded.
+constexpr size_t BU_ETC1S_STREAM_MIN_BLOCKS = 32768, BU_ETC1S_BAND_BLOCKS = 16384;
+
+static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, const BuFilePlan& p, uint8_t* out,
+                                        bool crc_pending, uint16_t crc_want, bool trace)
+{
+    using bu_host::in_file;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t = now();
+        fprintf(stderr, "[bu_read_to] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    const bu_basis_header& h = p.h;
+    if (!in_file(len, h.endpoint_cb_file_ofs, h.endpoint_cb_file_size) || !in_file(len, h.selector_cb_file_ofs, h.selector_cb_file_size) ||
+        !in_file(len, h.tables_file_ofs, h.tables_file_size) || !in_file(len, h.extended_file_ofs, h.extended_file_size))
+        return (crc_pending && bu_host::crc16(file + 77, len - 77, 0) != crc_want) ? BU_ERR_DATA_CRC : BU_ERR_BOUNDS;
+    bu_host::BasisLz lz;
+    // total_selectors for both codebooks: basis.rs:289-291
+    const bu_status st_tables = lz.init_tables(h.total_selectors, h.total_selectors, file + h.tables_file_ofs, h.tables_file_size, h.tex_type == 3);
+    lap("tables");
+    const size_t n_img = p.images.size();
+    auto align_up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // layout of the index buffer and the kernel's slice table, as in the one-launch path
+    std::vector<size_t> in_off(n_img, 0), ain_off(n_img, 0);
+    size_t words = 0;
+    for (size_t k = 0; k < n_img; k++) {
+        const bu_slice_desc& s = p.slices[p.first_slice[k]];
+        const size_t nblk = (size_t)s.num_blocks_x * s.num_blocks_y;
+        in_off[k] = words;
+        words += (nblk + 63) & ~(size_t)63;
+        if (p.alpha_pairs) {
+            ain_off[k] = words;
+            words += (nblk + 63) & ~(size_t)63;
+        }
+    }
+    std::vector<BuEtc1sSlice> descs;
+    std::vector<uint32_t> unit0(n_img, 0), units_of(n_img, 0);
+    uint32_t n_units = 0;
+    for (size_t k = 0; k < n_img; k++) {
+        const bu_slice_desc& sl = p.slices[p.first_slice[k]];
+        const size_t nblk = (size_t)sl.num_blocks_x * sl.num_blocks_y;
+        unit0[k] = n_units;
+        if (p.images[k].size == 0 || nblk == 0) continue;
+        BuEtc1sSlice d;
+        d.unit0 = n_units;
+        d.n_blocks = (uint32_t)nblk;
+        d.nbx = sl.num_blocks_x;
+        d.idx_ofs = (uint32_t)in_off[k];
+        d.aidx_ofs = (p.alpha_pairs && target == BU_READ_RGBA) ? (uint32_t)ain_off[k] : 0xFFFFFFFFu;
+        d.image = (uint32_t)k;
+        d.out_ofs = p.images[k].offset;
+        descs.push_back(d);
+        units_of[k] = (uint32_t)((nblk + 63) / 64);
+        n_units += units_of[k];
+    }
+    BuEtc1sSlice end = {};
+    end.unit0 = n_units;
+    descs.push_back(end);
+
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint64_t> status_words(n_img, 0);  // landing area of the status download: outlives the drain
+    BuDrain drain(ctx);
+    const size_t idx_bytes = (words ? words : 16) * 4;
+    if (idx_bytes > ctx->h_idx_cap) {
+        if (ctx->h_idx) BU_HIP(ctx, hipHostFree(ctx->h_idx));
+        ctx->h_idx = nullptr;
+        ctx->h_idx_cap = 0;
+        const size_t cap = idx_bytes < ((size_t)4 << 20) ? ((size_t)4 << 20) : idx_bytes + idx_bytes / 4;
+        BU_HIP(ctx, hipHostMalloc(&ctx->h_idx, cap, hipHostMallocDefault));
+        ctx->h_idx_cap = cap;
+    }
+    uint32_t* const h_idx = static_cast<uint32_t*>(ctx->h_idx);
+    void* d_idx_view = nullptr;
+    if (!bu_device_view(h_idx, &d_idx_view)) return BU_ERR_HIP;
+    void* zout = nullptr;
+    const bool direct_out = bu_device_view(out, &zout);
+    bu_status st;
+    if (!direct_out && (st = bu_reserve(ctx, &ctx->d_out, &ctx->out_cap, p.out_bytes ? p.out_bytes : 16))) return st;
+    const size_t n_cb = h.total_selectors;
+    const size_t ep_bytes = align_up(n_cb * 4), sel_bytes = align_up(n_cb * 8), status_bytes = align_up(8 * n_img),
+                 desc_bytes = align_up(descs.size() * sizeof(BuEtc1sSlice));
+    if ((st = bu_reserve(ctx, &ctx->d_aux, &ctx->aux_cap, ep_bytes + sel_bytes + status_bytes + desc_bytes + 256))) return st;
+    uint8_t* const aux = static_cast<uint8_t*>(ctx->d_aux);
+    uint8_t* const d_out = direct_out ? static_cast<uint8_t*>(zout) : static_cast<uint8_t*>(ctx->d_out);
+    uint64_t* const d_status = reinterpret_cast<uint64_t*>(aux + ep_bytes + sel_bytes);
+    const BuEtc1sSlice* const d_descs = reinterpret_cast<const BuEtc1sSlice*>(aux + ep_bytes + sel_bytes + status_bytes);
+    BU_HIP(ctx, hipMemsetAsync(d_status, 0xFF, 8 * n_img, ctx->stream));
+    BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes + sel_bytes + status_bytes, descs.data(), descs.size() * sizeof(BuEtc1sSlice), hipMemcpyHostToDevice, ctx->stream));
+    lap("reserve");
+
+    // ---- the jobs: [payload CRC] [codebooks] [slice 0] [slice 1] ... pulled from one counter by the pool threads ----
+    struct Job {
+        size_t nbx = 0, nby = 0;
+        const uint8_t* data = nullptr;
+        size_t len = 0;
+        uint32_t* idx = nullptr;
+        std::atomic<uint32_t> rows{0};
+        std::atomic<int> done{0};
+        bu_status st = BU_OK;
+    };
+    const size_t per_img = p.alpha_pairs ? 2 : 1;
+    std::vector<Job> jobs(n_img * per_img);
+    for (size_t k = 0; k < n_img; k++)
+        for (size_t a = 0; a < per_img; a++) {
+            const bu_slice_desc& s = p.slices[p.first_slice[k] + a];
+            Job& j = jobs[k * per_img + a];
+            j.nbx = s.num_blocks_x;
+            j.nby = s.num_blocks_y;
+            j.data = file + s.file_ofs;
+            j.len = s.file_size;
+            j.idx = h_idx + (a ? ain_off[k] : in_off[k]);
+        }
+    std::atomic<bool> abort{false}, feeder_taken{false};
+    std::atomic<int> cb_done{0};
+    bu_status st_cb = BU_OK, st_feed = BU_OK;
+    bool crc_ok = true;
+    // Who does what: the CALLING thread decodes slice 0 itself, at once -- the symbol stream of the (first) slice is the critical
+    // path, and a parked pool thread takes tens of microseconds to wake up.  The first pool thread to arrive becomes the feeder
+    // (it launches bands of finished units on the context stream until everything is launched); the others pull the remaining
+    // jobs -- codebooks, payload CRC, slices 1.. -- from one counter, and so does the calling thread once slice 0 is done.  If no
+    // pool thread ever takes the feeder role the calling thread runs it last, when everything is decoded.
+    const uint32_t n_cb0 = (uint32_t)n_cb;
+    auto launch = [&](uint32_t u0, uint32_t u1) -> bu_status {
+        const unsigned grid = bu_grid_for((size_t)(u1 - u0) * 64, ctx->cu_count);
+        if (target == BU_READ_RGBA)
+            hipLaunchKernelGGL(bu_etc1s_file_kernel<true>, dim3(grid), dim3(BU_WG), 0, ctx->stream, static_cast<const uint32_t*>(d_idx_view), d_descs,
+                               (uint32_t)(descs.size() - 1), u0, u1, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                               reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+        else
+            hipLaunchKernelGGL(bu_etc1s_file_kernel<false>, dim3(grid), dim3(BU_WG), 0, ctx->stream, static_cast<const uint32_t*>(d_idx_view), d_descs,
+                               (uint32_t)(descs.size() - 1), u0, u1, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                               reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
+        BU_HIP(ctx, hipGetLastError());
+        return BU_OK;
+    };
+    auto feeder = [&]() -> bu_status {
+        BU_HIP(ctx, hipSetDevice(ctx->device));  // (a pool thread has no current device yet)
+        for (unsigned spin = 0; !cb_done.load(std::memory_order_acquire); spin++) {
+            if (abort.load(std::memory_order_relaxed)) return BU_OK;
+            if (spin > 64) std::this_thread::yield();
+        }
+        if (st_cb != BU_OK || st_tables != BU_OK) return BU_OK;  // (reported by the caller, in the reference's order)
+        if (!lz.endpoints.empty()) BU_HIP(ctx, hipMemcpyAsync(aux, lz.endpoints.data(), lz.endpoints.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!lz.selectors.empty()) BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes, lz.selectors.data(), lz.selectors.size(), hipMemcpyHostToDevice, ctx->stream));
+        std::vector<uint32_t> launched(n_img, 0);  // units of image k already handed to the GPU
+        for (unsigned spin = 0;; spin++) {
+            bool all = true, progressed = false;
+            for (size_t k = 0; k < n_img; k++) {
+                if (units_of[k] == 0 || launched[k] == units_of[k]) continue;
+                // finished units of image k: whole 64-block units inside the rows BOTH of its slices have finished
+                uint32_t avail = units_of[k];
+                bool finished = true;
+                for (size_t a2 = 0; a2 < per_img; a2++) {
+                    Job& j = jobs[k * per_img + a2];
+                    if (j.done.load(std::memory_order_acquire)) continue;
+                    finished = false;
+                    const size_t blocks = (size_t)j.rows.load(std::memory_order_acquire) * j.nbx;
+                    avail = std::min<uint32_t>(avail, (uint32_t)(blocks / 64));
+                }
+                if (avail > launched[k] && (finished || (size_t)(avail - launched[k]) * 64 >= BU_ETC1S_BAND_BLOCKS)) {
+                    const bu_status ls = launch(unit0[k] + launched[k], unit0[k] + avail);
+                    if (ls) return ls;
+                    launched[k] = avail;
+                    progressed = true;
+                }
+                if (launched[k] != units_of[k]) all = false;
+            }
+            if (all || abort.load(std::memory_order_relaxed)) return BU_OK;
+            if (!progressed && spin > 16) std::this_thread::yield();
+        }
+    };
+    auto run_slice = [&](Job& j) {
+        if (st_tables == BU_OK && !abort.load(std::memory_order_relaxed))
+            j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx, &j.rows, &abort);
+        else
+            j.st = BU_ERR_ARGUMENT;  // never reported: an earlier error decides
+        if (j.st) abort.store(true, std::memory_order_relaxed);  // a failing slice fails the call: the others may stop
+        j.done.store(1, std::memory_order_release);
+    };
+    std::atomic<size_t> next{0};
+    const std::thread::id caller = std::this_thread::get_id();
+    const std::function<void()> work = [&] {
+        if (std::this_thread::get_id() != caller && !feeder_taken.exchange(true)) {
+            const bu_status fs = feeder();
+            if (fs) {
+                st_feed = fs;
+                abort.store(true, std::memory_order_relaxed);
+            }
+            return;
+        }
+        for (size_t k; (k = next.fetch_add(1)) < jobs.size() + 1;) {
+            if (k == 0) {  // codebooks: the first kernel launch waits for them
+                st_cb = lz.init_codebooks(file + h.endpoint_cb_file_ofs, h.endpoint_cb_file_size, file + h.selector_cb_file_ofs, h.selector_cb_file_size);
+                if (st_cb) abort.store(true, std::memory_order_relaxed);
+                cb_done.store(1, std::memory_order_release);
+            } else if (k == 1) {
+                if (crc_pending) crc_ok = bu_host::crc16(file + 77, len - 77, 0) == crc_want;
+            } else {
+                run_slice(jobs[k - 1]);  // (job 0 is the calling thread's)
+            }
+        }
+    };
+    const unsigned helpers = bu_host::pool().begin((unsigned)std::min<size_t>(jobs.size() + 2, bu_host::Pool::capacity()), work);
+    (void)helpers;
+    struct PoolEnd {  // the pool is released on every path out of this function, after the jobs have seen the abort flag
+        std::atomic<bool>& abort;
+        bool armed = true;
+        ~PoolEnd()
+        {
+            if (armed) {
+                abort.store(true);
+                bu_host::pool().end();
+            }
+        }
+    } pool_end{abort};
+    if (!jobs.empty()) run_slice(jobs[0]);
+    lap("slice 0 decoded");
+    work();  // whatever is still in the queue
+    if (!feeder_taken.exchange(true)) {  // nobody fed the GPU meanwhile: everything is decoded, launch it now
+        st_feed = feeder();
+    }
+    pool_end.armed = false;
+    bu_host::pool().end();  // every job has finished, the feeder has launched everything (or seen the abort flag)
+    lap("pool joined, bands launched");
+    if (crc_pending && !crc_ok) return BU_ERR_DATA_CRC;
+    if (st_cb) return st_cb;
+    if (st_tables) return st_tables;
+    for (const Job& j : jobs)
+        if (j.st) return j.st;
+    if (st_feed) return st_feed;
+    BU_HIP(ctx, hipMemcpyAsync(status_words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
+    if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain.armed = false;
+    lap("last band + synchronise");
+    for (size_t k = 0; k < n_img; k++) {
+        st = bu_status_word_decode(status_words[k], nullptr);
+        if (st) return st;
+    }
+    return BU_OK;
+}
+
 static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out, bu_image* images,
                                 size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes)
 {
@@ -92,6 +348,11 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
     {
         bu_basis_header h0;
         if (file && len >= ((size_t)1 << 20) && bu_host::read_header(file, len, &h0) == BU_OK && h0.tex_format == 1 && target != BU_READ_UASTC) {
+            crc_deferred = true;
+            crc_want = h0.data_crc16;
+        }
+        // ETC1S files of some size: the payload CRC runs on a pool thread beside the entropy decode (bu_read_etc1s_streamed)
+        if (file && len >= ((size_t)64 << 10) && !getenv("BU_ETC1S_ONE_LAUNCH") && bu_host::read_header(file, len, &h0) == BU_OK && h0.tex_format == 0) {
             crc_deferred = true;
             crc_want = h0.data_crc16;
         }
@@ -125,6 +386,15 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
     // Batched front door: every slice's input is staged at an aligned offset of one device buffer, the device output
     // buffer mirrors `out`, all launches go to the context stream back to back (one status word per image) and a
     // single synchronisation ends the call.  The host-side BasisLZ decode of all slices happens before any upload.
+    if (p.etc1s && !getenv("BU_ETC1S_ONE_LAUNCH")) {
+        size_t total_blocks = 0;
+        for (size_t k = 0; k < p.images.size(); k++) total_blocks += (size_t)p.slices[p.first_slice[k]].num_blocks_x * p.slices[p.first_slice[k]].num_blocks_y;
+        if (total_blocks >= BU_ETC1S_STREAM_MIN_BLOCKS) {
+            const bool pending = crc_deferred;
+            crc_deferred = false;  // settled inside (on a pool thread); nothing is left for settle()
+            return bu_read_etc1s_streamed(ctx, target, file, len, p, out, pending, crc_want, trace);
+        }
+    }
     bu_host::BasisLz lz;
     const size_t n_img = p.images.size();
     std::vector<size_t> in_off(n_img, 0), ain_off(n_img, 0), run_of(n_img, 0);  // run_of[k]: first image of k's run
@@ -254,11 +524,11 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
             const BuEtc1sSlice* d_descs = reinterpret_cast<const BuEtc1sSlice*>(aux + ep_bytes + sel_bytes + status_bytes);
             if (target == BU_READ_RGBA)
                 hipLaunchKernelGGL(bu_etc1s_file_kernel<true>, dim3(grid), dim3(BU_WG), 0, ctx->stream, reinterpret_cast<const uint32_t*>(d_in), d_descs,
-                                   (uint32_t)(descs.size() - 1), n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                                   (uint32_t)(descs.size() - 1), 0u, n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
                                    reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
             else
                 hipLaunchKernelGGL(bu_etc1s_file_kernel<false>, dim3(grid), dim3(BU_WG), 0, ctx->stream, reinterpret_cast<const uint32_t*>(d_in), d_descs,
-                                   (uint32_t)(descs.size() - 1), n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
+                                   (uint32_t)(descs.size() - 1), 0u, n_units, reinterpret_cast<const uint32_t*>(aux), n_cb0,
                                    reinterpret_cast<const uint2*>(aux + ep_bytes), n_cb0, d_out, reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
             BU_HIP(ctx, hipGetLastError());
         }

@@ -137,6 +137,34 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
     return BU_OK;
 }
 
+// The reference's own micro-benchmark shape (benches/benchmark.rs:66-98: 32 blocks x 1000 calls per target): `reps` passes over
+// `n_blocks` blocks, ONE per-block API call per block, timed with the host's steady clock around the whole loop.  target
+// RGBA32 times bu_unpack_uastc_block_to_rgba.  The last pass's results stay in `out` (n_blocks x block bytes); a failing
+// block's status is returned.
+bu_status bu_time_block_api(bu_context* ctx, bu_target target, const uint8_t* blocks, size_t n_blocks, int reps, uint8_t* out, float* out_ns_per_call)
+{
+    if (!ctx || !blocks || !out || n_blocks == 0 || reps <= 0 || !out_ns_per_call) return BU_ERR_ARGUMENT;
+    const size_t bb = bu_target_block_bytes(target);
+    if (bb == 0) return BU_ERR_ARGUMENT;
+    bu_status st = BU_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps && st == BU_OK; r++)
+        for (size_t i = 0; i < n_blocks && st == BU_OK; i++) {
+            const uint8_t* in = blocks + 16 * i;
+            uint8_t* o = out + bb * i;
+            switch (target) {
+            case BU_TARGET_ASTC: st = bu_transcode_uastc_block_to_astc(ctx, in, o); break;
+            case BU_TARGET_BC7: st = bu_transcode_uastc_block_to_bc7(ctx, in, o); break;
+            case BU_TARGET_ETC1: st = bu_transcode_uastc_block_to_etc1(ctx, in, o); break;
+            case BU_TARGET_ETC2: st = bu_transcode_uastc_block_to_etc2(ctx, in, o); break;
+            default: st = bu_unpack_uastc_block_to_rgba(ctx, in, reinterpret_cast<uint32_t*>(o)); break;
+            }
+        }
+    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+    *out_ns_per_call = (float)(ns / ((double)reps * (double)n_blocks));
+    return st;
+}
+
 bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers, size_t first_buffer,
                                 size_t n_blocks, int launches, void* stream, float* out_ms)
 {

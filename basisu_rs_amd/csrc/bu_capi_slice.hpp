@@ -102,6 +102,7 @@ void bu_context_destroy(bu_context* ctx)
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+    if (ctx->h_idx) (void)hipHostFree(ctx->h_idx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -266,26 +267,32 @@ bu_status bu_uastc_decode_to_rgba(bu_context* ctx, const uint8_t* in, size_t in_
     return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, in_bytes, blocks_per_row, out, out_bytes, first_bad_block);
 }
 
-bu_status bu_unpack_uastc_block_to_rgba(bu_context* ctx, const uint8_t in[16], uint32_t out[16])
+// ---- per-block API (lib.rs:29-53) -----------------------------------------------------------------------------------------------
+// One 16-byte block is not worth a kernel launch (upload + 1-block launch + download: tens of microseconds; the reference's own
+// benchmark calls these 32 000 times, benches/benchmark.rs:66-98).  They run the product's OWN block code -- the mode-templated
+// front-end and packers of bu_uastc_*.hpp, which this translation unit compiles for the host as well as for gfx950 (BU_DEV) --
+// on the calling thread, against a host copy of the table blob the kernels stage in LDS.  A context is still required (the
+// library has no CPU mode: bu_context_create fails without a gfx950 device); bu_block_api_on_device(ctx, 1) routes the calls
+// through the one-lane-per-block kernel instead (what rounds 1-3 shipped; tests compare both with the reference's vectors).
+bu_status bu_block_api_on_device(bu_context* ctx, int enable)
 {
-    return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, 16, 1, reinterpret_cast<uint8_t*>(out), 64, nullptr);
+    if (!ctx) return BU_ERR_ARGUMENT;
+    ctx->block_api_on_device.store(enable != 0, std::memory_order_relaxed);
+    return BU_OK;
 }
-bu_status bu_transcode_uastc_block_to_astc(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
-{
-    return bu_uastc_host(ctx, BU_TARGET_ASTC, in, 16, 1, out, 16, nullptr);
-}
-bu_status bu_transcode_uastc_block_to_bc7(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
-{
-    return bu_uastc_host(ctx, BU_TARGET_BC7, in, 16, 1, out, 16, nullptr);
-}
-bu_status bu_transcode_uastc_block_to_etc1(bu_context* ctx, const uint8_t in[16], uint8_t out[8])
-{
-    return bu_uastc_host(ctx, BU_TARGET_ETC1, in, 16, 1, out, 8, nullptr);
-}
-bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16], uint8_t out[16])
-{
-    return bu_uastc_host(ctx, BU_TARGET_ETC2, in, 16, 1, out, 16, nullptr);
-}
+
+#define BU_BLOCK_API(TGT, target_enum, out_bytes)                                                                    \
+    if (!ctx || !in || !out) return BU_ERR_ARGUMENT;                                                                 \
+    if (ctx->block_api_on_device.load(std::memory_order_relaxed))                                                    \
+        return bu_uastc_host(ctx, target_enum, in, 16, 1, reinterpret_cast<uint8_t*>(out), out_bytes, nullptr);      \
+    return bu_block_on_host<TGT>(in, out)
+
+bu_status bu_unpack_uastc_block_to_rgba(bu_context* ctx, const uint8_t in[16], uint32_t out[16]) { BU_BLOCK_API(BU_TGT_RGBA, BU_TARGET_RGBA32, 64); }
+bu_status bu_transcode_uastc_block_to_astc(bu_context* ctx, const uint8_t in[16], uint8_t out[16]) { BU_BLOCK_API(BU_TGT_ASTC, BU_TARGET_ASTC, 16); }
+bu_status bu_transcode_uastc_block_to_bc7(bu_context* ctx, const uint8_t in[16], uint8_t out[16]) { BU_BLOCK_API(BU_TGT_BC7, BU_TARGET_BC7, 16); }
+bu_status bu_transcode_uastc_block_to_etc1(bu_context* ctx, const uint8_t in[16], uint8_t out[8]) { BU_BLOCK_API(BU_TGT_ETC1, BU_TARGET_ETC1, 8); }
+bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16], uint8_t out[16]) { BU_BLOCK_API(BU_TGT_ETC2, BU_TARGET_ETC2, 16); }
+#undef BU_BLOCK_API
 
 // ---- ETC1S ---------------------------------------------------------------------------------------
 void bu_etc1s_selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8]) { bu_host::selector_from_rows(rows, out_entry); }

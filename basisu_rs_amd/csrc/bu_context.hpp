@@ -16,9 +16,12 @@ struct bu_context {
     size_t out_cap = 0;
     void* d_aux = nullptr;  // codebooks / alpha indices of the host-pointer ETC1S calls
     size_t aux_cap = 0;
+    void* h_idx = nullptr;  // page-locked index buffer of the streamed ETC1S front door: the host decoder writes it, the kernels read it over PCIe
+    size_t h_idx_cap = 0;
     unsigned long long* d_status = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::atomic<bool> block_api_on_device{false};  // per-block API: host build of the block code (default) or a 1-block launch
     size_t etc1s_lds_attr[2] = {0, 0};  // dynamic LDS already allowed for bu_etc1s_staged_kernel<false / true>
     std::mutex lock;  // host-pointer entry points share the staging buffers
     char err[256] = {0};
@@ -270,6 +273,30 @@ bu_status bu_uastc_host(bu_context* ctx, bu_target target, const uint8_t* in, si
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain.armed = false;
     return bu_status_word_decode(word, first_bad);
+}
+
+// ---- the per-block API's host side (bu_capi_slice.hpp): the product's block code compiled for the host, over a host copy of the tables
+const BuTablesAll& bu_host_tables()
+{
+    static const BuTablesAll* const tables = [] {
+        BuTablesAll* t = new BuTablesAll();
+        bu_build_tables(t);
+        return t;
+    }();
+    return *tables;
+}
+
+template <int TARGET>
+bu_status bu_block_on_host(const uint8_t in[16], void* out)
+{
+    const BuTables& T = bu_host_tables().t;
+    BuBlk b;
+    memcpy(b.w, in, 16);
+    constexpr int NO = TARGET == BU_TGT_RGBA ? 16 : (TARGET == BU_TGT_ETC1 ? 2 : 4);
+    uint32_t o[16] = {0};  // a failing block leaves its zeros (every path checks before it writes), as the kernels' result slots do
+    const int st = bu_block_any<TARGET>(T, T.mode_lut[b.w[0] & 127u], b, o);
+    memcpy(out, o, NO * sizeof(uint32_t));
+    return st == BU_ST_OK ? BU_OK : (st == BU_ST_BAD_PATTERN ? BU_ERR_INVALID_PATTERN : BU_ERR_INVALID_MODE);
 }
 
 }  // namespace

@@ -1003,7 +1003,7 @@ static_assert(sizeof(BuEtc1sSlice) == 32, "descriptor layout is shared with the 
 
 template <bool RGBA>
 __global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __restrict__ idx, const BuEtc1sSlice* __restrict__ slices, uint32_t n_slices,
-                                                              uint32_t n_units, const uint32_t* __restrict__ endpoints, uint32_t n_ep,
+                                                              uint32_t unit_begin, uint32_t n_units, const uint32_t* __restrict__ endpoints, uint32_t n_ep,
                                                               const uint2* __restrict__ selectors, uint32_t n_sel, uint8_t* __restrict__ out,
                                                               unsigned long long* status, const BuTablesAll* __restrict__ tables)
 {
@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(BU_WG) void bu_etc1s_file_kernel(const uint32_t* __
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u, wpg = BU_WG / 64;
-    for (uint32_t unit = blockIdx.x * wpg + (threadIdx.x >> 6); unit < n_units; unit += gridDim.x * wpg) {
+    // units [unit_begin, n_units) of the file: the streamed front door launches the bands of a slice as their rows are decoded
+    for (uint32_t unit = unit_begin + blockIdx.x * wpg + (threadIdx.x >> 6); unit < n_units; unit += gridDim.x * wpg) {
         // largest s with slices[s].unit0 <= unit (unit is wave-uniform: the search runs on the scalar unit)
         uint32_t lo = 0, hi = n_slices;
         while (hi - lo > 1) {

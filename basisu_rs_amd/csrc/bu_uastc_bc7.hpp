@@ -71,7 +71,7 @@ BU_DEV uint32_t bu_sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
 // v_bfe_u32 / v_bfe_i32 with a run-time offset (offset and width use their low five bits)
 BU_DEV uint32_t bu_ubfe(uint32_t v, uint32_t ofs, uint32_t n)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     return __builtin_amdgcn_ubfe(v, ofs, n);
 #else
     return (v >> (ofs & 31u)) & ((1u << n) - 1u);
@@ -80,7 +80,7 @@ BU_DEV uint32_t bu_ubfe(uint32_t v, uint32_t ofs, uint32_t n)
 // all-ones if bit `ofs` of v is set
 BU_DEV uint32_t bu_sbfe1(uint32_t v, uint32_t ofs)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     return (uint32_t)__builtin_amdgcn_sbfe((int)v, ofs, 1u);
 #else
     return 0u - ((v >> (ofs & 31u)) & 1u);

@@ -15,7 +15,7 @@ BU_DEV uint32_t bu_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // a * b + c with a, b < 2^24 (v_mad_u32_u24)
 BU_DEV uint32_t bu_mad24(uint32_t a, uint32_t b, uint32_t c)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     return __umul24(a, b) + c;
 #else
     return a * b + c;

@@ -13,10 +13,16 @@
 #pragma once
 #include "bu_tables_dev.hpp"
 
+// Under hipcc the per-block code is host + device: the device pass (BU_GCN) maps the helpers below to gfx950 instructions, the host
+// pass compiles their portable forms -- that is the code the per-block API of the C ABI runs on the CPU (bu_capi_slice.hpp:
+// one 16-byte block is not worth a kernel launch, lib.rs:29-53).
 #if defined(__HIPCC__)
-#define BU_DEV __device__ __forceinline__
-#define BU_DEVM __device__ __forceinline__  // member functions
+#define BU_DEV __host__ __device__ __forceinline__
+#define BU_DEVM __host__ __device__ __forceinline__  // member functions
 #define BU_UNROLL _Pragma("unroll")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BU_GCN 1
+#endif
 #else
 #define BU_DEV static inline __attribute__((always_inline))
 #define BU_DEVM inline __attribute__((always_inline))
@@ -252,7 +258,7 @@ BU_DEV uint32_t bu_wfield(const uint32_t W[3], int k)
 //   lo16*(256-4w) + hi16*4w + 128      (v_dot2_u32_u16, max 65535*256+128 < 2^32)
 BU_DEV uint32_t bu_udot2(uint32_t a, uint32_t b, uint32_t c)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     typedef unsigned short bu_us2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_udot2(__builtin_bit_cast(bu_us2, a), __builtin_bit_cast(bu_us2, b), c, false);
 #else
@@ -262,7 +268,7 @@ BU_DEV uint32_t bu_udot2(uint32_t a, uint32_t b, uint32_t c)
 // 4 x u8 dot product + accumulator (v_dot4_u32_u8)
 BU_DEV uint32_t bu_udot4(uint32_t a, uint32_t b, uint32_t c)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     return __builtin_amdgcn_udot4(a, b, c, false);
 #else
     uint32_t r = c;
@@ -274,7 +280,7 @@ BU_DEV uint32_t bu_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // ({hi, lo} >> sh) & 0xFFFFFFFF for 0 < sh < 32 (v_alignbit_b32)
 BU_DEV uint32_t bu_alignbit(uint32_t hi, uint32_t lo, int sh)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
 #else
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
@@ -283,7 +289,7 @@ BU_DEV uint32_t bu_alignbit(uint32_t hi, uint32_t lo, int sh)
 // bytes of a:b selected into one word (v_perm_b32): sel byte k picks byte (sel>>8k)&7 of {b (0-3), a (4-7)}, 0x0C = zero, 0x0D.. = 0xFF
 BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     return __builtin_amdgcn_perm(a, b, sel);
 #else
     const uint64_t v = ((uint64_t)a << 32) | b;
@@ -300,7 +306,7 @@ BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 // two i32 -> two i16 with signed saturation, the first in the low half (v_cvt_pk_i16_i32)
 BU_DEV uint32_t bu_cvt_pk_i16(int32_t lo, int32_t hi)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     typedef short bu_s2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi));
 #else
@@ -311,7 +317,7 @@ BU_DEV uint32_t bu_cvt_pk_i16(int32_t lo, int32_t hi)
 // i16 lanes, a + b with signed saturation (v_pk_add_i16 ... clamp)
 BU_DEV uint32_t bu_pk_add_i16_sat(uint32_t a, uint32_t b)
 {
-#if defined(__HIPCC__)
+#if defined(BU_GCN)
     typedef short bu_s2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(bu_s2, a), __builtin_bit_cast(bu_s2, b)));
 #else

@@ -90,8 +90,14 @@ bu_status bu_uastc_transcode(bu_context* ctx, bu_target target, const uint8_t* i
 bu_status bu_uastc_decode_to_rgba(bu_context* ctx, const uint8_t* in, size_t in_bytes, size_t blocks_per_row,
                                   uint8_t* out, size_t out_bytes, uint64_t* first_bad_block);
 
-/* ---- per-block API of lib.rs:29-53 (each call is one 1-block launch; present for drop-in
- *      completeness and the known-answer tests, not for throughput) -------------------------- */
+/* ---- per-block API of lib.rs:29-53 -------------------------------------------------------------
+ * One 16-byte block per call, the way the reference's callers and its benchmark use them (benches/benchmark.rs:66-98:
+ * 32 blocks x 1000 calls).  By default a call runs on the calling thread: the library compiles its own per-block
+ * code (the mode-templated front-end and packers the gfx950 kernels are built from) for the host as well, and a block is
+ * not worth an upload + launch + download (well under 1 us against tens of us).  A context is still required -- the
+ * library has no CPU mode -- and is only read.  bu_block_api_on_device(ctx, 1) sends these calls through a one-block
+ * kernel launch instead (same results; kept so that the device path of a single block stays testable), 0 switches back. */
+bu_status bu_block_api_on_device(bu_context* ctx, int enable);
 bu_status bu_unpack_uastc_block_to_rgba(bu_context* ctx, const uint8_t in[16], uint32_t out[16]); /* lib.rs:29 */
 bu_status bu_transcode_uastc_block_to_astc(bu_context* ctx, const uint8_t in[16], uint8_t out[16]); /* lib.rs:33 */
 bu_status bu_transcode_uastc_block_to_bc7(bu_context* ctx, const uint8_t in[16], uint8_t out[16]);  /* lib.rs:39 */
@@ -332,6 +338,10 @@ bu_status bu_time_uastc_launches_each(bu_context* ctx, bu_target target, const v
 bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                          size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches, int n_streams,
                                          float* out_ms);
+/* The reference's micro-benchmark shape (benches/benchmark.rs:66-98): `reps` passes over `n_blocks` blocks, one per-block API
+ * call per block (RGBA32: bu_unpack_uastc_block_to_rgba), host steady clock around the loop; nanoseconds per call. */
+bu_status bu_time_block_api(bu_context* ctx, bu_target target, const uint8_t* blocks, size_t n_blocks, int reps, uint8_t* out,
+                            float* out_ns_per_call);
 bu_status bu_time_copy_launches(bu_context* ctx, const void* const* d_in, void* const* d_out, size_t n_buffers,
                                 size_t first_buffer, size_t n_blocks, int launches, void* stream, float* out_ms);
 

@@ -100,7 +100,8 @@ extern "C" {
                               first_bad_block: *mut u64) -> c_int;
     pub fn bu_uastc_decode_to_rgba(ctx: *mut bu_context, input: *const u8, in_bytes: usize, blocks_per_row: usize, out: *mut u8,
                                    out_bytes: usize, first_bad_block: *mut u64) -> c_int;
-    // per-block API (lib.rs:29-53)
+    // per-block API (lib.rs:29-53): on the calling thread by default, through a one-block launch after bu_block_api_on_device(ctx, 1)
+    pub fn bu_block_api_on_device(ctx: *mut bu_context, enable: c_int) -> c_int;
     pub fn bu_unpack_uastc_block_to_rgba(ctx: *mut bu_context, input: *const u8, out: *mut u32) -> c_int;
     pub fn bu_transcode_uastc_block_to_astc(ctx: *mut bu_context, input: *const u8, out: *mut u8) -> c_int;
     pub fn bu_transcode_uastc_block_to_bc7(ctx: *mut bu_context, input: *const u8, out: *mut u8) -> c_int;

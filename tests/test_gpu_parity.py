@@ -29,11 +29,64 @@ def test_per_block_api_reproduces_reference_vectors(ctx, golden):
 
     fns = {"astc": bu.transcode_uastc_block_to_astc, "bc7": bu.transcode_uastc_block_to_bc7,
            "etc1": bu.transcode_uastc_block_to_etc1, "etc2": bu.transcode_uastc_block_to_etc2}
-    for i in range(0, 608, 7):  # every mode, 1-block launches are slow: sample
+
+    def check(i):
         u = golden["uastc"][i]
         for t, f in fns.items():
             assert (f(u, ctx) == golden[t][i]).all(), (t, i)
         assert (bu.unpack_uastc_block_to_rgba(u, ctx).view(np.uint8) == golden["rgba"][i]).all()
+
+    # default: the library's own block code on the calling thread -- all 608 x 5 vectors (tests/transcode_uastc_block.rs:35-78)
+    for i in range(608):
+        check(i)
+    # the same entry points through the one-block launch (every mode, sampled: a launch per call is slow)
+    ctx.block_api_on_device(True)
+    try:
+        for i in range(0, 608, 7):
+            check(i)
+    finally:
+        ctx.block_api_on_device(False)
+
+
+def test_per_block_api_errors_and_host_device_agreement(ctx, golden):
+    """Error contract of lib.rs:26-53 on both routes of the per-block API (invalid mode code 69, pattern index out of range:
+    uastc.rs:336,364), and host route == device route == oracle on random valid and raw random blocks."""
+    import basisu_rs_amd as bu
+    from basisu_rs_amd import BasisuError as BasisError, synth
+
+    bad_mode = np.zeros(16, dtype=np.uint8)
+    bad_mode[0] = 69
+    bad_pat = golden["uastc"][2 * 32].copy()  # a mode-2 vector: the 5-bit pattern field sits right behind the 5-bit mode code + 15 flag bits
+    bits = int.from_bytes(bad_pat.tobytes(), "little")
+    bits = (bits & ~(31 << 20)) | (31 << 20)  # pattern 31 >= 30 patterns
+    bad_pat = np.frombuffer(bits.to_bytes(16, "little"), dtype=np.uint8)
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, (300, 16), dtype=np.uint8)
+    valid = synth.atlas_rand(300, seed=5)
+    for on_device in (False, True):
+        ctx.block_api_on_device(on_device)
+        try:
+            for blk, want in ((bad_mode, 1), (bad_pat, 2)):  # BU_ERR_INVALID_MODE, BU_ERR_INVALID_PATTERN
+                for f in (bu.transcode_uastc_block_to_astc, bu.transcode_uastc_block_to_bc7, bu.transcode_uastc_block_to_etc1,
+                          bu.transcode_uastc_block_to_etc2, bu.unpack_uastc_block_to_rgba):
+                    with pytest.raises(BasisError) as e:
+                        f(blk, ctx)
+                    assert e.value.status == want
+        finally:
+            ctx.block_api_on_device(False)
+    # host route against the slice path (the kernels) on the same blocks, statuses included
+    for blocks in (valid, raw):
+        for t, f in (("astc", bu.transcode_uastc_block_to_astc), ("bc7", bu.transcode_uastc_block_to_bc7),
+                     ("etc1", bu.transcode_uastc_block_to_etc1), ("etc2", bu.transcode_uastc_block_to_etc2)):
+            for u in blocks[:120]:
+                try:
+                    one = f(u, ctx)
+                except BasisError as e1:
+                    with pytest.raises(BasisError) as e2:
+                        ctx.transcode(FMT[t], u.reshape(1, 16))
+                    assert e2.value.status == e1.status
+                    continue
+                assert (ctx.transcode(FMT[t], u.reshape(1, 16)).reshape(-1) == one).all(), t
 
 
 @pytest.mark.parametrize("target", ALL)

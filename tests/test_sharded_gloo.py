@@ -185,15 +185,17 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
 
 
 def test_bench_live_traffic_falls_back_without_a_gpu():
-    """bench.py measures roofline.traffic with two child rocprofv3 counter passes; where they cannot run (no GPU here, no
-    rocprofv3, a run that is itself profiled) it must return a reason, not raise -- the committed passes are quoted then."""
+    """bench.py measures roofline.traffic with child rocprofv3 passes (a kernel trace, then two counter passes); where they cannot
+    run (no GPU here, no rocprofv3, a run that is itself profiled) it must return a reason, not raise -- the committed passes are
+    quoted then.  Third element: what the trace pass saw (None, or a dict that may only carry an error here)."""
     sys.path.insert(0, ROOT)
     import bench
 
     got = bench.live_traffic(timeout_s=120)
-    assert got[0] is None and isinstance(got[1], str) and got[1]
+    assert len(got) == 3 and got[0] is None and isinstance(got[1], str) and got[1]
+    assert got[2] is None or "kernel_avg_ns" not in got[2]
     os.environ["ROCPROF_TEST_MARKER"] = "1"  # a profiled run never starts a nested profiler
     try:
-        assert bench.live_traffic() in ((None, "this run is itself being profiled"), (None, "rocprofv3 not on PATH"))
+        assert bench.live_traffic() in ((None, "this run is itself being profiled", None), (None, "rocprofv3 not on PATH", None))
     finally:
         del os.environ["ROCPROF_TEST_MARKER"]
