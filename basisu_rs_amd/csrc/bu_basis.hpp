@@ -105,7 +105,9 @@ public:
             running = helpers;
             epoch++;
         }
-        cv.notify_all();
+        // one wake-up per helper wanted: a pool that once ran 32 copies has 32 parked threads, and waking them all for a 3-thread
+        // job queues 29 of them on the mutex in front of the three that have work
+        for (unsigned i = 0; i < helpers; i++) cv.notify_one();
         return helpers;
     }
     void end()

@@ -57,6 +57,21 @@ bu_status bu_context_create(int device, bu_context** out_ctx)
     if (!ctx) return BU_ERR_HIP;
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        // LDS a workgroup of this device may ask for (a partition mode or a runtime with a smaller limit than gfx950's 160 KiB simply
+        // lowers the codebook size up to which the LDS-staged ETC1S kernels are used)
+        int max_lds = 0, optin = 0;
+        if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || max_lds <= 0) {
+            (void)hipGetLastError();
+            max_lds = 64 * 1024;
+        }
+        // (the figure a kernel can opt in to with hipFuncSetAttribute, where the runtime reports one)
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > max_lds) max_lds = optin;
+        else (void)hipGetLastError();
+        const size_t margin = 8 * 1024;  // the kernels' static LDS and allocation granularity
+        const size_t lim = (size_t)max_lds > margin ? (size_t)max_lds - margin : 0;
+        ctx->etc1s_lds_limit = lim < BU_ETC1S_LDS_MAX ? lim : BU_ETC1S_LDS_MAX;
+    }
     bu_status st = BU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { st = BU_ERR_NO_DEVICE; break; }
@@ -200,8 +215,8 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
     // several runs at unrelated addresses: ONE launch per BU_MULTI_RUNS runs, the run table in the kernel arguments (kernel layout
     // MULTI).  Launching the runs one by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices
     // of 65 536 blocks: 290 us on one stream, 230-260 us on 2-8, profiles/r03_small_slices_streams_vs_one_launch.txt).
-    for (const Run& r : runs)
-        if (r.n > ((size_t)1 << 32) - 1024) return BU_ERR_ARGUMENT;  // (a tile's first block is a 32-bit index inside its run)
+    // (a run too long for the table's 32-bit fields -- 2^32 blocks or more -- never enters it: it goes out as the plain launch
+    // below, which cuts it into pieces of 2^26 blocks, exactly as it would on its own)
     BU_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long* stw = reinterpret_cast<unsigned long long*>(d_status);
     for (size_t r0 = 0; r0 < runs.size();) {
@@ -297,15 +312,30 @@ bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16]
 // ---- ETC1S ---------------------------------------------------------------------------------------
 void bu_etc1s_selector_from_rows(const uint8_t rows[4], uint8_t out_entry[8]) { bu_host::selector_from_rows(rows, out_entry); }
 
-// dynamic LDS above 64 KiB has to be allowed per kernel, once (hipFuncSetAttribute); remembered in the context
-static bu_status bu_etc1s_lds_attr(bu_context* ctx, bool rgba, size_t lds)
+// Dynamic LDS above 64 KiB has to be allowed per kernel, once (hipFuncSetAttribute).  May the LDS-staged kernel be used for `lds`
+// bytes of codebooks on this context's device?  The first question per kernel asks the runtime for the most the kernels were
+// measured with (BU_ETC1S_LDS_MAX); a device, partition mode or runtime that refuses is asked again for what the device itself
+// reports (bu_context_create: etc1s_lds_limit); if that fails too the L2-gather kernels serve every size.  The granted size is
+// remembered per kernel in an atomic (the device entry points may be called from several threads; asking twice is harmless):
+// 0 = not asked yet, 1 = refused, otherwise the bytes allowed.
+static bool bu_etc1s_staged_ok(bu_context* ctx, bool rgba, size_t lds)
 {
-    size_t& have = ctx->etc1s_lds_attr[rgba ? 1 : 0];
-    if (lds <= have) return BU_OK;
-    const void* fn = rgba ? reinterpret_cast<const void*>(&bu_etc1s_staged_kernel<true>) : reinterpret_cast<const void*>(&bu_etc1s_staged_kernel<false>);
-    BU_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BU_ETC1S_LDS_MAX));
-    have = BU_ETC1S_LDS_MAX;
-    return BU_OK;
+    std::atomic<size_t>& state = ctx->etc1s_lds_state[rgba ? 1 : 0];
+    size_t s = state.load(std::memory_order_acquire);
+    if (s == 0) {
+        const void* fn = rgba ? reinterpret_cast<const void*>(&bu_etc1s_staged_kernel<true>) : reinterpret_cast<const void*>(&bu_etc1s_staged_kernel<false>);
+        s = 1;
+        for (const size_t want : {(size_t)BU_ETC1S_LDS_MAX, ctx->etc1s_lds_limit}) {
+            if (want < 4096 || want > BU_ETC1S_LDS_MAX) continue;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) {
+                s = want;
+                break;
+            }
+            (void)hipGetLastError();  // (not sticky)
+        }
+        state.store(s, std::memory_order_release);
+    }
+    return s > 1 && lds <= s;
 }
 
 bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx, size_t n_blocks, const uint32_t* d_endpoints,
@@ -315,12 +345,10 @@ bu_status bu_etc1s_transcode_etc1_device(bu_context* ctx, const uint32_t* d_idx,
     if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
     if (n_blocks == 0) return BU_OK;
     const size_t lds = ((size_t)n_endpoints + n_selectors) * 4;
-    if (n_blocks >= BU_ETC1S_STAGED_MIN && lds <= BU_ETC1S_LDS_MAX) {
+    if (n_blocks >= BU_ETC1S_STAGED_MIN && bu_etc1s_staged_ok(ctx, false, lds)) {
         // codebooks in LDS, one persistent workgroup per CU (with four blocks per lane and step in flight a second workgroup only
         // doubles the staging: 2^21 blocks 8.0 against 9.3 us, 2^22 12.95 / 13.2, 2^24 37.4 / 39.3)
         const unsigned per_cu = 1u;
-        bu_status st = bu_etc1s_lds_attr(ctx, false, lds);
-        if (st) return st;
         hipLaunchKernelGGL(bu_etc1s_staged_kernel<false>, dim3((unsigned)ctx->cu_count * per_cu), dim3(1024), lds, static_cast<hipStream_t>(stream), d_idx,
                            nullptr, 1u, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
                            static_cast<uint8_t*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);
@@ -342,9 +370,7 @@ bu_status bu_etc1s_decode_rgba_device(bu_context* ctx, const uint32_t* d_idx, co
     if (!ctx || (n_blocks && (!d_idx || !d_endpoints || !d_selectors || !d_out))) return BU_ERR_ARGUMENT;
     if (n_blocks == 0) return BU_OK;
     const size_t lds = ((size_t)n_endpoints + n_selectors + 256) * 4;
-    if (n_blocks >= BU_ETC1S_STAGED_MIN && lds <= BU_ETC1S_LDS_MAX) {
-        bu_status st = bu_etc1s_lds_attr(ctx, true, lds);
-        if (st) return st;
+    if (n_blocks >= BU_ETC1S_STAGED_MIN && bu_etc1s_staged_ok(ctx, true, lds)) {
         hipLaunchKernelGGL(bu_etc1s_staged_kernel<true>, dim3((unsigned)ctx->cu_count), dim3(1024), lds, static_cast<hipStream_t>(stream), d_idx, d_alpha_idx,
                            (unsigned)nbx, n_blocks, d_endpoints, n_endpoints, static_cast<const uint2*>(d_selectors), n_selectors,
                            static_cast<uint8_t*>(d_out), reinterpret_cast<unsigned long long*>(d_status), ctx->d_tables);

@@ -22,7 +22,8 @@ struct bu_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::atomic<bool> block_api_on_device{false};  // per-block API: host build of the block code (default) or a 1-block launch
-    size_t etc1s_lds_attr[2] = {0, 0};  // dynamic LDS already allowed for bu_etc1s_staged_kernel<false / true>
+    size_t etc1s_lds_limit = 0;  // what the device reports a workgroup may use, less a margin (bu_context_create)
+    std::atomic<size_t> etc1s_lds_state[2] = {{0}, {0}};  // bu_etc1s_staged_kernel<false / true>: 0 not asked, 1 refused, else dynamic LDS bytes granted
     std::mutex lock;  // host-pointer entry points share the staging buffers
     char err[256] = {0};
 };

@@ -247,18 +247,21 @@ bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_targ
         for (int j = 0; j < i; j++)
             if (ctxs[j] == ctxs[i]) return BU_ERR_ARGUMENT;  // one status word and one stream per context: contexts must be distinct
     }
-    // the call owns every context's status word and stream until it returns: locks taken in index order (callers that pass
-    // the same set in the same order cannot deadlock each other), released by the guard
+    // the call owns every context's status word and stream until it returns.  The locks are taken in ONE canonical order -- by
+    // context address, whatever order the caller listed the contexts in -- so two threads that pass overlapping sets in different
+    // orders cannot deadlock each other (A-then-B against B-then-A); released by the guard
     struct Locks {
-        bu_context* const* c;
-        int n = 0;
+        std::vector<bu_context*> c;
+        size_t n = 0;
         ~Locks()
         {
-            for (int i = n - 1; i >= 0; i--) c[i]->lock.unlock();
+            for (size_t i = n; i-- > 0;) c[i]->lock.unlock();
         }
-    } locks{ctxs};
-    for (int i = 0; i < n_ctx; i++) {
-        ctxs[i]->lock.lock();
+    } locks;
+    locks.c.assign(ctxs, ctxs + n_ctx);
+    std::sort(locks.c.begin(), locks.c.end(), [](const bu_context* a, const bu_context* b) { return std::less<const bu_context*>()(a, b); });
+    for (size_t i = 0; i < locks.c.size(); i++) {
+        locks.c[i]->lock.lock();
         locks.n = i + 1;
     }
     // an early error return must not leave kernels or copies in flight on any of the contexts

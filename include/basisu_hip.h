@@ -294,7 +294,9 @@ bu_status bu_allgather_peer(bu_context* ctx, void* d_full, void* const* d_peer_f
  * virtual ranks).  d_in_shard[i]: device i's slice range only, resident on device i; d_full[i]: n_slices *
  * blocks_per_slice * block_bytes bytes on device i.  Transcodes every range in place, then (gather != 0) every device
  * pulls the other ranges from its peers.  Block-linear targets only.  Synchronous; on a block error returns the
- * status and index (array-wide) of the LOWEST failing block, like the sequential loop over slices. */
+ * status and index (array-wide) of the LOWEST failing block, like the sequential loop over slices.
+ * Threading: the call locks every context it is given for its whole duration (other calls on those contexts wait), in one
+ * canonical order whatever the order of `ctxs`, so concurrent calls over overlapping context sets cannot deadlock. */
 bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_target target, const void* const* d_in_shard,
                                      size_t n_slices, size_t blocks_per_slice, void* const* d_full, int gather,
                                      uint64_t* first_bad_block);

@@ -230,7 +230,7 @@ def test_staged_etc1_kernel_on_ragged_sizes_and_unaligned_arrays(ctx, oracle):
 
 def test_batch_entry_point_merges_contiguous_slices_and_fans_out_the_rest(ctx, golden):
     """bu_uastc_transcode_batch_device: a loop over independent slices in one call.  Contiguous slices (one launch), slices in
-    separate allocations (side by side on context streams), a mix with an empty slice, RGBA32 slices of one pitch -- same bytes
+    separate allocations (ONE launch per 96 runs on the caller's stream, the run table in the kernel arguments), a mix with an empty slice, RGBA32 slices of one pitch -- same bytes
     as slice-by-slice calls, block errors numbered through the whole batch (basis.rs:246-257)."""
     import torch
 
