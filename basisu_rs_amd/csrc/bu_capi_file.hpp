@@ -193,7 +193,10 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             j.len = s.file_size;
             j.idx = h_idx + (a ? ain_off[k] : in_off[k]);
         }
-    std::atomic<bool> abort{false}, feeder_taken{false};
+    // abort: nothing that is still running can matter any more (a codebook / table / device error, or this function is on its way
+    // out): decoders stop at the next row.  slice_failed: some slice failed -- the feeder stops launching, but the OTHER slices
+    // decode on: the call reports the first failing slice in file order, and an earlier slice may still fail too.
+    std::atomic<bool> abort{false}, slice_failed{false}, feeder_taken{false};
     std::atomic<int> cb_done{0};
     bu_status st_cb = BU_OK, st_feed = BU_OK;
     bool crc_ok = true;
@@ -248,7 +251,7 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
                 }
                 if (launched[k] != units_of[k]) all = false;
             }
-            if (all || abort.load(std::memory_order_relaxed)) return BU_OK;
+            if (all || abort.load(std::memory_order_relaxed) || slice_failed.load(std::memory_order_relaxed)) return BU_OK;
             if (!progressed && spin > 16) std::this_thread::yield();
         }
     };
@@ -257,7 +260,7 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx, &j.rows, &abort);
         else
             j.st = BU_ERR_ARGUMENT;  // never reported: an earlier error decides
-        if (j.st) abort.store(true, std::memory_order_relaxed);  // a failing slice fails the call: the others may stop
+        if (j.st) slice_failed.store(true, std::memory_order_relaxed);
         j.done.store(1, std::memory_order_release);
     };
     std::atomic<size_t> next{0};
@@ -308,9 +311,9 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     if (crc_pending && !crc_ok) return BU_ERR_DATA_CRC;
     if (st_cb) return st_cb;
     if (st_tables) return st_tables;
+    if (st_feed) return st_feed;  // (a device error: it stopped the decoders, whose statuses mean nothing then)
     for (const Job& j : jobs)
         if (j.st) return j.st;
-    if (st_feed) return st_feed;
     BU_HIP(ctx, hipMemcpyAsync(status_words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
     if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
