@@ -84,11 +84,23 @@ size_t bu_balanced_tile(size_t max_tile, size_t n_blocks, size_t slots, bool dyn
     return t < 64 ? 64 : (t > max_tile ? max_tile : t);
 }
 
+// experiment knob (tools/exp): BU_X_BCAP = workgroups per launch of the big shapes as a multiple of the resident set (0 = one tile
+// per workgroup, whatever the size); unset = the resident set (persistent workgroups walk their tiles with prefetch)
+inline size_t bu_x_bcap(size_t resident)
+{
+    static const long mult = [] {
+        const char* e = getenv("BU_X_BCAP");
+        return e ? atol(e) : 1L;
+    }();
+    return mult <= 0 ? (size_t)1 << 40 : resident * (size_t)mult;
+}
+
 // shapes that are also compiled with rectangular tiles (bu_uastc_sorted_kernel, RECT): the 1024-block tiles (64 x 16 blocks) of
 // BC7, ASTC and RGBA32, the 4096-block tiles (64 x 64) of ETC1 and ETC2
 constexpr bool bu_rect_compiled(int target, int tile)
 {
     if (target == BU_TGT_BC7 && tile == BuBigCfg<BU_TGT_BC7>::WGS * BuBigCfg<BU_TGT_BC7>::BPT) return true;
+    if ((target == BU_TGT_ETC1 || target == BU_TGT_ETC2) && tile == BuBigCfg<BU_TGT_ETC1>::WGS * BuBigCfg<BU_TGT_ETC1>::BPT) return true;
     return tile == 1024 ? (target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA)
                         : (tile == 4096 && (target == BU_TGT_ETC1 || target == BU_TGT_ETC2));
 }
@@ -130,7 +142,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
 #define BU_GO(T, W, B, MINW, PF, DIR, SK, GRID, CUS, TRT)                                                                                       \
     do {                                                                                                                                        \
         constexpr int tile_ = (W) * (B);                                                                                                        \
-        if (bu_rect_compiled(T, tile_) && rect_ok((size_t)tile_ / RW) && ((T) == BU_TGT_BC7 || tile_ == 1024 || (TRT) == 4096u))                \
+        if (bu_rect_compiled(T, tile_) && rect_ok((size_t)tile_ / RW) && ((T) == BU_TGT_BC7 || tile_ == 1024 || (TRT) == (unsigned)tile_))        \
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, bu_rect_compiled(T, tile_)>), dim3(GRID), dim3(W), 0, stream, pin, pout, \
                                (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, rect_magic BU_STAMP_PASS);                           \
         else                                                                                                                                    \
@@ -147,7 +159,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         using C = BuBigCfg<T>;                                                                                                          \
         const size_t tile_rt = bu_balanced_tile((size_t)C::WGS * C::BPT, nb, (size_t)ctx->cu_count * C::WG_PER_CU, C::DYN_TILE);        \
         const size_t btiles = (nb + tile_rt - 1) / tile_rt;                                                                             \
-        const size_t bcap = (size_t)ctx->cu_count * C::WG_PER_CU;                                                                       \
+        const size_t bcap = bu_x_bcap((size_t)ctx->cu_count * C::WG_PER_CU);                                                            \
         /* generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per */      \
         /* slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0) */   \
         const unsigned pcus = (btiles <= bcap || btiles % bcap == 0) ? (unsigned)ctx->cu_count : 0u;                                    \

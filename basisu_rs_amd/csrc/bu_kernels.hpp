@@ -182,8 +182,12 @@ struct BuBigCfg {
     // tile k.  Nothing changes for one tile per workgroup (2^20 blocks: 19.17 / 19.11 us); 2^25 blocks ETC1 516 -> 474 us,
     // ETC2 661 -> 613, BC7 227 -> 213 (0.63 of the HBM peak).  ASTC would cross 64 VGPRs (2^20 blocks: 9.55 -> 12.97 us).
     static constexpr bool PREFETCH = true, DIRECT = false;
-    static constexpr int WGS = 1024, BPT = 4, WG_PER_CU = 1, SKEW = 0, MINW = 1, NT = 1;
-    static constexpr bool DYN_TILE = true;    // the kernel takes the tile size at run time (bu_balanced_tile)
+#ifndef BU_XE_BPT  // experiment (round 4): ETC1 / ETC2 on smaller tiles walked by one workgroup per CU with every load up front
+#define BU_XE_BPT 4
+#define BU_XE_NT 1
+#endif
+    static constexpr int WGS = 1024, BPT = BU_XE_BPT, WG_PER_CU = 1, SKEW = 0, MINW = 1, NT = BU_XE_NT;
+    static constexpr bool DYN_TILE = BU_XE_NT == 1;    // the kernel takes the tile size at run time (bu_balanced_tile)
     static constexpr bool ALL_SIZES = false;  // up to 3 Ki blocks per CU the launcher uses 512 x 2 (1024-block tiles, all resident): bu_launch_uastc
 };
 #ifndef BU_X_WGS
