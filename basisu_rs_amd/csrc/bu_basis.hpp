@@ -50,6 +50,7 @@ class Pool {
             if (stop) return;
             seen = epoch;
             started++;
+            running++;
             const std::function<void()>* f = job;
             lk.unlock();
             (*f)();
@@ -102,21 +103,24 @@ public:
             job = &f;
             want = helpers;
             started = 0;
-            running = helpers;
+            running = 0;  // counts copies that have actually started (worker()): end() waits for those, not for wake-ups that never came
             epoch++;
+            // One wake-up per helper wanted (a pool that once ran 32 copies has 32 parked threads: waking them all for a 3-thread job
+            // queues 29 of them on the mutex in front of the three that have work) -- issued UNDER the mutex: a woken thread cannot
+            // run, finish and park again while the loop is still notifying, so every notification reaches a different parked thread.
+            // (Notified outside the lock, a copy that finished at once re-entered the wait queue and swallowed the next
+            // notification: the job then waited for a copy that was never going to start.)
+            for (unsigned i = 0; i < helpers; i++) cv.notify_one();
         }
-        // one wake-up per helper wanted: a pool that once ran 32 copies has 32 parked threads, and waking them all for a 3-thread
-        // job queues 29 of them on the mutex in front of the three that have work
-        for (unsigned i = 0; i < helpers; i++) cv.notify_one();
         return helpers;
     }
     void end()
     {
         if (active_helpers) {
             std::unique_lock<std::mutex> lk(m);
+            want = 0;  // admissions are closed: a helper that has not started by now sits this job out (the items come from a shared counter)
             cv_done.wait(lk, [&] { return running == 0; });
             job = nullptr;
-            want = 0;
         }
         active_helpers = 0;
         run_m.unlock();

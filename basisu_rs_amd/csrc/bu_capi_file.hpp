@@ -95,7 +95,7 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     const bu_basis_header& h = p.h;
     if (!in_file(len, h.endpoint_cb_file_ofs, h.endpoint_cb_file_size) || !in_file(len, h.selector_cb_file_ofs, h.selector_cb_file_size) ||
         !in_file(len, h.tables_file_ofs, h.tables_file_size) || !in_file(len, h.extended_file_ofs, h.extended_file_size))
-        return (crc_pending && bu_host::crc16(file + 77, len - 77, 0) != crc_want) ? BU_ERR_DATA_CRC : BU_ERR_BOUNDS;
+        return (crc_pending && bu_host::crc16(file + 77, len - 77, 0) != crc_want) ? BU_ERR_DATA_CRC : BU_ERR_BOUNDS;  // (pool not taken yet)
     bu_host::BasisLz lz;
     // total_selectors for both codebooks: basis.rs:289-291
     const bu_status st_tables = lz.init_tables(h.total_selectors, h.total_selectors, file + h.tables_file_ofs, h.tables_file_size, h.tex_type == 3);
@@ -280,7 +280,8 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
                 if (st_cb) abort.store(true, std::memory_order_relaxed);
                 cb_done.store(1, std::memory_order_release);
             } else if (k == 1) {
-                if (crc_pending) crc_ok = bu_host::crc16(file + 77, len - 77, 0) == crc_want;
+                // (the serial form: bu_host::crc16 cuts large inputs into pieces for the pool -- which this call is holding)
+                if (crc_pending) crc_ok = (uint16_t)~bu_host::crc16_raw(file + 77, len - 77, 0xFFFF) == crc_want;
             } else {
                 run_slice(jobs[k - 1]);  // (job 0 is the calling thread's)
             }

@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every GPU test gets a deadline (pytest-timeout, method "thread": the whole run is ended -- a test stuck inside a C call never
+    returns to the interpreter, so a signal handler would not run).  A deadlock in the library then fails the run in minutes
+    instead of holding the GPU box until the job limit."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(900, method="thread"))
+
+
 def pytest_sessionstart(session):
     """a fresh checkout has no built artefacts (they are git-ignored): build the C-ABI library once, up front"""
     from basisu_rs_amd import _lib

@@ -3,6 +3,10 @@
 // available on the pool, and this code is what faces untrusted `.basis` bytes, so it gets the sanitizer treatment.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <functional>
 
 #include <vector>
 
@@ -56,8 +60,38 @@ static int process(const uint8_t* f, size_t len, int target)
     return seq_st;
 }
 
+// The worker pool under the pattern that once deadlocked it: many parked threads (a wide job first), then thousands of narrow jobs
+// whose copies finish at once -- a copy that parked again used to swallow the wake-up meant for the next helper, and the job
+// waited for a copy that never started.  Also the split begin() / end() form with the caller doing something else meanwhile.
+static int pool_stress(int rounds)
+{
+    std::atomic<long> sum{0};
+    const std::function<void()> wide = [&] { sum.fetch_add(1); };
+    bu_host::pool().run(bu_host::Pool::capacity(), wide);
+    for (int r = 0; r < rounds; r++) {
+        std::atomic<int> next{0}, done{0};
+        const std::function<void()> narrow = [&] {
+            for (int k; (k = next.fetch_add(1)) < 5;) done.fetch_add(1);
+        };
+        if (r & 1) {
+            bu_host::pool().run(3, narrow);
+        } else {
+            bu_host::pool().begin(3, narrow);
+            narrow();
+            bu_host::pool().end();
+        }
+        if (done.load() != 5) return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 3 && !strcmp(argv[1], "--pool-stress")) {
+        const int st = pool_stress(atoi(argv[2]));
+        printf("pool stress %s\n", st ? "FAILED" : "ok");
+        return st;
+    }
     if (argc < 3) return 2;
     const int iters = atoi(argv[2]);
     FILE* fp = fopen(argv[1], "rb");

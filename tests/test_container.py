@@ -202,6 +202,10 @@ def test_concurrent_slice_decode_is_race_free(tmp_path):
     r = subprocess.run([os.path.join(he, "bu_hostlogic_tsan"), str(path), "300"], capture_output=True, text=True)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
     assert "fuzz done" in r.stdout
+    # the worker pool itself: a wide job (every thread parked afterwards), then thousands of narrow jobs whose copies finish at
+    # once, through run() and through the split begin() / end() form -- a lost wake-up hangs here (the timeout fails the test)
+    r = subprocess.run([os.path.join(he, "bu_hostlogic_tsan"), "--pool-stress", "20000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "pool stress ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
 def test_allocation_failure_inside_the_abi_is_a_status_not_a_terminate(tmp_path):

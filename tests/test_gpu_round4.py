@@ -86,7 +86,7 @@ def test_streamed_etc1s_front_door_reports_errors_in_the_reference_order(ctx, or
     assert len(seen) >= 3  # success, the CRC and at least one decoder error all occurred
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600, method="thread")
 def test_sharded_calls_over_the_same_contexts_in_opposite_orders_do_not_deadlock(golden):
     """bu_array_transcode_sharded locks every context it is given.  Two threads that list the same contexts in opposite orders
     used to be an A-then-B against B-then-A deadlock; the locks are now taken in one canonical order (by address)."""

@@ -1,0 +1,19 @@
+# round-end evidence, part B: the rocprofv3 kernel trace of the headline bench, kernel trace + counter passes over every kernel, size sweeps
+set -u
+export TMPDIR=/tmp
+TAG=${TAG:-v}
+O=gpurun_out/$TAG
+mkdir -p $O
+rm -rf $O/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --headline-only --steps 512 --warmup 64 > $O/bench_profiled.json 2> $O/bench_profiled.err
+find $O/prof -name "*kernel_stats*.csv" | head -1 | while read f; do cp "$f" $O/rocprofv3_kernel_stats.csv; done
+rm -rf $O/prof
+head -5 $O/rocprofv3_kernel_stats.csv | cut -c1-200
+timeout 1500 bash tools/gpu_pmc.sh > $O/gpu_pmc.log 2>&1
+cp gpurun_out/pmc/kernel_stats.csv $O/rocprofv3_kernel_stats_all_kernels.csv
+cp gpurun_out/pmc/pmc_all.json gpurun_out/pmc/pmc_bc7.json gpurun_out/pmc/pmc_summary.txt $O/
+rm -rf gpurun_out/pmc/trace gpurun_out/pmc/lds gpurun_out/pmc/sq gpurun_out/pmc/sq2 gpurun_out/pmc/fetch gpurun_out/pmc/write gpurun_out/pmc/grbm
+LG_LO=10 LG_HI=23 timeout 600 python tools/exp/size_sweep_all.py > $O/size_sweep_all_targets.txt 2>&1
+tail -3 $O/size_sweep_all_targets.txt
+timeout 600 python tools/exp/copy_sweep.py > $O/copy_vs_bc7_size_sweep.txt 2>&1
+tail -4 $O/copy_vs_bc7_size_sweep.txt
