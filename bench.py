@@ -978,8 +978,13 @@ def run_atlas4096(env):
             d_o8 = [torch.empty((nbl, 8), dtype=torch.uint8, device=dev) for _ in range(32)]
             d_o64 = [torch.empty((nbl, 64), dtype=torch.uint8, device=dev) for _ in range(32)]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for name, fn, bpb in (("etc1s_to_etc1", lambda k: lib.bu_etc1s_transcode_etc1_device(ctx.handle, d_idx[k].data_ptr(), nbl, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, d_o8[k].data_ptr(), None, sp), 12),
-                                  ("etc1s_to_rgba32", lambda k: lib.bu_etc1s_decode_rgba_device(ctx.handle, d_idx[k].data_ptr(), None, 512, 512, d_ep.data_ptr(), 4096, d_sel.data_ptr(), 8192, d_o64[k].data_ptr(), None, sp), 68)):
+            # (argument tuples built once: at 4-5 us of kernel the loop is bound by what the host spends per call, and four .data_ptr()
+            # calls per launch were most of that)
+            h_, pe_, ps_ = ctx.handle, d_ep.data_ptr(), d_sel.data_ptr()
+            a8 = [(h_, d_idx[k].data_ptr(), nbl, pe_, 4096, ps_, 8192, d_o8[k].data_ptr(), None, sp) for k in range(32)]
+            a64 = [(h_, d_idx[k].data_ptr(), None, 512, 512, pe_, 4096, ps_, 8192, d_o64[k].data_ptr(), None, sp) for k in range(32)]
+            f8, f64 = lib.bu_etc1s_transcode_etc1_device, lib.bu_etc1s_decode_rgba_device
+            for name, fn, bpb in (("etc1s_to_etc1", lambda k: f8(*a8[k]), 12), ("etc1s_to_rgba32", lambda k: f64(*a64[k]), 68)):
                 for k in range(32):
                     fn(k)
                 torch.cuda.synchronize()
