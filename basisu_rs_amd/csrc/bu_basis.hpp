@@ -951,7 +951,13 @@ inline bu_status decode_slices(const BasisLz& lz, std::vector<SliceJob>& jobs, u
     }
     std::atomic<size_t> next{0};
     const std::function<void()> work = [&] {
-        for (size_t k; (k = next.fetch_add(1)) < jobs.size();) jobs[k].st = lz.decode_slice(jobs[k].nbx, jobs[k].nby, jobs[k].data, jobs[k].len, jobs[k].idx);
+        for (size_t k; (k = next.fetch_add(1)) < jobs.size();) {
+            try {  // (a copy of this runs on pool threads: an exception must become a status there)
+                jobs[k].st = lz.decode_slice(jobs[k].nbx, jobs[k].nby, jobs[k].data, jobs[k].len, jobs[k].idx);
+            } catch (...) {
+                jobs[k].st = BU_ERR_BOUNDS;
+            }
+        }
     };
     pool().run(nt - 1, work);
     for (const SliceJob& j : jobs)

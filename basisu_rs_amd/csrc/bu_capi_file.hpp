@@ -255,10 +255,16 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             if (!progressed && spin > 16) std::this_thread::yield();
         }
     };
+    // (a job runs on a pool thread: an exception -- std::bad_alloc from a vector sized by a hostile file -- must become a status there,
+    // it cannot unwind through the pool)
     auto run_slice = [&](Job& j) {
-        if (st_tables == BU_OK && !abort.load(std::memory_order_relaxed))
-            j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx, &j.rows, &abort);
-        else
+        if (st_tables == BU_OK && !abort.load(std::memory_order_relaxed)) {
+            try {
+                j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx, &j.rows, &abort);
+            } catch (...) {
+                j.st = BU_ERR_BOUNDS;
+            }
+        } else
             j.st = BU_ERR_ARGUMENT;  // never reported: an earlier error decides
         if (j.st) slice_failed.store(true, std::memory_order_relaxed);
         j.done.store(1, std::memory_order_release);
@@ -267,7 +273,12 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     const std::thread::id caller = std::this_thread::get_id();
     const std::function<void()> work = [&] {
         if (std::this_thread::get_id() != caller && !feeder_taken.exchange(true)) {
-            const bu_status fs = feeder();
+            bu_status fs;
+            try {
+                fs = feeder();
+            } catch (...) {
+                fs = BU_ERR_HIP;
+            }
             if (fs) {
                 st_feed = fs;
                 abort.store(true, std::memory_order_relaxed);
@@ -276,7 +287,11 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
         }
         for (size_t k; (k = next.fetch_add(1)) < jobs.size() + 1;) {
             if (k == 0) {  // codebooks: the first kernel launch waits for them
-                st_cb = lz.init_codebooks(file + h.endpoint_cb_file_ofs, h.endpoint_cb_file_size, file + h.selector_cb_file_ofs, h.selector_cb_file_size);
+                try {
+                    st_cb = lz.init_codebooks(file + h.endpoint_cb_file_ofs, h.endpoint_cb_file_size, file + h.selector_cb_file_ofs, h.selector_cb_file_size);
+                } catch (...) {
+                    st_cb = BU_ERR_BOUNDS;
+                }
                 if (st_cb) abort.store(true, std::memory_order_relaxed);
                 cb_done.store(1, std::memory_order_release);
             } else if (k == 1) {
