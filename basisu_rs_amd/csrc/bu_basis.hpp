@@ -808,6 +808,221 @@ struct BasisLz {
         return true;
     }
 
+    // ---- the slice loop on TWO threads (round 4) -----------------------------------------------------------------------------------
+    // The loop above is bound by instruction throughput on one host core (~21 clocks per block), and half of its instructions do
+    // not touch the bit stream: endpoint prediction, the selector history, the index store.  slice_lex is the bit-serial half -- it
+    // walks the stream with exactly the state that decides WHICH table reads next (predictor bits, predictor-repeat and selector-run
+    // counters) and leaves one token pair per block: tok_ep = predictor | delta symbol << 2, tok_sel = selector symbol (a run block:
+    // n_selectors, i.e. history entry 0; a texture-video block that keeps the previous frame's selector: SPLIT_SKIP).  slice_resolve,
+    // on another thread, turns tokens into indices one row behind.  Rows are handed over through `rows_lexed` (release / acquire);
+    // the token arrays cover the whole slice, so the lexer never waits for the resolver.  Like decode_slice_fast both halves only
+    // handle regular streams: any irregularity makes them give up (`failed`), and the caller decodes the slice again with the exact loop.
+    static constexpr uint16_t SPLIT_SKIP = 0xFFFF;
+    bool split_ok() const
+    {
+        return n_endpoints != 0 && n_selectors != 0 && n_endpoints <= 65536u && (uint64_t)n_selectors + history_size < 0xFFFFu && endpoint_pred.bits() &&
+               delta_endpoint.bits() && selector.bits() && history_rle.bits();
+    }
+    bool slice_lex(size_t nbx, size_t nby, const uint8_t* data, size_t len, uint32_t* tok_ep, uint16_t* tok_sel, std::atomic<uint32_t>& rows_lexed,
+                   std::atomic<bool>& failed) const
+    {
+        const uint32_t n_sel = n_selectors, hs = history_size;
+        const uint32_t *tp = endpoint_pred.table(), *td = delta_endpoint.table(), *ts = selector.table(), *tr = history_rle.table();
+        const uint32_t mp = (1u << endpoint_pred.bits()) - 1u, md = (1u << delta_endpoint.bits()) - 1u, msel = (1u << selector.bits()) - 1u,
+                       mr = (1u << history_rle.bits()) - 1u;
+        uint64_t acc = 0;
+        unsigned have = 0;
+        size_t pos = 0;
+        auto refill = [&]() __attribute__((always_inline)) {
+            if (pos + 8 <= len) {
+                uint64_t w;
+                memcpy(&w, data + pos, 8);
+                acc |= w << have;
+                pos += (63u - have) >> 3;
+                have |= 56u;
+            } else {
+                while (have <= 56) {
+                    const uint64_t byte = pos < len ? data[pos] : 0;
+                    pos++;
+                    acc |= byte << have;
+                    have += 8;
+                }
+            }
+        };
+        auto vlc_fast = [&](unsigned chunk_bits, uint32_t* out) {
+            uint32_t v = 0;
+            for (unsigned ofs = 0;; ofs += chunk_bits) {
+                if (ofs >= 32) return false;
+                if (have < 16) refill();
+                const uint32_t sy = (uint32_t)(acc & ((1ull << (chunk_bits + 1)) - 1ull));
+                acc >>= chunk_bits + 1;
+                have -= chunk_bits + 1;
+                v |= (sy & ((1u << chunk_bits) - 1u)) << ofs;
+                if (!(sy >> chunk_bits)) break;
+            }
+            *out = v;
+            return true;
+        };
+        std::vector<uint8_t> saved_bits((nbx + 1) / 2, 0);
+        const uint32_t rle_sym = (n_sel + hs) & 0xFFFFu;
+        uint32_t sel_rle = 0, pred_repeat = 0, prev_pred_sym = 0, bad = 0;
+        const bool video = is_video;
+        auto block = [&](size_t i, uint32_t pred) __attribute__((always_inline)) -> bool {
+            const uint32_t ed = td[(uint32_t)acc & md];
+            const bool is3 = pred == 3;
+            const uint32_t dl = is3 ? (ed & 31u) : 0u;
+            acc >>= dl;
+            have -= dl;
+            bad |= is3 & ((ed & 31u) == 0u);
+            tok_ep[i] = pred | ((ed >> 5) << 2);
+            if (video && pred == 2) {
+                tok_sel[i] = SPLIT_SKIP;
+                return true;
+            }
+            if (sel_rle) {
+                sel_rle--;
+                tok_sel[i] = (uint16_t)n_sel;
+                return true;
+            }
+            const uint32_t es = ts[(uint32_t)acc & msel];
+            bad |= (es & 31u) == 0u;
+            acc >>= (es & 31u);
+            have -= (es & 31u);
+            uint32_t sym = es >> 5;
+            if (sym == rle_sym) {
+                if (hs == 0) return false;
+                if (have < 16) refill();
+                const uint32_t er = tr[(uint32_t)acc & mr];
+                if ((er & 31u) == 0u) return false;
+                acc >>= (er & 31u);
+                have -= (er & 31u);
+                uint32_t run = er >> 5;
+                if (run == 63) {
+                    uint32_t v;
+                    if (!vlc_fast(7, &v)) return false;
+                    run = v;
+                }
+                sel_rle = 3 + run - 1;
+                sym = n_sel;
+            }
+            tok_sel[i] = (uint16_t)sym;
+            return true;
+        };
+        for (size_t by = 0; by < nby; by++) {
+            const bool even = !(by & 1);
+            const size_t row = by * nbx;
+            for (size_t bx = 0; bx < nbx; bx += 2) {
+                refill();
+                uint32_t bits;
+                if (even) {
+                    if (pred_repeat) {
+                        pred_repeat--;
+                        bits = prev_pred_sym;
+                    } else {
+                        const uint32_t e0 = tp[(uint32_t)acc & mp];
+                        bad |= (e0 & 31u) == 0u;
+                        acc >>= (e0 & 31u);
+                        have -= (e0 & 31u);
+                        const uint32_t sy = e0 >> 5;
+                        if (sy == 256) {
+                            uint32_t v;
+                            if (!vlc_fast(4, &v)) {
+                                failed.store(true, std::memory_order_release);
+                                return false;
+                            }
+                            pred_repeat = v + 2;
+                            bits = prev_pred_sym;
+                            refill();
+                        } else {
+                            bits = sy & 0xFF;
+                            prev_pred_sym = sy & 0xFF;
+                        }
+                    }
+                    saved_bits[bx >> 1] = (uint8_t)(bits >> 4);
+                } else {
+                    bits = saved_bits[bx >> 1];
+                }
+                bool ok = block(row + bx, bits & 3);
+                if (ok && bx + 1 < nbx) {
+                    refill();
+                    ok = block(row + bx + 1, (bits >> 2) & 3);
+                }
+                if (!ok) {
+                    failed.store(true, std::memory_order_release);
+                    return false;
+                }
+            }
+            if (bad || failed.load(std::memory_order_relaxed)) {
+                failed.store(true, std::memory_order_release);
+                return false;
+            }
+            rows_lexed.store((uint32_t)(by + 1), std::memory_order_release);
+        }
+        return true;
+    }
+    bool slice_resolve(size_t nbx, size_t nby, const uint32_t* tok_ep, const uint16_t* tok_sel, uint32_t* idx, const std::atomic<uint32_t>& rows_lexed,
+                       std::atomic<bool>& failed, std::atomic<uint32_t>* rows_done, const std::atomic<bool>* abort) const
+    {
+        const uint32_t n_ep = n_endpoints, n_sel = n_selectors, hs = history_size;
+        std::vector<uint16_t> above_v(nbx + 1, 0), cur_v(nbx + 1, 0);  // [0] = the column left of the slice (never a valid source)
+        std::vector<uint16_t> hist(hs ? hs : 1, 0);
+        uint16_t *above = above_v.data() + 1, *cur_row = cur_v.data() + 1;
+        uint32_t rover = hs / 2, prev_ep = 0, bad = 0;
+        const bool video = is_video;
+        for (size_t by = 0; by < nby; by++) {
+            for (unsigned spin = 0; rows_lexed.load(std::memory_order_acquire) <= by; spin++) {
+                if (failed.load(std::memory_order_acquire) || (abort && abort->load(std::memory_order_relaxed))) return false;
+                if (spin > 256) std::this_thread::yield();
+            }
+            const uint32_t row_edge = by == 0 ? (video ? 2u : 6u) : 0u, col_edge = video ? 1u : 5u;
+            const uint32_t* te = tok_ep + by * nbx;
+            const uint16_t* tsl = tok_sel + by * nbx;
+            uint32_t* out_row = idx + by * nbx;
+            for (size_t bx = 0; bx < nbx; bx++) {
+                const uint32_t t = te[bx], pred = t & 3u;
+                if (bx == 0 || by == 0) bad |= ((row_edge | (bx == 0 ? col_edge : 0u)) >> pred) & 1u;
+                const bool is3 = pred == 3;
+                uint32_t e3 = ((t >> 2) + prev_ep) & 0xFFFFu;
+                e3 = e3 >= n_ep ? (e3 - n_ep) & 0xFFFFu : e3;
+                bad |= is3 & (e3 >= n_ep);
+                const uint32_t e01 = (pred & 1) ? above[bx] : prev_ep;
+                const uint32_t e2 = video ? 0u : above[(ptrdiff_t)bx - 1];
+                const uint32_t e = is3 ? e3 : ((pred & 2) ? e2 : e01);
+                cur_row[bx] = (uint16_t)e;
+                prev_ep = e;
+                const uint32_t sym = tsl[bx];
+                uint32_t sel;
+                if (sym == SPLIT_SKIP) {
+                    sel = 0;
+                } else if (sym >= n_sel) {
+                    const uint32_t hi = sym - n_sel;
+                    if (hi >= hs) {
+                        failed.store(true, std::memory_order_release);
+                        return false;
+                    }
+                    sel = hist[hi];
+                    const uint16_t x = hist[hi / 2];  // (hi == 0: swaps entry 0 with itself)
+                    hist[hi / 2] = (uint16_t)sel;
+                    hist[hi] = x;
+                } else {
+                    if (hs) {
+                        hist[rover] = (uint16_t)sym;
+                        rover = rover + 1 == hs ? hs / 2 : rover + 1;
+                    }
+                    sel = sym;
+                }
+                out_row[bx] = e | (sel << 16);
+            }
+            if (bad) {
+                failed.store(true, std::memory_order_release);
+                return false;
+            }
+            std::swap(above, cur_row);
+            if (rows_done) rows_done->store((uint32_t)(by + 1), std::memory_order_release);
+        }
+        return true;
+    }
+
     bu_status decode_slice_exact(size_t nbx, size_t nby, const uint8_t* data, size_t len, uint32_t* idx) const
     {
         BitReader r(data, len);

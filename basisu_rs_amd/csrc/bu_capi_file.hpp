@@ -269,10 +269,42 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
         if (j.st) slice_failed.store(true, std::memory_order_relaxed);
         j.done.store(1, std::memory_order_release);
     };
+    // Slice 0 on TWO threads (bu_host::BasisLz::slice_lex / slice_resolve): the calling thread walks the bit stream and leaves a token
+    // pair per block, the first pool thread to arrive turns tokens into indices one row behind (endpoint prediction, selector
+    // history, the stores the GPU reads) -- the symbol loop of a slice is bound by the host core's instruction throughput, and
+    // this takes a sixth off it (1.34 -> 1.13 ms for BASELINE config 4's slice on the box's host).  Token buffers live in the
+    // context.  Any irregularity ends both halves and the calling thread decodes the slice again with the ordinary loops.
+    const size_t blocks0 = jobs.empty() ? 0 : jobs[0].nbx * jobs[0].nby;
+    bool split = st_tables == BU_OK && blocks0 >= BU_ETC1S_STREAM_MIN_BLOCKS && lz.split_ok() && !getenv("BU_ETC1S_ONE_THREAD");
+    if (split && blocks0 * 6 + 64 > ctx->lex_cap) {
+        free(ctx->lex_buf);
+        ctx->lex_cap = 0;
+        ctx->lex_buf = malloc(blocks0 * 6 + 64 + blocks0 / 2);
+        if (ctx->lex_buf) ctx->lex_cap = blocks0 * 6 + 64 + blocks0 / 2;
+        else split = false;
+    }
+    uint32_t* const tok_ep = static_cast<uint32_t*>(ctx->lex_buf);
+    uint16_t* const tok_sel = split ? reinterpret_cast<uint16_t*>(tok_ep + blocks0 + 8) : nullptr;
+    std::atomic<uint32_t> rows_lexed{0};
+    std::atomic<bool> split_failed{false}, resolver_taken{false};
+    std::atomic<int> resolver_done{0};
+    bool res_ok = false;
+    auto resolver = [&] {
+        try {
+            res_ok = lz.slice_resolve(jobs[0].nbx, jobs[0].nby, tok_ep, tok_sel, jobs[0].idx, rows_lexed, split_failed, &jobs[0].rows, &abort);
+        } catch (...) {
+            res_ok = false;
+            split_failed.store(true, std::memory_order_release);
+        }
+        resolver_done.store(1, std::memory_order_release);
+    };
     std::atomic<size_t> next{0};
     const std::thread::id caller = std::this_thread::get_id();
     const std::function<void()> work = [&] {
-        if (std::this_thread::get_id() != caller && !feeder_taken.exchange(true)) {
+        // roles of the pool threads, in order of arrival: slice 0's resolver (the most urgent: the lexer is already running), the
+        // feeder, then the job queue
+        if (split && std::this_thread::get_id() != caller && !resolver_taken.exchange(true)) resolver();
+        else if (std::this_thread::get_id() != caller && !feeder_taken.exchange(true)) {
             bu_status fs;
             try {
                 fs = feeder();
@@ -302,7 +334,7 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             }
         }
     };
-    const unsigned helpers = bu_host::pool().begin((unsigned)std::min<size_t>(jobs.size() + 2, bu_host::Pool::capacity()), work);
+    const unsigned helpers = bu_host::pool().begin((unsigned)std::min<size_t>(jobs.size() + 3, bu_host::Pool::capacity()), work);
     (void)helpers;
     struct PoolEnd {  // the pool is released on every path out of this function, after the jobs have seen the abort flag
         std::atomic<bool>& abort;
@@ -315,8 +347,29 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             }
         }
     } pool_end{abort};
-    if (!jobs.empty()) run_slice(jobs[0]);
-    lap("slice 0 decoded");
+    if (split) {
+        bool lex_ok = false;
+        try {
+            lex_ok = lz.slice_lex(jobs[0].nbx, jobs[0].nby, jobs[0].data, jobs[0].len, tok_ep, tok_sel, rows_lexed, split_failed);
+        } catch (...) {
+            split_failed.store(true, std::memory_order_release);
+        }
+        if (!resolver_taken.exchange(true)) {  // no pool thread came for it: resolve here (or not at all, if the lexer gave up)
+            if (lex_ok) resolver();
+            else resolver_done.store(1, std::memory_order_release);
+        }
+        for (unsigned spin = 0; !resolver_done.load(std::memory_order_acquire); spin++)
+            if (spin > 64) std::this_thread::yield();
+        if (lex_ok && res_ok) {
+            jobs[0].st = BU_OK;
+            jobs[0].done.store(1, std::memory_order_release);
+        } else {
+            run_slice(jobs[0]);  // an irregular stream (or an abort): the ordinary loops, from the slice's first bit
+        }
+    } else if (!jobs.empty()) {
+        run_slice(jobs[0]);
+    }
+    lap(split ? "slice 0 decoded (two threads)" : "slice 0 decoded");
     work();  // whatever is still in the queue
     if (!feeder_taken.exchange(true)) {  // nobody fed the GPU meanwhile: everything is decoded, launch it now
         st_feed = feeder();

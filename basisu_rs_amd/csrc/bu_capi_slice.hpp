@@ -118,6 +118,7 @@ void bu_context_destroy(bu_context* ctx)
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_aux) (void)hipFree(ctx->d_aux);
     if (ctx->h_idx) (void)hipHostFree(ctx->h_idx);
+    free(ctx->lex_buf);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -16,6 +16,8 @@ struct bu_context {
     size_t out_cap = 0;
     void* d_aux = nullptr;  // codebooks / alpha indices of the host-pointer ETC1S calls
     size_t aux_cap = 0;
+    void* lex_buf = nullptr;  // token buffer of the two-thread slice loop (bu_read_etc1s_streamed): malloc'ed, grows
+    size_t lex_cap = 0;
     void* h_idx = nullptr;  // page-locked index buffer of the streamed ETC1S front door: the host decoder writes it, the kernels read it over PCIe
     size_t h_idx_cap = 0;
     unsigned long long* d_status = nullptr;

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <functional>
 
+#include <thread>
 #include <vector>
 
 #include "bu_basis.hpp"
@@ -34,10 +35,12 @@ static int process(const uint8_t* f, size_t len, int target)
     // sequential, as the reference does it ...
     std::vector<std::vector<uint32_t>> seq(p.slices.size()), par(p.slices.size());
     bu_status seq_st = BU_OK;
+    size_t seq_decoded = 0;  // slices the sequential loop got through without an error
     for (size_t k = 0; k < p.slices.size() && !seq_st; k++) {
         const bu_slice_desc& s = p.slices[k];
         seq[k].assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
         seq_st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, seq[k].data());
+        if (!seq_st) seq_decoded = k + 1;
     }
     // ... and on 4 threads, as bu_read_to does it (threading forced: these files are tiny): same status, same indices
     std::vector<bu_host::SliceJob> jobs;
@@ -45,6 +48,33 @@ static int process(const uint8_t* f, size_t len, int target)
         const bu_slice_desc& s = p.slices[k];
         par[k].assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
         jobs.push_back({s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, par[k].data(), BU_OK});
+    }
+    // ... and every slice on two threads (slice_lex + slice_resolve, the streamed front door's form for the first slice): where both
+    // halves report a regular stream the indices are the sequential loop's; they may only give up where that loop is the judge
+    if (lz.split_ok()) {
+        for (size_t k = 0; k < p.slices.size(); k++) {
+            const bu_slice_desc& s = p.slices[k];
+            const size_t n = (size_t)s.num_blocks_x * s.num_blocks_y;
+            std::vector<uint32_t> tok_ep(n + 1), out(n + 1, 0);
+            std::vector<uint16_t> tok_sel(n + 1);
+            std::atomic<uint32_t> rows_lexed{0}, rows_done{0};
+            std::atomic<bool> failed{false};
+            bool res_ok = false;
+            std::thread th([&] { res_ok = lz.slice_resolve(s.num_blocks_x, s.num_blocks_y, tok_ep.data(), tok_sel.data(), out.data(), rows_lexed, failed, &rows_done, nullptr); });
+            const bool lex_ok = lz.slice_lex(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, tok_ep.data(), tok_sel.data(), rows_lexed, failed);
+            th.join();
+            if (lex_ok && res_ok) {
+                // (slices behind the first failing one were never decoded by the sequential loop: nothing to compare with)
+                const bool have_seq = seq_decoded > k;
+                if (have_seq && out != seq[k]) {
+                    fprintf(stderr, "two-thread decode differs in slice %zu\n", k);
+                    abort();
+                }
+            } else if (seq_st == BU_OK && s.num_blocks_x && s.num_blocks_y) {
+                fprintf(stderr, "two-thread decode gave up on slice %zu of a file the sequential loop accepts\n", k);
+                abort();
+            }
+        }
     }
     const bu_status par_st = bu_host::decode_slices(lz, jobs, 4, 0);
     if (par_st != seq_st) {

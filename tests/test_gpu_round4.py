@@ -14,13 +14,16 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _read_all(bu, ctx, f, one_launch):
-    """(status or None, images) of read_to_rgba / read_to_etc1 with the streamed front door on or off"""
+def _read_all(bu, ctx, f, one_launch, one_thread=False):
+    """(status or None, images) of read_to_rgba / read_to_etc1 with the streamed front door on or off (and, when on, with the first
+    slice decoded on one thread instead of two)"""
     from basisu_rs_amd import BasisuError
 
     out = {}
     if one_launch:
         os.environ["BU_ETC1S_ONE_LAUNCH"] = "1"
+    if one_thread:
+        os.environ["BU_ETC1S_ONE_THREAD"] = "1"
     try:
         for name, fn in (("rgba", lambda: bu.read_to_rgba(f, ctx)[1]), ("etc1", lambda: bu.read_to_etc1(f, ctx))):
             try:
@@ -29,6 +32,7 @@ def _read_all(bu, ctx, f, one_launch):
                 out[name] = (e.status, None)
     finally:
         os.environ.pop("BU_ETC1S_ONE_LAUNCH", None)
+        os.environ.pop("BU_ETC1S_ONE_THREAD", None)
     return out
 
 
@@ -46,6 +50,8 @@ def test_streamed_etc1s_front_door_equals_one_launch_path_and_oracle(ctx, oracle
     f, _, _ = bb.etc1s_file(np.random.default_rng(900 + len(dims) + 2 * alpha + video), dims, n_codebook=1024, alpha=alpha, is_video=video)
     a, b = _read_all(bu, ctx, f, False), _read_all(bu, ctx, f, True)
     assert a == b
+    # a first slice of 32 768 blocks and more is decoded on two threads (slice_lex on the caller, slice_resolve on a pool thread)
+    assert _read_all(bu, ctx, f, False, one_thread=True) == a
     for target in ("rgba", "etc1"):
         st, _, want = oracle.read_to(target, f)
         assert st == 0 and a[target][0] == 0
@@ -65,7 +71,9 @@ def test_streamed_etc1s_front_door_reports_errors_in_the_reference_order(ctx, or
     import basis_builder as bb
     import basisu_rs_amd as bu
 
-    f, _, _ = bb.etc1s_file(np.random.default_rng(77), [(160, 128), (128, 96)], n_codebook=512, history_size=16)
+    # (the first slice is large enough for the two-thread decode: its give-up path -- decode again with the exact loop -- is what
+    # turns damage inside that slice into the reference's status)
+    f, _, _ = bb.etc1s_file(np.random.default_rng(77), [(256, 160), (128, 96)], n_codebook=512, history_size=16)
     hdr = bu.read_header(f)
     rng = np.random.default_rng(5)
     spots = [hdr.endpoint_cb_file_ofs + 3, hdr.selector_cb_file_ofs + 1, hdr.tables_file_ofs + 2, hdr.tables_file_ofs + hdr.tables_file_size - 2]
