@@ -131,7 +131,8 @@ struct BuLayout {
     static constexpr int w_words = (w_total + 31) / 32;
     static_assert(M == 8 || pos_w + w_raw <= 128, "mode does not fit in 128 bits");
     // texel unpack through byte palettes (bu_block_unpack): entries of the alpha palette, 0 = the mode takes the generic path
-    static constexpr int alpha_palette = (M != 8 && has_alpha && d.wb <= 2 && (d.planes == 2 || d.wb == 2)) ? (d.subsets == 2 ? 8 : 4) : 0;
+    static constexpr int alpha_palette = (M != 8 && has_alpha && d.wb <= 2 && (d.planes == 2 || d.wb == 2)) ? (d.subsets == 2 ? 8 : 4)
+                                         : (M != 8 && has_alpha && d.wb == 3 && d.planes == 1 && d.subsets == 1) ? 8 : 0;  // (mode 12)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -344,7 +345,7 @@ BU_DEV uint32_t bu_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b
 //                    selector that read the alpha channel out of alpha_palette(lo, hi)  (2-bit weights, below)
 // with i = row-major texel index, compile-time after unrolling.
 //
-// Two-bit weights (modes 1, 3, 4, 7, 9, 14, 16; with two planes 6, 11, 17, and 13 with one-bit weights): a channel takes one of four values per subset, and the weights
+// Two-bit weights (modes 1, 3, 4, 7, 9, 14, 16; with two planes 6, 11, 17, and 13 with one-bit weights; three-bit weights: further down): a channel takes one of four values per subset, and the weights
 // of a column are already byte-aligned -- texel (x, y) sits at bits 8y + 2x of the weight word, so (W >> 2x) & 0x03030303 is
 // the column's four weights, one per byte.  That is exactly a v_perm_b32 selector: with the four values of a channel in the
 // bytes of one register (two subsets: eight values in a register pair, selector |= subset << 2) ONE instruction
@@ -468,6 +469,46 @@ BU_DEV int bu_block_unpack(const BuTables& T, const BuBlk& b, SINK& sink)
                     for (int c = 0; c < NC; c++) ch[c] = bu_bfi(is2, bu_perm(0u, pal[2][c], wsel), bu_perm(pal[1][c], pal[0][c], sel));
                 }
                 sink.template cols<fmt>(x, ch, asel);
+            }
+            return BU_ST_OK;
+        }
+        if constexpr (wb == 3 && planes == 1) {
+            // Three-bit weights (modes 2, 5, 12): eight values per channel and subset -- exactly the eight source bytes of ONE
+            // v_perm_b32.  Entries 0 and 7 are the endpoints, entries 1..6 a v_dot2 each (LUT3 = 0, 9, 18, 27, 37, 46, 55, 64).
+            // A block row is 12 bits of the weight string: rows 0 | 1 and 2 | 3 go into the 16-bit lanes of two words once, and a
+            // column's selector is a shift + mask of each and a v_perm that lines the four rows up.  Per block 36 (RGB) / 48
+            // (RGBA) instructions of palette + 8 / 9 per column where the generic path below issues 9 to 12 per TEXEL.
+            constexpr uint32_t LUT3[6] = {9, 18, 27, 37, 46, 55};
+            uint32_t pal[2][4][2];
+            BU_UNROLL
+            for (int s = 0; s < subsets; s++) {
+                BU_UNROLL
+                for (int c = 0; c < NC; c++) {
+                    const uint32_t lo = e[(2 * L::channels) * s + 2 * c], hi = e[(2 * L::channels) * s + 2 * c + 1];
+                    uint32_t v[6];
+                    BU_UNROLL
+                    for (int k = 0; k < 6; k++) v[k] = bu_udot2(A[s][c], LUT3[k] * 0x3FFFCu + 256u, 128u);
+                    pal[s][c][0] = bu_perm(v[0], lo, 0x0C0C0600u) | bu_perm(v[2], v[1], 0x06020C0Cu);
+                    pal[s][c][1] = bu_perm(v[4], v[3], 0x0C0C0602u) | bu_perm(hi, v[5], 0x04020C0Cu);
+                }
+            }
+            if constexpr (L::has_alpha) sink.alpha_palette(pal[0][NC - 1][0], pal[0][NC - 1][1]);
+            const uint32_t w23 = bu_alignbit(W[1], W[0], 24);  // rows 2 and 3
+            const uint32_t q01 = (W[0] & 0xFFFu) | ((W[0] << 4) & 0x0FFF0000u), q23 = (w23 & 0xFFFu) | ((w23 << 4) & 0x0FFF0000u);
+            BU_UNROLL
+            for (int x = 0; x < 4; x++) {
+                const uint32_t sel = bu_perm((q23 >> (3 * x)) & 0x00070007u, (q01 >> (3 * x)) & 0x00070007u, 0x06040200u);
+                uint32_t ch[4] = {0, 0, 0, 0};
+                if constexpr (subsets == 1) {
+                    BU_UNROLL
+                    for (int c = 0; c < NC; c++) ch[c] = bu_perm(pal[0][c][1], pal[0][c][0], sel);
+                } else {
+                    static_assert(subsets <= 2, "three-subset modes have 2-bit weights");
+                    const uint32_t is1 = ((upat >> (2 * x)) & 0x01010101u) * 255u;
+                    BU_UNROLL
+                    for (int c = 0; c < NC; c++) ch[c] = bu_bfi(is1, bu_perm(pal[1][c][1], pal[1][c][0], sel), bu_perm(pal[0][c][1], pal[0][c][0], sel));
+                }
+                sink.template cols<fmt>(x, ch, sel);
             }
             return BU_ST_OK;
         }
