@@ -32,7 +32,7 @@ for k in range(NBUF):
     ins.append(gu[idx].contiguous())
     if k == 0: idx0 = idx
 outs = [torch.empty((N, 16), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
-routs = [torch.empty((N, 64), dtype=torch.uint8, device=dev) for _ in range(min(NBUF, 16))]
+routs = [torch.empty((N, 64), dtype=torch.uint8, device=dev) for _ in range(min(NBUF, 16) if "rgba" in a.targets.split(",") else 1 if N <= (1 << 22) else 0)] or [outs[0]]
 sp = vp(torch.cuda.current_stream().cuda_stream)
 A = vp * NBUF
 ip, op = A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs])
