@@ -422,7 +422,8 @@ def etc1s_file(rng, dims, n_codebook=256, history_size=32, alpha=False, raw_sele
     slices = []
     for i, ((nbx, nby), d) in enumerate(zip(all_dims, datas)):
         is_a = alpha and (i & 1)
-        slices.append(dict(data=d, orig_w=4 * nbx, orig_h=4 * nby, nbx=nbx, nby=nby, image_index=i // (2 if alpha else 1), flags=1 if is_a else 0))
+        slices.append(dict(data=d, orig_w=min(4 * nbx, 65535), orig_h=min(4 * nby, 65535), nbx=nbx, nby=nby,  # (orig_* are u16 metadata, basis.rs:554-571)
+                            image_index=i // (2 if alpha else 1), flags=1 if is_a else 0))
     flags = 1 | (4 if alpha else 0)
     return build_basis_file(0, slices, flags=flags, tex_type=3 if is_video else 0, total_endpoints=n_codebook, endpoint_cb=ecb,
                             total_selectors=n_codebook, selector_cb=scb, tables=tables, total_images=len(dims)), ep, rows

@@ -208,6 +208,25 @@ def test_concurrent_slice_decode_is_race_free(tmp_path):
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "pool stress ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("dims,kw", [([(1, 700)], dict()), ([(700, 1)], dict()), ([(3, 301), (5, 3)], dict(alpha=True)), ([(1, 650)], dict(is_video=True)),
+                                     ([(2, 2)], dict(history_size=0))])
+def test_two_thread_slice_decode_on_degenerate_grids(tmp_path, dims, kw):
+    """slice_lex + slice_resolve (the streamed front door's form for a large first slice) against the sequential loop on grids
+    whose block pairs and row pairs degenerate -- one block column, one block row, odd widths, no selector history -- pristine
+    and under fuzz, ASan / UBSan and ThreadSanitizer builds (the harness compares every slice it decodes both ways)"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    he = os.path.join(root, "tests", "host_emul")
+    subprocess.run(["make", "-C", he, "bu_hostlogic_asan", "bu_hostlogic_tsan"], check=True, capture_output=True)
+    f, _, _ = bb.etc1s_file(np.random.default_rng(11 + len(dims)), dims, n_codebook=90, **kw)
+    path = tmp_path / "t.basis"
+    path.write_bytes(f)
+    for exe, n in (("bu_hostlogic_asan", "600"), ("bu_hostlogic_tsan", "60")):
+        r = subprocess.run([os.path.join(he, exe), str(path), n], capture_output=True, text=True)
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "fuzz done" in r.stdout, exe + r.stdout + r.stderr[-3000:]
+
+
 def test_allocation_failure_inside_the_abi_is_a_status_not_a_terminate(tmp_path):
     """C++ exceptions must not cross the C ABI: a file whose slice table needs more memory than the process may have
     (address-space limit set just above the current footprint) makes std::vector throw std::bad_alloc inside

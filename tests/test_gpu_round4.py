@@ -38,7 +38,12 @@ def _read_all(bu, ctx, f, one_launch, one_thread=False):
 
 @pytest.mark.parametrize("dims,alpha,video", [([(256, 160)], False, False), ([(192, 192), (64, 64), (7, 5)], True, False),
                                               ([(96, 96)] * 5, False, False), ([(200, 170), (33, 31)], False, True),
-                                              ([(181, 183)], True, False)])
+                                              ([(181, 183)], True, False),
+                                              # degenerate grids, large enough for the two-thread decode of the first slice: one block
+                                              # column (every block is a left edge, block pairs are single blocks), one block row (no
+                                              # odd rows at all: the saved predictor bits are never read), three columns (odd width)
+                                              ([(1, 33000)], False, False), ([(33000, 1)], False, False), ([(3, 11001), (5, 3)], True, False),
+                                              ([(1, 32800)], False, True)])
 def test_streamed_etc1s_front_door_equals_one_launch_path_and_oracle(ctx, oracle, dims, alpha, video):
     """ETC1S files of 32 768 blocks and more take the streamed front door (bu_read_etc1s_streamed: tables first, codebooks / payload
     CRC / slices on pool threads, bands of finished rows launched while the rest is decoded, indices read from page-locked memory).
