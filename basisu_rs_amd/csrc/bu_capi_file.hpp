@@ -171,7 +171,13 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     BU_HIP(ctx, hipMemcpyAsync(aux + ep_bytes + sel_bytes + status_bytes, descs.data(), descs.size() * sizeof(BuEtc1sSlice), hipMemcpyHostToDevice, ctx->stream));
     lap("reserve");
 
-    // ---- the jobs: [payload CRC] [codebooks] [slice 0] [slice 1] ... pulled from one counter by the pool threads ----
+    // ---- the jobs: [codebooks] [payload CRC] [slices ...] pulled from one counter by the pool threads ----
+    // A slice of BU_ETC1S_STREAM_MIN_BLOCKS blocks and more is decoded on TWO threads (bu_host::BasisLz::slice_lex / slice_resolve):
+    // one walks the bit stream and leaves a token pair per block, the other turns tokens into indices one row behind (endpoint
+    // prediction, selector history, the stores the GPU reads) -- the symbol loop of a slice is bound by one host core's instruction
+    // throughput, and this takes a quarter off it (1.55 -> 1.2 ms end to end for BASELINE config 4).  Token buffers live in the
+    // context.  Any irregularity ends both halves, and whichever of the two finishes second decodes the slice again with the ordinary
+    // loops, which decide the status.
     struct Job {
         size_t nbx = 0, nby = 0;
         const uint8_t* data = nullptr;
@@ -180,9 +186,19 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
         std::atomic<uint32_t> rows{0};
         std::atomic<int> done{0};
         bu_status st = BU_OK;
+        // the two-thread form
+        bool split = false;
+        uint32_t* tok_ep = nullptr;
+        uint16_t* tok_sel = nullptr;
+        std::atomic<uint32_t> rows_lexed{0};
+        std::atomic<bool> split_failed{false};
+        std::atomic<int> halves_done{0};
+        bool lex_ok = false, res_ok = false;
     };
     const size_t per_img = p.alpha_pairs ? 2 : 1;
     std::vector<Job> jobs(n_img * per_img);
+    const bool may_split = st_tables == BU_OK && lz.split_ok() && !getenv("BU_ETC1S_ONE_THREAD");
+    size_t tok_bytes = 0, n_split = 0;
     for (size_t k = 0; k < n_img; k++)
         for (size_t a = 0; a < per_img; a++) {
             const bu_slice_desc& s = p.slices[p.first_slice[k] + a];
@@ -192,7 +208,33 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             j.data = file + s.file_ofs;
             j.len = s.file_size;
             j.idx = h_idx + (a ? ain_off[k] : in_off[k]);
+            if (may_split && j.nbx * j.nby >= BU_ETC1S_STREAM_MIN_BLOCKS) {
+                j.split = true;
+                n_split++;
+                tok_bytes += (j.nbx * j.nby * 6 + 127) & ~(size_t)63;
+            }
         }
+    if (tok_bytes > ctx->lex_cap) {
+        free(ctx->lex_buf);
+        ctx->lex_cap = 0;
+        ctx->lex_buf = malloc(tok_bytes + tok_bytes / 4);
+        if (ctx->lex_buf) ctx->lex_cap = tok_bytes + tok_bytes / 4;
+    }
+    {
+        uint8_t* t = static_cast<uint8_t*>(ctx->lex_buf);
+        for (Job& j : jobs) {
+            if (!j.split) continue;
+            if (!t) {  // (no memory for the tokens: the ordinary loop)
+                j.split = false;
+                n_split--;
+                continue;
+            }
+            const size_t nblk = j.nbx * j.nby;
+            j.tok_ep = reinterpret_cast<uint32_t*>(t);
+            j.tok_sel = reinterpret_cast<uint16_t*>(t + nblk * 4);
+            t += (nblk * 6 + 127) & ~(size_t)63;
+        }
+    }
     // abort: nothing that is still running can matter any more (a codebook / table / device error, or this function is on its way
     // out): decoders stop at the next row.  slice_failed: some slice failed -- the feeder stops launching, but the OTHER slices
     // decode on: the call reports the first failing slice in file order, and an earlier slice may still fail too.
@@ -200,11 +242,13 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     std::atomic<int> cb_done{0};
     bu_status st_cb = BU_OK, st_feed = BU_OK;
     bool crc_ok = true;
-    // Who does what: the CALLING thread decodes slice 0 itself, at once -- the symbol stream of the (first) slice is the critical
-    // path, and a parked pool thread takes tens of microseconds to wake up.  The first pool thread to arrive becomes the feeder
-    // (it launches bands of finished units on the context stream until everything is launched); the others pull the remaining
-    // jobs -- codebooks, payload CRC, slices 1.. -- from one counter, and so does the calling thread once slice 0 is done.  If no
-    // pool thread ever takes the feeder role the calling thread runs it last, when everything is decoded.
+    // Who does what: the CALLING thread starts on the first slice at once (all of it, or its bit-serial half) -- the symbol stream
+    // of the (first) slice is the critical path, and a parked pool thread takes tens of microseconds to wake up.  The pool threads
+    // pull work items from one counter, in this order: the first slice's resolver half (its lexer is already running), the codebooks,
+    // the feeder role (it launches bands of finished units on the context stream until everything is launched), the payload
+    // CRC, then the other slices -- a two-thread slice as two items, lexer first, so that whoever pulls a resolver item knows its
+    // lexer has been claimed by a thread that never waits for anything.  The calling thread joins the queue when its own slice is
+    // done; if no pool thread ever took the feeder role it runs it last, when everything is decoded.
     const uint32_t n_cb0 = (uint32_t)n_cb;
     auto launch = [&](uint32_t u0, uint32_t u1) -> bu_status {
         const unsigned grid = bu_grid_for((size_t)(u1 - u0) * 64, ctx->cu_count);
@@ -269,56 +313,94 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
         if (j.st) slice_failed.store(true, std::memory_order_relaxed);
         j.done.store(1, std::memory_order_release);
     };
-    // Slice 0 on TWO threads (bu_host::BasisLz::slice_lex / slice_resolve): the calling thread walks the bit stream and leaves a token
-    // pair per block, the first pool thread to arrive turns tokens into indices one row behind (endpoint prediction, selector
-    // history, the stores the GPU reads) -- the symbol loop of a slice is bound by the host core's instruction throughput, and
-    // this takes a sixth off it (1.34 -> 1.13 ms for BASELINE config 4's slice on the box's host).  Token buffers live in the
-    // context.  Any irregularity ends both halves and the calling thread decodes the slice again with the ordinary loops.
-    const size_t blocks0 = jobs.empty() ? 0 : jobs[0].nbx * jobs[0].nby;
-    bool split = st_tables == BU_OK && blocks0 >= BU_ETC1S_STREAM_MIN_BLOCKS && lz.split_ok() && !getenv("BU_ETC1S_ONE_THREAD");
-    if (split && blocks0 * 6 + 64 > ctx->lex_cap) {
-        free(ctx->lex_buf);
-        ctx->lex_cap = 0;
-        ctx->lex_buf = malloc(blocks0 * 6 + 64 + blocks0 / 2);
-        if (ctx->lex_buf) ctx->lex_cap = blocks0 * 6 + 64 + blocks0 / 2;
-        else split = false;
-    }
-    uint32_t* const tok_ep = static_cast<uint32_t*>(ctx->lex_buf);
-    uint16_t* const tok_sel = split ? reinterpret_cast<uint16_t*>(tok_ep + blocks0 + 8) : nullptr;
-    std::atomic<uint32_t> rows_lexed{0};
-    std::atomic<bool> split_failed{false}, resolver_taken{false};
-    std::atomic<int> resolver_done{0};
-    bool res_ok = false;
-    auto resolver = [&] {
-        try {
-            res_ok = lz.slice_resolve(jobs[0].nbx, jobs[0].nby, tok_ep, tok_sel, jobs[0].idx, rows_lexed, split_failed, &jobs[0].rows, &abort);
-        } catch (...) {
-            res_ok = false;
-            split_failed.store(true, std::memory_order_release);
+    // the halves of a two-thread slice; the one that finishes second settles the slice
+    auto settle_split = [&](Job& j) {
+        if (j.halves_done.fetch_add(1, std::memory_order_acq_rel) != 1) return;
+        if (j.lex_ok && j.res_ok) {
+            j.st = BU_OK;
+            j.done.store(1, std::memory_order_release);
+        } else {
+            run_slice(j);  // an irregular stream (or an abort): the ordinary loops, from the slice's first bit
         }
-        resolver_done.store(1, std::memory_order_release);
     };
+    auto run_lex = [&](Job& j) {
+        try {
+            j.lex_ok = lz.slice_lex(j.nbx, j.nby, j.data, j.len, j.tok_ep, j.tok_sel, j.rows_lexed, j.split_failed);
+        } catch (...) {
+            j.lex_ok = false;
+        }
+        if (!j.lex_ok) j.split_failed.store(true, std::memory_order_release);
+        settle_split(j);
+    };
+    auto run_resolve = [&](Job& j) {
+        try {
+            j.res_ok = lz.slice_resolve(j.nbx, j.nby, j.tok_ep, j.tok_sel, j.idx, j.rows_lexed, j.split_failed, &j.rows, &abort);
+        } catch (...) {
+            j.res_ok = false;
+        }
+        if (!j.res_ok) j.split_failed.store(true, std::memory_order_release);
+        settle_split(j);
+    };
+    // the work items behind the calling thread's own start on slice 0
+    enum ItemKind { I_RESOLVE, I_FEED, I_CODEBOOKS, I_CRC, I_SLICE, I_LEX };
+    struct Item {
+        ItemKind kind;
+        size_t job;
+    };
+    std::vector<Item> items;
+    if (!jobs.empty() && jobs[0].split) items.push_back({I_RESOLVE, 0});
+    items.push_back({I_CODEBOOKS, 0});
+    items.push_back({I_FEED, 0});
+    items.push_back({I_CRC, 0});
+    for (size_t k = 1; k < jobs.size(); k++) {
+        if (jobs[k].split) {
+            items.push_back({I_LEX, k});
+            items.push_back({I_RESOLVE, k});
+        } else
+            items.push_back({I_SLICE, k});
+    }
     std::atomic<size_t> next{0};
     const std::thread::id caller = std::this_thread::get_id();
+    // BU_TRACE: when every item started and ended, relative to this point
+    struct ItemLog {
+        double t0 = 0, t1 = 0;
+    };
+    std::vector<ItemLog> item_log(trace ? items.size() + 1 : 0);
+    const auto t_items = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_items).count(); };
     const std::function<void()> work = [&] {
-        // roles of the pool threads, in order of arrival: slice 0's resolver (the most urgent: the lexer is already running), the
-        // feeder, then the job queue
-        if (split && std::this_thread::get_id() != caller && !resolver_taken.exchange(true)) resolver();
-        else if (std::this_thread::get_id() != caller && !feeder_taken.exchange(true)) {
-            bu_status fs;
-            try {
-                fs = feeder();
-            } catch (...) {
-                fs = BU_ERR_HIP;
+        for (size_t i; (i = next.fetch_add(1)) < items.size();) {
+            const Item it = items[i];
+            struct Stamp {
+                ItemLog* l;
+                decltype(since)& now;
+                Stamp(ItemLog* l_, decltype(since)& n) : l(l_), now(n)
+                {
+                    if (l) l->t0 = now();
+                }
+                ~Stamp()
+                {
+                    if (l) l->t1 = now();
+                }
+            } stamp(trace ? &item_log[i] : nullptr, since);
+            switch (it.kind) {
+            case I_FEED: {
+                // (the calling thread leaves the role to a pool thread: it would stop pulling items for as long as bands are pending;
+                // it runs the feeder itself at the very end if nobody else did)
+                if (std::this_thread::get_id() == caller || feeder_taken.exchange(true)) break;
+                bu_status fs;
+                try {
+                    fs = feeder();
+                } catch (...) {
+                    fs = BU_ERR_HIP;
+                }
+                if (fs) {
+                    st_feed = fs;
+                    abort.store(true, std::memory_order_relaxed);
+                }
+                return;  // everything is launched (or stopped): nothing is left that this thread should start on
             }
-            if (fs) {
-                st_feed = fs;
-                abort.store(true, std::memory_order_relaxed);
-            }
-            return;
-        }
-        for (size_t k; (k = next.fetch_add(1)) < jobs.size() + 1;) {
-            if (k == 0) {  // codebooks: the first kernel launch waits for them
+            case I_CODEBOOKS:  // the first kernel launch waits for them
                 try {
                     st_cb = lz.init_codebooks(file + h.endpoint_cb_file_ofs, h.endpoint_cb_file_size, file + h.selector_cb_file_ofs, h.selector_cb_file_size);
                 } catch (...) {
@@ -326,15 +408,18 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
                 }
                 if (st_cb) abort.store(true, std::memory_order_relaxed);
                 cb_done.store(1, std::memory_order_release);
-            } else if (k == 1) {
+                break;
+            case I_CRC:
                 // (the serial form: bu_host::crc16 cuts large inputs into pieces for the pool -- which this call is holding)
                 if (crc_pending) crc_ok = (uint16_t)~bu_host::crc16_raw(file + 77, len - 77, 0xFFFF) == crc_want;
-            } else {
-                run_slice(jobs[k - 1]);  // (job 0 is the calling thread's)
+                break;
+            case I_SLICE: run_slice(jobs[it.job]); break;
+            case I_LEX: run_lex(jobs[it.job]); break;
+            case I_RESOLVE: run_resolve(jobs[it.job]); break;
             }
         }
     };
-    const unsigned helpers = bu_host::pool().begin((unsigned)std::min<size_t>(jobs.size() + 3, bu_host::Pool::capacity()), work);
+    const unsigned helpers = bu_host::pool().begin((unsigned)std::min<size_t>(items.size(), bu_host::Pool::capacity()), work);
     (void)helpers;
     struct PoolEnd {  // the pool is released on every path out of this function, after the jobs have seen the abort flag
         std::atomic<bool>& abort;
@@ -347,36 +432,29 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             }
         }
     } pool_end{abort};
-    if (split) {
-        bool lex_ok = false;
-        try {
-            lex_ok = lz.slice_lex(jobs[0].nbx, jobs[0].nby, jobs[0].data, jobs[0].len, tok_ep, tok_sel, rows_lexed, split_failed);
-        } catch (...) {
-            split_failed.store(true, std::memory_order_release);
-        }
-        if (!resolver_taken.exchange(true)) {  // no pool thread came for it: resolve here (or not at all, if the lexer gave up)
-            if (lex_ok) resolver();
-            else resolver_done.store(1, std::memory_order_release);
-        }
-        for (unsigned spin = 0; !resolver_done.load(std::memory_order_acquire); spin++)
-            if (spin > 64) std::this_thread::yield();
-        if (lex_ok && res_ok) {
-            jobs[0].st = BU_OK;
-            jobs[0].done.store(1, std::memory_order_release);
-        } else {
-            run_slice(jobs[0]);  // an irregular stream (or an abort): the ordinary loops, from the slice's first bit
-        }
-    } else if (!jobs.empty()) {
-        run_slice(jobs[0]);
+    if (!jobs.empty()) {
+        if (jobs[0].split) run_lex(jobs[0]);
+        else run_slice(jobs[0]);
     }
-    lap(split ? "slice 0 decoded (two threads)" : "slice 0 decoded");
-    work();  // whatever is still in the queue
-    if (!feeder_taken.exchange(true)) {  // nobody fed the GPU meanwhile: everything is decoded, launch it now
-        st_feed = feeder();
-    }
+    lap(!jobs.empty() && jobs[0].split ? "slice 0 lexed (resolver on a pool thread)" : "slice 0 decoded");
+    work();  // whatever is still in the queue (the feeder item is skipped by this thread)
     pool_end.armed = false;
-    bu_host::pool().end();  // every job has finished, the feeder has launched everything (or seen the abort flag)
+    bu_host::pool().end();  // every item has finished; the feeder, if a pool thread took the role, has launched everything (or seen a flag)
+    if (!feeder_taken.exchange(true)) {  // nobody fed the GPU meanwhile: everything is decoded, launch it now
+        try {
+            st_feed = feeder();
+        } catch (...) {
+            st_feed = BU_ERR_HIP;
+        }
+    }
     lap("pool joined, bands launched");
+    if (trace) {
+        static const char* const names[] = {"resolve", "feed", "codebooks", "crc", "slice", "lex"};
+        for (size_t i = 0; i < items.size(); i++)
+            fprintf(stderr, "[bu_read_to]   item %2zu %-9s job %2zu (%5zu x %5zu)  %7.3f .. %7.3f ms\n", i, names[items[i].kind], items[i].job,
+                    items[i].kind >= I_SLICE || items[i].kind == I_RESOLVE ? jobs[items[i].job].nbx : (size_t)0,
+                    items[i].kind >= I_SLICE || items[i].kind == I_RESOLVE ? jobs[items[i].job].nby : (size_t)0, item_log[i].t0, item_log[i].t1);
+    }
     if (crc_pending && !crc_ok) return BU_ERR_DATA_CRC;
     if (st_cb) return st_cb;
     if (st_tables) return st_tables;

@@ -76,9 +76,9 @@ def test_streamed_etc1s_front_door_reports_errors_in_the_reference_order(ctx, or
     import basis_builder as bb
     import basisu_rs_amd as bu
 
-    # (the first slice is large enough for the two-thread decode: its give-up path -- decode again with the exact loop -- is what
-    # turns damage inside that slice into the reference's status)
-    f, _, _ = bb.etc1s_file(np.random.default_rng(77), [(256, 160), (128, 96)], n_codebook=512, history_size=16)
+    # (the first image's colour and alpha slices are large enough for the two-thread decode: its give-up path -- whichever half
+    # finishes second decodes the slice again with the exact loop -- is what turns damage inside them into the reference's status)
+    f, _, _ = bb.etc1s_file(np.random.default_rng(77), [(256, 160), (128, 96)], n_codebook=512, history_size=16, alpha=True)
     hdr = bu.read_header(f)
     rng = np.random.default_rng(5)
     spots = [hdr.endpoint_cb_file_ofs + 3, hdr.selector_cb_file_ofs + 1, hdr.tables_file_ofs + 2, hdr.tables_file_ofs + hdr.tables_file_size - 2]
