@@ -145,8 +145,10 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
 // so global loads and stores stay fully coalesced (1 KiB per wave instruction).
 //   LDS per workgroup: tile 16 B x BU_TILE + tables 5.9 KiB + 1 B x BU_TILE status + counters and the chunk list.
-// Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr),
-// BU_RUN_PIECE_MIB (piece size of the two-stream upload pipeline, 0 = off).
+// Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr, and
+// for the streamed ETC1S front door when every work item started and ended), BU_RUN_PIECE_MIB (piece size of the two-stream upload
+// pipeline, 0 = off), BU_ETC1S_ONE_LAUNCH (ETC1S files: decode everything, then one launch -- the round-3 path),
+// BU_ETC1S_ONE_THREAD (streamed ETC1S front door: every slice's symbol loop on one thread), BU_X_BCAP (tools/exp only).
 // inclusive add-scan over lanes 0..31 (and 32..63) with DPP row shifts: 5 VALU, no LDS round trips
 __device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
 {
