@@ -120,7 +120,9 @@ bu_status bu_transcode_uastc_block_to_etc2(bu_context* ctx, const uint8_t in[16]
  *                   min over failing blocks of (block_index << 8 | status); may be shared by several
  *                   launches whose block indices are disjoint (`block_index_base` is added)
  *   stream          hipStream_t
- * Returns launch/argument errors only; block errors arrive through d_status. */
+ * Returns launch/argument errors only; block errors arrive through d_status.
+ * This call, the batch call below and bu_status_word_reset only enqueue work on `stream` (nothing is allocated, copied from the host or
+ * synchronised behind them), so they may be recorded into a HIP graph by stream capture and replayed (tests/test_gpu_round4.py). */
 bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
                                     size_t blocks_per_row, uint64_t block_index_base, uint64_t* d_status, void* stream);
 /* A loop over independent slices (the per-slice loops of basis.rs:246-257) as ONE call: slice i = n_blocks[i] blocks at d_in[i]

@@ -174,3 +174,53 @@ def test_batch_entry_point_accepts_runs_of_any_length_beside_others(ctx, golden)
     torch.cuda.synchronize()
     for o, w in zip(outs, wants):
         assert torch.equal(o, w)
+
+
+def test_device_entry_points_can_be_captured_in_a_hip_graph(ctx, golden):
+    """bu_uastc_transcode_device, bu_uastc_transcode_batch_device and bu_status_word_reset only enqueue work on the caller's stream --
+    nothing is allocated, copied from the host or synchronised behind them -- so a caller may record them into a HIP graph and
+    replay it (tools/exp/graph_capture.py measures that: replaying 64 captured launches costs what launching them costs, the batch
+    entry point is the fast form).  Capture, three replays on re-zeroed outputs, a bad block reported through the captured status
+    word."""
+    import torch
+
+    lib = _lib.load()
+    ns, nb = 4, 4096
+    idx = [synth.gold_indices(nb, seed=70 + k) for k in range(ns)]
+    blocks = [golden["uastc"][i].copy() for i in idx]
+    blocks[2][100, 0] = 0x45  # the one invalid 7-bit mode code (69): block 2 * 4096 + 100 of the batch
+    ins = [torch.from_numpy(b).cuda() for b in blocks]
+    outs = [torch.zeros((nb, 16), dtype=torch.uint8, device="cuda") for _ in range(ns)]
+    status = torch.zeros(1, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    def record():
+        sp = ctypes.c_void_p(side.cuda_stream)
+        assert lib.bu_status_word_reset(ctx.handle, ctypes.c_void_p(status.data_ptr()), sp) == 0
+        for k in range(2):  # two slices as single launches, two through the batch entry point
+            assert lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(ins[k].data_ptr()), nb, ctypes.c_void_p(outs[k].data_ptr()), 64, k * nb,
+                                                 ctypes.c_void_p(status.data_ptr()), sp) == 0
+        base = (ctypes.c_uint64 * 2)(2 * nb, 3 * nb)
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, 2, (ctypes.c_void_p * 2)(ins[2].data_ptr(), ins[3].data_ptr()),
+                                                   (ctypes.c_size_t * 2)(nb, nb), (ctypes.c_void_p * 2)(outs[2].data_ptr(), outs[3].data_ptr()), 64, base,
+                                                   ctypes.c_void_p(status.data_ptr()), sp) == 0
+
+    with torch.cuda.stream(side):
+        record()  # (first use outside the capture: anything lazily created exists afterwards)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        record()
+    for _ in range(3):
+        for o in outs:
+            o.zero_()
+        status.fill_(0)
+        graph.replay()
+        torch.cuda.synchronize()
+        word = int(status.item()) & (2**64 - 1)
+        assert word == ((2 * nb + 100) << 8 | 1)  # first failing block of the batch, BU_ERR_INVALID_MODE
+        for k in (0, 1, 3):
+            assert torch.equal(outs[k], torch.from_numpy(golden["bc7"][idx[k]]).cuda())
+        want2 = golden["bc7"][idx[2]].copy()
+        want2[100] = 0  # a failing block leaves zeros
+        got2 = outs[2].cpu().numpy()
+        assert (got2[:100] == want2[:100]).all() and (got2[101:] == want2[101:]).all()
