@@ -107,6 +107,12 @@ constexpr bool bu_rect_compiled(int target, int tile)
                         : (tile == 4096 && (target == BU_TGT_ETC1 || target == BU_TGT_ETC2));
 }
 
+// experiment (round 4): BC7 / ASTC launches of one tile per workgroup load their tile straight into LDS (kernel, GLDS)
+#ifdef BU_X_GLDS
+constexpr bool BU_GLDS_ON = true;
+#else
+constexpr bool BU_GLDS_ON = false;
+#endif
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
                           uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0)
@@ -170,6 +176,18 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
             if (btiles % C::NT == 0 && btiles / C::NT <= bcap && rect_ok((size_t)C::WGS * C::BPT / RW)) {                               \
                 hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_RECT, C::NT>), dim3((unsigned)(btiles / C::NT)), \
                                    dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, rect_magic BU_STAMP_PASS); \
+                break;                                                                                                                  \
+            }                                                                                                                           \
+        }                                                                                                                               \
+        if constexpr (BU_GLDS_ON && ((T) == BU_TGT_BC7 || (T) == BU_TGT_ASTC) && C::WGS * C::BPT == 1024) {                            \
+            /* one tile per workgroup: the tile goes straight into LDS (kernel, GLDS) */                                               \
+            if (btiles <= bcap) {                                                                                                       \
+                if (rect_ok((size_t)1024 / RW))                                                                                         \
+                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_RECT, 1, true>), dim3((unsigned)btiles), \
+                                       dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, rect_magic BU_STAMP_PASS); \
+                else                                                                                                                    \
+                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_STRIP, 1, true>), dim3((unsigned)btiles), \
+                                       dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, 1024u BU_STAMP_PASS); \
                 break;                                                                                                                  \
             }                                                                                                                           \
         }                                                                                                                               \

@@ -271,7 +271,8 @@ struct BuTileDesc {
     uint64_t base;
 };
 enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1>
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1,
+          bool GLDS = false>
 __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                      unsigned bpr, unsigned long long base, unsigned long long* status,
                                                      const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
@@ -333,7 +334,14 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // byte: BC7's unary mode prefix, ASTC's block mode / void-extent marker), the other targets in a byte per block
     constexpr bool INBLOCK = (TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC) && !DIRECT;
     __shared__ uint8_t sst[(DIRECT || INBLOCK) ? 16 : BU_TILE];
-    __shared__ uint16_t sorig[DIRECT ? BU_TILE : 16];
+    // GLDS (round 4): the tile goes from global memory straight into LDS (global_load_lds_dwordx4: no VGPRs, no ds_write_b128), in
+    // ORIGINAL order -- the LDS address of such a load is wave-uniform base + lane * 16, it cannot scatter.  The sort then moves
+    // 2-byte indices instead of 16-byte blocks: `sorig[sorted slot]` = the block's place in the tile; a chunk lane reads its block
+    // through it, and writes the result back to the SAME place, so the write-back phase reads LDS in order.  One tile per workgroup
+    // (the launcher's one-tile grids); BC7 and ASTC (status inside the result slot).
+    static_assert(!GLDS || ((TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC) && !PREFETCH && !DIRECT && NT == 1 && LAYOUT != BU_LAYOUT_MULTI),
+                  "direct-to-LDS tile loads: BC7 / ASTC, one tile per workgroup");
+    __shared__ uint16_t sorig[(DIRECT || GLDS) ? BU_TILE : 16];
     // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
     // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
     __shared__ uint32_t cnt[2][32], next_chunk[2];
@@ -424,9 +432,23 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     else if (bu_gen == 3) __builtin_amdgcn_s_sleep(BU_X_STAG3);
 #endif
     uint4 v[BU_BPT];
+    if constexpr (GLDS) {
+        typedef const __attribute__((address_space(1))) void* bu_gptr;
+        typedef __attribute__((address_space(3))) void* bu_lptr;
+#ifndef BU_X_GLDS_AUX
+#define BU_X_GLDS_AUX 0
+#endif
 #pragma unroll
-    for (int j = 0; j < BU_BPT; j++)
-        v[j] = (RECT || blk_valid(tile, j * BU_WG + tid)) ? bu_ld_stream(blk_src(tile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
+        for (int j = 0; j < BU_BPT; j++) {
+            v[j] = make_uint4(0, 0, 0, 0);
+            if (RECT || blk_valid(tile, j * BU_WG + tid))  // (lanes without a block: exec off, their LDS slot keeps whatever it held)
+                __builtin_amdgcn_global_load_lds((bu_gptr)blk_src(tile, j * BU_WG + tid), (bu_lptr)(sblk + j * BU_WG + (tid & ~63u)), 16, 0, BU_X_GLDS_AUX);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < BU_BPT; j++)
+            v[j] = (RECT || blk_valid(tile, j * BU_WG + tid)) ? bu_ld_stream(blk_src(tile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
+    }
     uint4 vq[NT > 1 ? NT - 1 : 1][BU_BPT];
     if constexpr (NT > 1) {
 #pragma unroll
@@ -469,6 +491,10 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             const bool valid = RECT || (MULTI ? (unsigned)(j * BU_WG) + tid < td.n : (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid)));  // (RECT: whole tiles only)
+            if constexpr (GLDS) {
+                if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's own two blocks have landed in LDS
+                v[j].x = valid ? sblk[j * BU_WG + tid].x : 0u;
+            }
             key[j] = valid ? T.key_lut[TARGET][v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
@@ -511,8 +537,8 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             const uint32_t st = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key[j] << 2), (int)run_excl) & 0xFFFFu;
             dest[j] = has_block(key[j]) ? st + pos[j] : 0u;
             if (has_block(key[j])) {
-                sblk[dest[j]] = v[j];
-                if constexpr (DIRECT) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
+                if constexpr (!GLDS) sblk[dest[j]] = v[j];
+                if constexpr (DIRECT || GLDS) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
             }
         }
         // prefetch the next tile while this one is transcoded
@@ -546,7 +572,8 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             const uint32_t s0 = (r_ex & 0xFFFFu) + k64, left = (r_pk & 0xFFFFu) - k64, count = left < 64u ? left : 64u;
             const bool active = lane < count;
             const uint32_t slot = s0 + (active ? lane : 0u);
-            const uint4 bv = sblk[slot];
+            const uint32_t bslot = GLDS ? (uint32_t)sorig[slot] : slot;  // where the block is, and where its result goes
+            const uint4 bv = sblk[bslot];
             BuBlk b;
             b.w[0] = bv.x;
             b.w[1] = bv.y;
@@ -591,7 +618,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                     for (int r2 = 0; r2 < 4; r2++) sout[r2 * BU_TILE + slot] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
                     sst[slot] = (uint8_t)st;
                 } else if constexpr (INBLOCK) {
-                    sblk[slot] = make_uint4(o[0], o[1], o[2], o[3] | (uint32_t)st);  // (a failing block's o[] is all zeros)
+                    sblk[bslot] = make_uint4(o[0], o[1], o[2], o[3] | (uint32_t)st);  // (a failing block's o[] is all zeros)
                 } else {
                     sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
                     sst[slot] = (uint8_t)st;
@@ -613,7 +640,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                     void* const out = td.out;                  // (the launch's `out` unless MULTI)
                     const unsigned long long base = td.base;
                     if constexpr (INBLOCK) {
-                        uint4 r = sblk[dest[j]];
+                        uint4 r = sblk[GLDS ? (uint32_t)(j * BU_WG + tid) : dest[j]];
                         if ((r.x & 0xFFu) == 0u) {  // no valid block of these formats starts with a zero byte: word 3 is the status
                             bu_report(status, base + idx, (int)r.w);
                             r.w = 0;
@@ -656,6 +683,17 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
+        } else if constexpr (GLDS) {
+            // (a workgroup that walks several tiles: the next tile may only land once every result of this one has left LDS)
+            if (ntile < n_tiles) {
+                typedef const __attribute__((address_space(1))) void* bu_gptr;
+                typedef __attribute__((address_space(3))) void* bu_lptr;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < BU_BPT; j++)
+                    if (RECT || blk_valid(ntile, j * BU_WG + tid))
+                        __builtin_amdgcn_global_load_lds((bu_gptr)blk_src(ntile, j * BU_WG + tid), (bu_lptr)(sblk + j * BU_WG + (tid & ~63u)), 16, 0, BU_X_GLDS_AUX);
+            }
         } else {
             load_desc(ntile);
 #pragma unroll
@@ -668,13 +706,14 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     }
 }
 
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1>
+template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1,
+          bool GLDS = false>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
                                                                 const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
 {
     static_assert(LAYOUT != BU_LAYOUT_MULTI, "several runs per launch: bu_uastc_multi_kernel");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, MINW, PREFETCH, DIRECT, SKEW, LAYOUT, NT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr BU_STAMP_FWD);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, MINW, PREFETCH, DIRECT, SKEW, LAYOUT, NT, GLDS>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr BU_STAMP_FWD);
 }
 
 // several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value)
