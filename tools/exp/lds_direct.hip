@@ -21,6 +21,24 @@ __global__ __launch_bounds__(512) void tilek(const uint4* __restrict__ in, uint4
     __shared__ uint4 tile[1024 + 768];  // 28 KiB: four workgroups per CU, as the BC7 kernel
     const unsigned tid = threadIdx.x, wave = tid >> 6;
     const size_t base = (size_t)blockIdx.x * 1024;
+    if constexpr (MODE == 8 || MODE == 9) {
+        // half of the waves move four blocks per lane, the other half nothing (MODE 9: they still stage 8 KiB into LDS, like tables)
+        if (wave >= 4) {
+            if constexpr (MODE == 9) {
+                tile[1024 + (tid - 256)] = in[tid & 255u];
+                tile[1024 + 256 + (tid - 256)] = in[256 + (tid & 255u)];
+                __syncthreads();
+            }
+            return;
+        }
+        uint4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = ldnt(in + base + k * 256 + tid);
+        if constexpr (MODE == 9) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) stnt(out + base + k * 256 + tid, q[k]);
+        return;
+    }
     if constexpr (MODE == 0) {
         const uint4 a = ldnt(in + base + tid), b = ldnt(in + base + 512 + tid);
         stnt(out + base + tid, a);
@@ -85,5 +103,8 @@ int main()
         printf("plain %.2f | one trip: regs_seq %.2f regs_perm %.2f direct_seq %.2f direct_perm %.2f | two trips: regs_seq %.2f regs_perm %.2f direct+regs_perm %.2f  (us per launch)\n",
                timeit<0>(in, out, n, 256), timeit<1>(in, out, n, 256), timeit<2>(in, out, n, 256), timeit<3>(in, out, n, 256), timeit<4>(in, out, n, 256),
                timeit<5>(in, out, n, 256), timeit<6>(in, out, n, 256), timeit<7>(in, out, n, 256));
+    for (int round = 0; round < 3; round++)
+        printf("512-thread workgroups on 1024-block tiles: every wave moves 2 blocks per lane %.2f | waves 0-3 move 4 per lane, waves 4-7 exit %.2f | ... waves 4-7 stage 8 KiB into LDS, one barrier %.2f\n",
+               timeit<0>(in, out, n, 256), timeit<8>(in, out, n, 256), timeit<9>(in, out, n, 256));
     return 0;
 }
