@@ -19,7 +19,7 @@ SYMBOLS = [
     "bu_context_create", "bu_context_destroy", "bu_status_string", "bu_last_error", "bu_target_block_bytes",
     "bu_uastc_transcode", "bu_uastc_decode_to_rgba",
     "bu_unpack_uastc_block_to_rgba", "bu_transcode_uastc_block_to_astc", "bu_transcode_uastc_block_to_bc7",
-    "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2", "bu_block_api_on_device",
+    "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2", "bu_block_api_on_device", "bu_context_set_launch_policy", "bu_context_get_launch_policy", "bu_context_stream",
     "bu_uastc_transcode_device", "bu_uastc_transcode_batch_device", "bu_status_word_reset", "bu_status_word_decode", "bu_host_alloc", "bu_host_free",
     "bu_etc1s_selector_from_rows", "bu_etc1s_transcode_etc1_device", "bu_etc1s_decode_rgba_device",
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
@@ -28,7 +28,7 @@ SYMBOLS = [
     "bu_comm_unique_id", "bu_comm_create", "bu_comm_destroy", "bu_comm_query", "bu_allgather_inplace",
     "bu_ipc_export", "bu_ipc_open", "bu_ipc_close", "bu_allgather_peer", "bu_array_transcode_sharded",
     "bu_device_alloc", "bu_device_free", "bu_memcpy",
-    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_window", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_copy_launches", "bu_time_block_api",
+    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_window", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_uastc_launches_streams_window", "bu_time_copy_launches", "bu_time_block_api",
 ]
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
@@ -102,6 +102,12 @@ def load():
         getattr(lib, name).restype = c.c_int
     lib.bu_time_block_api.argtypes = [vp, c.c_int, vp, sz, c.c_int, vp, c.POINTER(c.c_float)]
     lib.bu_time_block_api.restype = c.c_int
+    lib.bu_context_set_launch_policy.argtypes = [vp, c.c_int]
+    lib.bu_context_set_launch_policy.restype = c.c_int
+    lib.bu_context_get_launch_policy.argtypes = [vp, c.POINTER(c.c_int)]
+    lib.bu_context_get_launch_policy.restype = c.c_int
+    lib.bu_context_stream.argtypes = [vp, c.c_int, c.POINTER(vp)]
+    lib.bu_context_stream.restype = c.c_int
     lib.bu_block_api_on_device.argtypes = [vp, c.c_int]
     lib.bu_block_api_on_device.restype = c.c_int
     lib.bu_uastc_transcode_device.argtypes = [vp, c.c_int, vp, sz, vp, sz, c.c_uint64, vp, vp]
@@ -179,6 +185,9 @@ def load():
     lib.bu_memcpy.restype = c.c_int
     lib.bu_time_uastc_launches_streams.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, c.c_int, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches_streams.restype = c.c_int
+    lib.bu_time_uastc_launches_streams_window.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, c.c_int, c.c_int, vp,
+                                                          c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_int)]
+    lib.bu_time_uastc_launches_streams_window.restype = c.c_int
     lib.bu_time_copy_launches.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, c.POINTER(c.c_float)]
     lib.bu_time_copy_launches.restype = c.c_int
     _lib = lib

@@ -124,6 +124,17 @@ class Context:
         self._check(st, bad)
         return out[: n * 64]
 
+    def set_launch_policy(self, shared):
+        """False (default) = BU_LAUNCH_EXCLUSIVE: a large launch fills the chip by itself; True = BU_LAUNCH_SHARED: it keeps at most half
+        of every CU so that launches queued on different streams run side by side (include/basisu_hip.h)."""
+        self._check(self._lib.bu_context_set_launch_policy(self._h, 1 if shared else 0))
+
+    def stream(self, index):
+        """the context's own stream `index` (0..7) as a raw hipStream_t value; streams 0..3 sit on different hardware queues"""
+        p = ctypes.c_void_p(0)
+        self._check(self._lib.bu_context_stream(self._h, int(index), ctypes.byref(p)))
+        return p.value
+
     def block_api_on_device(self, enable):
         """Per-block API: False (default) = the library's own block code on the calling thread, True = a one-block kernel launch."""
         self._check(self._lib.bu_block_api_on_device(self._h, 1 if enable else 0))

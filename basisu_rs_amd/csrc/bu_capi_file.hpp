@@ -714,7 +714,10 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                 }
                 if (target != BU_READ_RGBA && direct_out && piece_bytes && run_bytes >= 2 * piece_bytes) {
                     pieced = true;
-                    if (!ctx->extra_streams[0]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[0], hipStreamNonBlocking));
+                    {
+                        const bu_status sst = bu_ctx_streams(ctx, 1);
+                        if (sst) return sst;
+                    }
                     if (!used_extra) {
                         BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));  // the status words are reset on the context stream
                         BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[0], ctx->ev0, 0));

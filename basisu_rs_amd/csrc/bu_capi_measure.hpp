@@ -123,8 +123,10 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
 {
     if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || !out_ms || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
     BU_HIP(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < n_streams; i++)
-        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
+    {
+        const bu_status sst = bu_ctx_streams(ctx, n_streams);
+        if (sst) return sst;
+    }
     BU_HIP(ctx, hipDeviceSynchronize());
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < launches; i++) {
@@ -134,6 +136,95 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
     }
     BU_HIP(ctx, hipDeviceSynchronize());
     *out_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return BU_OK;
+}
+
+// The window of bu_time_uastc_launches_window with SEVERAL launches in flight: launch i (lead and timed alike) goes to context
+// stream i % n_streams, everything is enqueued up front with no host synchronisation in between.  Streams advance independently, so the
+// window is taken over ALL of them: every stream gets a start event directly in front of its first timed launch and an end event
+// behind its last one, and
+//     event_ms = (latest end event) - (earliest start event)
+// on the device's clock (each measured from one reference event at the head of the call, which every stream waits for before its
+// first launch).  The window therefore opens on a full pipeline -- the other streams are in the middle of lead launches when the first
+// start event fires -- covers every timed launch from its first instruction to its last, and holds the drain of the pipeline (the final
+// launches running with fewer partners).  If the streams drift apart the window only gets LONGER (it then also spans lead launches of
+// the streams that lag).  host_ms = steady clock from "a start event first seen complete" to "every end event seen complete".
+// n_streams == 1 is bu_time_uastc_launches_window on a context stream.
+bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                                size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches, int n_streams,
+                                                uint64_t* d_status, float* out_event_ms, float* out_host_ms, int* out_late)
+{
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || lead < 0 || !out_event_ms || !out_host_ms || n_streams < 1 || n_streams > 8)
+        return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        const bu_status sst = bu_ctx_streams(ctx, n_streams);
+        if (sst) return sst;
+    }
+    for (int i = 0; i < n_streams; i++) {
+        if (!ctx->ev_start[i]) BU_HIP(ctx, hipEventCreate(&ctx->ev_start[i]));
+        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreate(&ctx->ev_end[i]));
+    }
+    BuDrain drain(ctx);
+    BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->extra_streams[0]));  // the reference point of every time below
+    for (int i = 1; i < n_streams; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
+    bool used[8] = {false, false, false, false, false, false, false, false};
+    for (int i = 0; i < lead + launches; i++) {
+        const int si = i % n_streams;
+        hipStream_t s = ctx->extra_streams[si];
+        if (i >= lead && !used[si]) {
+            BU_HIP(ctx, hipEventRecord(ctx->ev_start[si], s));
+            used[si] = true;
+        }
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
+        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, s);
+        if (st) return st;
+    }
+    for (int i = 0; i < n_streams; i++)
+        if (used[i]) BU_HIP(ctx, hipEventRecord(ctx->ev_end[i], ctx->extra_streams[i]));
+    // host bracket: from the first start event seen complete ...
+    std::chrono::steady_clock::time_point t0, t1, t;
+    {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(BU_SPIN_SECONDS);
+        bool seen = false;
+        for (unsigned n = 0; !seen; n++) {
+            for (int i = 0; i < n_streams && !seen; i++) {
+                if (!used[i]) continue;
+                const hipError_t q = hipEventQuery(ctx->ev_start[i]);
+                if (q == hipSuccess) seen = true;
+                else if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
+            }
+            if (n == 0 && out_late) *out_late = seen ? 1 : 0;
+            if (!seen && (n & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) {
+                snprintf(ctx->err, sizeof(ctx->err), "hipEventQuery: no start event after %.0f s", BU_SPIN_SECONDS);
+                return BU_ERR_HIP;
+            }
+        }
+        t0 = std::chrono::steady_clock::now();
+        (void)hipGetLastError();
+    }
+    // ... to the last end event seen complete; device clock: latest end - earliest start, both measured from the reference event
+    t1 = t0;
+    float first_start = 0, last_end = 0;
+    bool any = false;
+    for (int i = 0; i < n_streams; i++) {
+        if (!used[i]) continue;
+        bu_status st = bu_spin_event(ctx, ctx->ev_end[i], &t);
+        if (st) return st;
+        if (t > t1) t1 = t;
+        float ms_s = 0, ms_e = 0;
+        BU_HIP(ctx, hipEventElapsedTime(&ms_s, ctx->ev0, ctx->ev_start[i]));
+        BU_HIP(ctx, hipEventElapsedTime(&ms_e, ctx->ev0, ctx->ev_end[i]));
+        if (!any || ms_s < first_start) first_start = ms_s;
+        if (!any || ms_e > last_end) last_end = ms_e;
+        any = true;
+    }
+    // (lead launches on streams that carry no timed launch -- more streams than timed launches -- finish before we return)
+    for (int i = 0; i < n_streams; i++)
+        if (!used[i]) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[i]));
+    drain.armed = false;
+    *out_host_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    *out_event_ms = last_end - first_start;
     return BU_OK;
 }
 

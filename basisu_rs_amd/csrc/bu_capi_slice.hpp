@@ -121,6 +121,10 @@ void bu_context_destroy(bu_context* ctx)
     free(ctx->lex_buf);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->ev_start)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_end)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (hipStream_t es : ctx->extra_streams)
         if (es) (void)hipStreamDestroy(es);
@@ -242,23 +246,20 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
         const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
         const size_t cap = (size_t)ctx->cu_count * 7;  // beyond seven workgroups per CU they walk the tiles (as bu_launch_uastc)
         const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
-#define BU_GO_MULTI(T)                                                                                                                      \
-    do {                                                                                                                                    \
-        if (one_per_cu)                                                                                                                     \
-            hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw,     \
-                               ctx->d_tables BU_STAMP_PASS);                                                                                \
-        else                                                                                                                                \
-            hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw,       \
-                               ctx->d_tables BU_STAMP_PASS);                                                                                \
-    } while (0)
+        auto go = [&](auto tgt) {
+            constexpr int T = decltype(tgt)::value;
+            if (one_per_cu)
+                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
+            else
+                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
+        };
         switch (target) {
-        case BU_TARGET_ASTC: BU_GO_MULTI(BU_TGT_ASTC); break;
-        case BU_TARGET_BC7: BU_GO_MULTI(BU_TGT_BC7); break;
-        case BU_TARGET_ETC1: BU_GO_MULTI(BU_TGT_ETC1); break;
-        case BU_TARGET_ETC2: BU_GO_MULTI(BU_TGT_ETC2); break;
-        default: BU_GO_MULTI(BU_TGT_RGBA); break;
+        case BU_TARGET_ASTC: go(std::integral_constant<int, BU_TGT_ASTC>()); break;
+        case BU_TARGET_BC7: go(std::integral_constant<int, BU_TGT_BC7>()); break;
+        case BU_TARGET_ETC1: go(std::integral_constant<int, BU_TGT_ETC1>()); break;
+        case BU_TARGET_ETC2: go(std::integral_constant<int, BU_TGT_ETC2>()); break;
+        default: go(std::integral_constant<int, BU_TGT_RGBA>()); break;
         }
-#undef BU_GO_MULTI
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return bu_fail(ctx, e, "multi-run launch");
         r0 += k;
@@ -281,6 +282,30 @@ bu_status bu_uastc_decode_to_rgba(bu_context* ctx, const uint8_t* in, size_t in_
     // (Rust panics there), so require whole block rows
     if (in_bytes % 16 == 0 && (in_bytes / 16) % blocks_per_row != 0) return BU_ERR_ARGUMENT;
     return bu_uastc_host(ctx, BU_TARGET_RGBA32, in, in_bytes, blocks_per_row, out, out_bytes, first_bad_block);
+}
+
+// ---- launch policy of the slice-level device entry points (include/basisu_hip.h; shapes: bu_context.hpp, BuBigShape) ----
+bu_status bu_context_set_launch_policy(bu_context* ctx, bu_launch_policy policy)
+{
+    if (!ctx || (policy != BU_LAUNCH_EXCLUSIVE && policy != BU_LAUNCH_SHARED)) return BU_ERR_ARGUMENT;
+    ctx->launch_policy.store(policy == BU_LAUNCH_SHARED ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE, std::memory_order_relaxed);
+    return BU_OK;
+}
+bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* out_policy)
+{
+    if (!ctx || !out_policy) return BU_ERR_ARGUMENT;
+    *out_policy = ctx->launch_policy.load(std::memory_order_relaxed) == BU_POLICY_SHARED ? BU_LAUNCH_SHARED : BU_LAUNCH_EXCLUSIVE;
+    return BU_OK;
+}
+
+bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream)
+{
+    if (!ctx || !out_stream || index < 0 || index >= 8) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    const bu_status st = bu_ctx_streams(ctx, index + 1);
+    if (st) return st;
+    *out_stream = ctx->extra_streams[index];
+    return BU_OK;
 }
 
 // ---- per-block API (lib.rs:29-53) -----------------------------------------------------------------------------------------------

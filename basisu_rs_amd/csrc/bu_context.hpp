@@ -22,10 +22,14 @@ struct bu_context {
     size_t h_idx_cap = 0;
     unsigned long long* d_status = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_start[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per-stream events of bu_time_uastc_launches_streams_window
+    hipEvent_t ev_end[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::atomic<int> launch_policy{0};  // BU_POLICY_*: how much of a CU one large launch of the mode-sorted kernel takes (bu_context_set_launch_policy)
     std::atomic<bool> block_api_on_device{false};  // per-block API: host build of the block code (default) or a 1-block launch
     size_t etc1s_lds_limit = 0;  // what the device reports a workgroup may use, less a margin (bu_context_create)
     std::atomic<size_t> etc1s_lds_state[2] = {{0}, {0}};  // bu_etc1s_staged_kernel<false / true>: 0 not asked, 1 refused, else dynamic LDS bytes granted
+    std::mutex stream_lock;  // creation of extra_streams (bu_ctx_streams)
     std::mutex lock;  // host-pointer entry points share the staging buffers
     char err[256] = {0};
 };
@@ -59,6 +63,40 @@ struct BuDrain {
     }
 };
 
+// The context's own streams 0..n-1 (n <= 8), created on first use.  The HIP runtime multiplexes a process's streams over a small pool
+// of hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), and launches on two streams that share a hardware queue
+// run one after the other exactly as on one stream (kernel trace, profiles/r05_streams_sharing_a_hardware_queue_serialise.txt: with
+// six streams at one priority in a process whose default stream and context stream already hold two queues, four of them shared two
+// queues and "4 launches in flight" ran as 2).  So the streams are spread over the priority levels in pairs -- 0, 1 normal; 2, 3 high;
+// 4, 5 low; 6, 7 normal -- which puts streams 0..3 (what the multi-stream callers use) on four different queues with the runtime's
+// defaults; measured the same as GPU_MAX_HW_QUEUES=8 with every stream at normal priority (BC7, 4 in flight: 6.04-6.23 against
+// 5.94-6.21 us per atlas).  The priorities only decide whose workgroups the dispatcher places first; nothing here depends on them.
+bu_status bu_ctx_streams(bu_context* ctx, int n)
+{
+    if (n < 0 || n > 8) return BU_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> g(ctx->stream_lock);
+    int least = 0, greatest = 0;
+    bool have_range = false;
+    for (int i = 0; i < n; i++) {
+        if (ctx->extra_streams[i]) continue;
+        if (!have_range) {
+            BU_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            have_range = true;
+        }
+        const int level = (i / 2) % 3;  // 0 normal, 1 high, 2 low
+        const int prio = level == 1 ? greatest : (level == 2 ? least : (least + greatest) / 2);
+        const char* tm = getenv("BU_TEST_STREAMS");
+        const int mode = tm ? atoi(tm) : 1;
+        if (mode == 2) {
+            uint32_t mask[16];
+            for (auto& m : mask) m = 0xFFFFFFFFu;
+            BU_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->extra_streams[i], (uint32_t)((ctx->cu_count + 31) / 32), mask));
+        } else
+        BU_HIP(ctx, hipStreamCreateWithPriority(&ctx->extra_streams[i], hipStreamNonBlocking, mode == 1 ? prio : (least + greatest) / 2));
+    }
+    return BU_OK;
+}
+
 bu_status bu_reserve(bu_context* ctx, void** p, size_t* cap, size_t need)
 {
     if (need <= *cap) return BU_OK;
@@ -86,33 +124,135 @@ size_t bu_balanced_tile(size_t max_tile, size_t n_blocks, size_t slots, bool dyn
     return t < 64 ? 64 : (t > max_tile ? max_tile : t);
 }
 
-// experiment knob (tools/exp): BU_X_BCAP = workgroups per launch of the big shapes as a multiple of the resident set (0 = one tile
-// per workgroup, whatever the size); unset = the resident set (persistent workgroups walk their tiles with prefetch)
-inline size_t bu_x_bcap(size_t resident)
+// ---- shapes of the mode-sorted kernel ------------------------------------------------------------------------------------------
+// One BuShape = one compiled instantiation of bu_uastc_sorted_kernel (strip layout, plus the rectangular layout where RECT is set):
+// WGS threads x BPT blocks per thread = one tile; MINW = waves per SIMD the register allocation leaves room for; PER_CU = how many
+// workgroups of ONE launch may be resident on a CU (the grid of a large launch is min(tiles, PER_CU x CUs); workgroups walk the
+// remaining tiles, with the next tile's loads in flight where PREFETCH is set).
+template <int W, int B, int MINW_, bool PF, bool RECT_, int PER_CU_>
+struct BuShape {
+    static constexpr int WGS = W, BPT = B, MINW = MINW_, PER_CU = PER_CU_, TILE = W * B;
+    static constexpr bool PREFETCH = PF, RECT = RECT_;
+};
+// The shape of a LARGE launch (more than one 1024-block tile per CU; ETC: more than three) per target and launch policy.
+//
+// BU_LAUNCH_EXCLUSIVE -- the launch is alone on the chip and must fill it by itself (rounds 1-4; every figure an A/B inside one run
+// on a 4096^2 atlas = 4096 blocks per CU, DESIGN_HISTORY.md section 4 and profiles/r04_ab_bc7_tile_shapes_and_upfront_loads.txt):
+//   BC7 / ASTC  512 x 2, four workgroups per CU = 32 waves, <= 64 VGPRs.  Four INDEPENDENT sort chains per CU hide each other's
+//               barriers and LDS round trips; 2048-block tiles +10 %, 4096 +35 %, 256 x 4 four per CU +18 %.
+//   ETC1 / ETC2 one 1024-thread workgroup per CU on a tile of up to 4096 blocks (99 / 121 VGPRs: 16 waves are all that fit);
+//               73 chunks per 4096 blocks where two 2048-block tiles have 83.
+//   RGBA32      1024-block tiles (64 KiB of LDS for the four pixel rows), two workgroups per CU, 1024 x 1 up to 3 Mi blocks then 512 x 2.
+// BU_LAUNCH_SHARED -- several launches from different streams are in flight and should run SIDE BY SIDE on every CU, so that one
+// launch's load phase (3.4 us with the vector ALUs idle when it is alone) lies under another one's chunk phase (ALUs saturated, HBM
+// idle).  A launch takes at most half of a CU's wave slots, registers and LDS (round 5, profiles/r05_ab_*_shapes_x_streams*.txt;
+// us per 4096^2 atlas with 1 / 2 / 3 / 4 launches in flight):
+//   BC7 / ASTC  256 x 4, two per CU (8 waves, 56 KiB)              11.8 / 7.35 / 6.25 / 5.95   (exclusive shape: 8.5 / 6.7 / 6.3 / 6.5)
+//   ETC1        512 x 4, one per CU (8 waves, <= 128 VGPRs, 63 KiB) 20.1 / 13.3 / 12.2 / 12.4   (17.7 / 15.5 / 15.2 / 15.7)
+//   ETC2        the same without the prefetch (115 VGPRs)           25.4 / 16.4 / 15.2 / 15.2   (22.1 / 19.7 / 19.3 / 20.4)
+// Alone on the chip a shared-policy launch is 15-40 % slower than an exclusive one: the policy is for callers that keep >= 2
+// streams busy (bu_context_set_launch_policy).
+enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1 };
+template <int TARGET, int POLICY> struct BuBigShape;
+template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_EXCLUSIVE> : BuShape<512, 2, 1, true, true, 4> {};
+template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_SHARED> : BuShape<256, 4, 1, true, true, 2> {};
+template <> struct BuBigShape<BU_TGT_ASTC, BU_POLICY_EXCLUSIVE> : BuShape<512, 2, 1, true, true, 4> {};
+template <> struct BuBigShape<BU_TGT_ASTC, BU_POLICY_SHARED> : BuShape<256, 4, 1, true, true, 2> {};
+template <> struct BuBigShape<BU_TGT_ETC1, BU_POLICY_EXCLUSIVE> : BuShape<1024, 4, 1, true, true, 1> {};
+template <> struct BuBigShape<BU_TGT_ETC1, BU_POLICY_SHARED> : BuShape<512, 4, 4, true, true, 1> {};
+template <> struct BuBigShape<BU_TGT_ETC2, BU_POLICY_EXCLUSIVE> : BuShape<1024, 4, 1, true, true, 1> {};
+template <> struct BuBigShape<BU_TGT_ETC2, BU_POLICY_SHARED> : BuShape<512, 4, 4, false, true, 1> {};
+// BC7 / ASTC use their large shape from the first tile beyond one per CU (8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us,
+// 2^18 8.1 -> 6.3 us); ETC1 / ETC2 keep every tile of the 512 x 2 shape resident up to three 1024-block tiles per CU (2^19 blocks:
+// 12.7 against 18.2 us for the 4096-block shape, 786 432: 16.7 / 18.6) and switch beyond it (917 504 blocks: 21.5 against 18.9 us)
+constexpr bool bu_big_from_one_tile_per_cu(int target) { return target == BU_TGT_BC7 || target == BU_TGT_ASTC; }
+// the shapes below the large ones, the same under both policies:
+//   at most one 1024-block tile per CU: 16 waves on it (BC7 1 Ki blocks 4.32 -> 3.92 us, 2^16 5.16 -> 4.80, 2^18 5.70 -> 5.41; ETC1 6.76 -> 6.47, 7.95 -> 7.64, 8.82 -> 8.54)
+template <int TARGET> using BuOneTileShape = BuShape<1024, 1, 1, false, (TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC), 1>;
+//   ETC, up to three tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us)
+using BuEtcMidShape = BuShape<512, 2, 1, false, false, 3>;
+//   zero-copy launches over PCIe (grid_cap): 256 x 4 on a small persistent grid
+using BuZeroCopyShape = BuShape<256, 4, 1, true, false, 1>;
+constexpr int BU_HOST_TILE = 1024;  // the tile the launcher counts in where the shape does not say otherwise
+
+// one piece (<= 2^26 blocks) of a slice, as the mode-sorted kernel takes it
+struct BuPiece {
+    const uint4* in;
+    void* out;
+    size_t nb, bpr;
+    unsigned long long base;
+    unsigned long long* status;
+    const BuTablesAll* tables;
+    hipStream_t stream;
+    bool rect_rows;       // blocks_per_row allows rectangular tiles at all: a multiple of 64, at least two tiles wide, below 2^21
+    size_t rect_quantum;  // every piece of the slice is a multiple of (rows per tile x blocks_per_row) for rows per tile dividing this
+    unsigned rect_magic;  // ceil(2^32 / tiles per row): the kernel's tile -> (row, column) reciprocal
+    // Rectangular tiles (kernel, RECT): the caller told us the block grid, it is a multiple of 64 wide and the piece -- and every
+    // other piece of the slice -- is whole rows of tiles `rows` blocks high
+    bool rect_ok(size_t rows) const { return rect_rows && nb % (rows * bpr) == 0 && (rect_quantum == 0 || rect_quantum % (rows * bpr) == 0); }
+};
+
+template <int TARGET, class S>
+void bu_go(const BuPiece& p, unsigned grid, unsigned cus, unsigned tile_rt)
 {
-    static const long mult = [] {
-        const char* e = getenv("BU_X_BCAP");
-        return e ? atol(e) : 1L;
-    }();
-    return mult <= 0 ? (size_t)1 << 40 : resident * (size_t)mult;
+    if constexpr (S::RECT) {
+        // (a shape that sizes its tile at run time is rectangular only when that size is the full tile)
+        if (p.rect_ok((size_t)S::TILE / BU_RECT_W) && (!bu_dyn_tile(TARGET, S::TILE) || tile_rt == (unsigned)S::TILE)) {
+            hipLaunchKernelGGL((bu_uastc_sorted_kernel<TARGET, S::WGS, S::BPT, S::MINW, S::PREFETCH, BU_LAYOUT_RECT>), dim3(grid), dim3(S::WGS), 0, p.stream, p.in,
+                               p.out, (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, p.rect_magic);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((bu_uastc_sorted_kernel<TARGET, S::WGS, S::BPT, S::MINW, S::PREFETCH, BU_LAYOUT_STRIP>), dim3(grid), dim3(S::WGS), 0, p.stream, p.in, p.out,
+                       (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, tile_rt);
 }
 
-// shapes that are also compiled with rectangular tiles (bu_uastc_sorted_kernel, RECT): the 1024-block tiles (64 x 16 blocks) of
-// BC7, ASTC and RGBA32, the 4096-block tiles (64 x 64) of ETC1 and ETC2
-constexpr bool bu_rect_compiled(int target, int tile)
+// a large launch in shape S: persistent workgroups, PER_CU per CU, walking equal shares of the tiles
+template <int TARGET, class S>
+void bu_go_big(const BuPiece& p, unsigned cu_count)
 {
-    if (target == BU_TGT_BC7 && tile == BuBigCfg<BU_TGT_BC7>::WGS * BuBigCfg<BU_TGT_BC7>::BPT) return true;
-    if ((target == BU_TGT_ETC1 || target == BU_TGT_ETC2) && tile == BuBigCfg<BU_TGT_ETC1>::WGS * BuBigCfg<BU_TGT_ETC1>::BPT) return true;
-    return tile == 1024 ? (target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA)
-                        : (tile == 4096 && (target == BU_TGT_ETC1 || target == BU_TGT_ETC2));
+    const size_t slots = (size_t)cu_count * S::PER_CU;
+    const size_t tile_rt = bu_balanced_tile((size_t)S::TILE, p.nb, slots, bu_dyn_tile(TARGET, S::TILE));
+    const size_t tiles = (p.nb + tile_rt - 1) / tile_rt;
+    // generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per
+    // slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0)
+    const unsigned cus = (tiles <= slots || tiles % slots == 0) ? cu_count : 0u;
+    bu_go<TARGET, S>(p, (unsigned)(tiles < slots ? tiles : slots), cus, (unsigned)tile_rt);
 }
 
-// experiment (round 4): BC7 / ASTC launches of one tile per workgroup load their tile straight into LDS (kernel, GLDS)
-#ifdef BU_X_GLDS
-constexpr bool BU_GLDS_ON = true;
-#else
-constexpr bool BU_GLDS_ON = false;
-#endif
+template <int TARGET>
+void bu_launch_sorted(const BuPiece& p, unsigned cu_count, int policy, unsigned grid_cap)
+{
+    const size_t tiles = (p.nb + BU_HOST_TILE - 1) / BU_HOST_TILE;
+    if (grid_cap) {
+        bu_go<TARGET, BuZeroCopyShape>(p, (unsigned)(tiles < grid_cap ? tiles : grid_cap), cu_count, (unsigned)BuZeroCopyShape::TILE);
+    } else if (p.nb <= (size_t)BU_HOST_TILE * cu_count) {
+        bu_go<TARGET, BuOneTileShape<TARGET>>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
+    } else if (bu_big_from_one_tile_per_cu(TARGET) || p.nb > (size_t)3 * BU_HOST_TILE * cu_count) {
+        if (policy == BU_POLICY_SHARED) bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_SHARED>>(p, cu_count);
+        else bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_EXCLUSIVE>>(p, cu_count);
+    } else {
+        bu_go<TARGET, BuEtcMidShape>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
+    }
+}
+
+// RGBA32, 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows, the input tile aliased
+// into row 0) so the image rows leave as coalesced 1 KiB stores; persistent workgroups walk their tiles with prefetch, two per
+// CU (one under the shared policy).  Up to 3 Mi blocks 1024 threads per tile (32 waves per CU: 2^18 blocks 7.8 -> 7.2 us,
+// 2^20 17.95 -> 16.9, 2^21 35.0 -> 33.75), above that 512 threads x 2 blocks (2^22 blocks 62.7 against 64.4 us, 2^24 252
+// against 265).  The zero-copy launches (grid_cap) keep the 512 x 2 shape.
+void bu_launch_sorted_rgba(const BuPiece& p, unsigned cu_count, int policy, unsigned grid_cap)
+{
+    const size_t tiles = (p.nb + BU_HOST_TILE - 1) / BU_HOST_TILE;
+    const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)cu_count * (policy == BU_POLICY_SHARED ? 1 : 2);
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+    // generation priorities only when every workgroup walks at least two tiles (2^19 blocks 10.7 -> 10.3 us and
+    // 786 432 blocks 15.75 -> 14.24 without them, 2^20 blocks 16.7 against 18.7 with them)
+    const unsigned cus = tiles >= 2 * (size_t)grid ? cu_count : 0u;
+    if (grid_cap == 0 && p.nb <= ((size_t)3 << 20)) bu_go<BU_TGT_RGBA, BuShape<1024, 1, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
+    else bu_go<BU_TGT_RGBA, BuShape<512, 2, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
+}
+
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
                           uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0)
@@ -122,112 +262,35 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
     const uint4* in = static_cast<const uint4*>(d_in);
     unsigned long long* st = reinterpret_cast<unsigned long long*>(d_status);
     if (n_blocks >= (size_t)BU_SORT_MIN_BLOCKS) {
-        // mode-sorted kernel: one tile per workgroup, grid-stride beyond 7 workgroups per CU.  The kernel
-        // indexes with 32 bits, so very large slices are cut into launches of <= 2^26 blocks (1 GiB in);
-        // RGBA32 pieces end on whole block rows so the image addressing stays launch-relative.
-        constexpr int BU_TILE = BU_SORT_WGS * BU_SORT_BPT;
+        // mode-sorted kernel.  The kernel indexes with 32 bits, so very large slices are cut into launches of <= 2^26 blocks
+        // (1 GiB in); RGBA32 pieces end on whole block rows so the image addressing stays launch-relative.
         size_t piece = (size_t)1 << 26;
         if (target == BU_TARGET_RGBA32) piece = bpr <= piece ? (piece / bpr) * bpr : bpr;
         const size_t obytes = bu_target_block_bytes(target);
+        const int policy = ctx->launch_policy.load(std::memory_order_relaxed);
+        constexpr size_t RW = BU_RECT_W;
+        BuPiece p;
+        p.status = st;
+        p.tables = ctx->d_tables;
+        p.stream = stream;
+        p.bpr = bpr;
+        // (one tile per row, blocks_per_row == 64: the strip IS the rectangle)
+        p.rect_rows = grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21);
+        p.rect_quantum = n_blocks <= piece ? 0 : piece;
+        p.rect_magic = p.rect_rows ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
         for (size_t done = 0; done < n_blocks; done += piece) {
-            const size_t nb = n_blocks - done < piece ? n_blocks - done : piece;
-            const uint4* pin = in + done;
-            void* pout = static_cast<uint8_t*>(d_out) + done * obytes;  // RGBA32: done is a multiple of bpr -> whole rows
-            const size_t tiles = (nb + BU_TILE - 1) / BU_TILE;
-            const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * 7;
-            const unsigned sgrid = (unsigned)(tiles < cap ? tiles : cap);
-            const unsigned long long pbase = base + done;
-            // Rectangular tiles (kernel, RECT): the caller told us the block grid (blocks_per_row), it is a multiple of 64 wide and
-            // the piece is whole rows of 64 x 16-block tiles (BC7, ASTC, RGBA32: the fixed 1024-block shapes) or of 64 x 64-block
-            // tiles (ETC1 / ETC2: the 4096-block shape, when the balanced tile size is the full 4096 anyway).
-            constexpr size_t RW = BU_RECT_W;
-            // (one tile per row, blocks_per_row == 64: the strip IS the rectangle)
-            auto rect_ok = [&](size_t rh) {
-                return grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21) && nb % (rh * bpr) == 0 &&
-                       (n_blocks <= piece || piece % (rh * bpr) == 0);
-            };
-            const unsigned rect_magic = (bpr >= 2 * RW && bpr % RW == 0) ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
-#define BU_GO(T, W, B, MINW, PF, DIR, SK, GRID, CUS, TRT)                                                                                       \
-    do {                                                                                                                                        \
-        constexpr int tile_ = (W) * (B);                                                                                                        \
-        if (bu_rect_compiled(T, tile_) && rect_ok((size_t)tile_ / RW) && ((T) == BU_TGT_BC7 || tile_ == 1024 || (TRT) == (unsigned)tile_))        \
-            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, bu_rect_compiled(T, tile_)>), dim3(GRID), dim3(W), 0, stream, pin, pout, \
-                               (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, rect_magic BU_STAMP_PASS);                           \
-        else                                                                                                                                    \
-            hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, W, B, MINW, PF, DIR, SK, false>), dim3(GRID), dim3(W), 0, stream, pin, pout,          \
-                               (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, CUS, TRT BU_STAMP_PASS);                                  \
-    } while (0)
-            // large inputs: the per-target BuBigCfg configuration, see its definition
-#define BU_LAUNCH_SORTED(T)                                                                                                             \
-    if (grid_cap == 0 && nb <= (size_t)1024 * ctx->cu_count) {                                                                         \
-        /* at most one tile per CU: 16 waves on it (BC7 1 Ki blocks 4.32 -> 3.92 us, 2^16 5.16 -> 4.80, 2^18 5.70 -> 5.41; */          \
-        /* ETC1 6.76 -> 6.47, 7.95 -> 7.64, 8.82 -> 8.54) */                                                                           \
-        BU_GO(T, 1024, 1, 1, false, false, 0, (unsigned)((nb + 1023) / 1024), (unsigned)ctx->cu_count, 1024u);                                   \
-    } else if (grid_cap == 0 && (many || BuBigCfg<T>::ALL_SIZES)) {                                                                    \
-        using C = BuBigCfg<T>;                                                                                                          \
-        const size_t tile_rt = bu_balanced_tile((size_t)C::WGS * C::BPT, nb, (size_t)ctx->cu_count * C::WG_PER_CU, C::DYN_TILE);        \
-        const size_t btiles = (nb + tile_rt - 1) / tile_rt;                                                                             \
-        const size_t bcap = bu_x_bcap((size_t)ctx->cu_count * C::WG_PER_CU);                                                            \
-        /* generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per */      \
-        /* slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0) */   \
-        const unsigned pcus = (btiles <= bcap || btiles % bcap == 0) ? (unsigned)ctx->cu_count : 0u;                                    \
-        if constexpr (C::NT > 1) {                                                                                                      \
-            /* every load up front: exact grids of whole rectangular tiles only */                                                      \
-            if (btiles % C::NT == 0 && btiles / C::NT <= bcap && rect_ok((size_t)C::WGS * C::BPT / RW)) {                               \
-                hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_RECT, C::NT>), dim3((unsigned)(btiles / C::NT)), \
-                                   dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, rect_magic BU_STAMP_PASS); \
-                break;                                                                                                                  \
-            }                                                                                                                           \
-        }                                                                                                                               \
-        if constexpr (BU_GLDS_ON && ((T) == BU_TGT_BC7 || (T) == BU_TGT_ASTC) && C::WGS * C::BPT == 1024) {                            \
-            /* one tile per workgroup: the tile goes straight into LDS (kernel, GLDS) */                                               \
-            if (btiles <= bcap) {                                                                                                       \
-                if (rect_ok((size_t)1024 / RW))                                                                                         \
-                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_RECT, 1, true>), dim3((unsigned)btiles), \
-                                       dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, rect_magic BU_STAMP_PASS); \
-                else                                                                                                                    \
-                    hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, C::WGS, C::BPT, C::MINW, false, false, 0, BU_LAYOUT_STRIP, 1, true>), dim3((unsigned)btiles), \
-                                       dim3(C::WGS), 0, stream, pin, pout, (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, pcus, 1024u BU_STAMP_PASS); \
-                break;                                                                                                                  \
-            }                                                                                                                           \
-        }                                                                                                                               \
-        BU_GO(T, C::WGS, C::BPT, C::MINW, C::PREFETCH, C::DIRECT, C::SKEW, (unsigned)(btiles < bcap ? btiles : bcap), pcus, (unsigned)tile_rt); \
-    } else if (grid_cap == 0) {                                                                                                         \
-        /* fewer than two 1024-block tiles per CU: 8 waves per tile, every tile resident (ETC1 at 2^16 blocks: 14.1 -> 11.3 us) */     \
-        BU_GO(T, 512, 2, 1, false, false, 0, (unsigned)((nb + 1023) / 1024), (unsigned)ctx->cu_count, 1024u);                                    \
-    } else                                                                                                                              \
-        hipLaunchKernelGGL((bu_uastc_sorted_kernel<T, BU_SORT_WGS, BU_SORT_BPT>), dim3(sgrid), dim3(BU_SORT_WGS), 0, stream, pin, pout,  \
-                           (unsigned)nb, (unsigned)bpr, pbase, st, ctx->d_tables, (unsigned)ctx->cu_count, (unsigned)(BU_SORT_WGS * BU_SORT_BPT) BU_STAMP_PASS);
-            // ETC1 / ETC2: three 1024-block workgroups (83 / 99 VGPRs) are resident per CU; up to there every tile of the small
-            // shape runs at once and beats the 4096-block shape (2^19 blocks: 12.7 against 18.2 us, 786 432: 16.7 / 18.6),
-            // beyond it the small shape needs a second round of workgroups (917 504 blocks: 21.5 against 18.9 us)
-            const bool many = nb > (size_t)3 * 1024 * (size_t)ctx->cu_count;
+            p.nb = n_blocks - done < piece ? n_blocks - done : piece;
+            p.in = in + done;
+            p.out = static_cast<uint8_t*>(d_out) + done * obytes;  // RGBA32: done is a multiple of bpr -> whole rows
+            p.base = base + done;
             switch (target) {
-            case BU_TARGET_ASTC: BU_LAUNCH_SORTED(BU_TGT_ASTC) break;
-            case BU_TARGET_BC7: BU_LAUNCH_SORTED(BU_TGT_BC7) break;
-            case BU_TARGET_ETC1: BU_LAUNCH_SORTED(BU_TGT_ETC1) break;
-            case BU_TARGET_RGBA32: {
-                // 64 B of output per block: results return through a 64 KiB LDS tile (1024 blocks x 4 rows, the input tile
-                // aliased into row 0) so the image rows leave as coalesced 1 KiB stores; persistent workgroups walk their
-                // tiles with prefetch, two per CU.  Up to 3 Mi blocks 1024 threads per tile (32 waves per CU: 2^18 blocks
-                // 7.8 -> 7.2 us, 2^20 17.95 -> 16.9, 2^21 35.0 -> 33.75), above that 512 threads x 2 blocks (2^22 blocks 62.7
-                // against 64.4 us, 2^24 252 against 265).  The zero-copy launches (grid_cap) keep the 512 x 2 shape.
-                constexpr size_t rtile = 1024;
-                const size_t rtiles = (nb + rtile - 1) / rtile;
-                const size_t rcap = grid_cap ? (size_t)grid_cap : (size_t)ctx->cu_count * BU_RGBA_WG_PER_CU;
-                const unsigned rgrid = (unsigned)(rtiles < rcap ? rtiles : rcap);
-                // generation priorities only when every workgroup walks at least two tiles (2^19 blocks 10.7 -> 10.3 us and
-                // 786 432 blocks 15.75 -> 14.24 without them, 2^20 blocks 16.7 against 18.7 with them)
-                const unsigned rcus = rtiles >= 2 * (size_t)rgrid ? (unsigned)ctx->cu_count : 0u;
-                if (grid_cap == 0 && nb <= ((size_t)3 << 20))
-                    BU_GO(BU_TGT_RGBA, 1024, 1, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW, rgrid, rcus, (unsigned)rtile);
-                else
-                    BU_GO(BU_TGT_RGBA, 512, 2, 1, BU_RGBA_PREFETCH, false, BU_RGBA_SKEW, rgrid, rcus, (unsigned)rtile);
-            } break;
-            default: BU_LAUNCH_SORTED(BU_TGT_ETC2) break;
+            case BU_TARGET_ASTC: bu_launch_sorted<BU_TGT_ASTC>(p, (unsigned)ctx->cu_count, policy, grid_cap); break;
+            case BU_TARGET_BC7: bu_launch_sorted<BU_TGT_BC7>(p, (unsigned)ctx->cu_count, policy, grid_cap); break;
+            case BU_TARGET_ETC1: bu_launch_sorted<BU_TGT_ETC1>(p, (unsigned)ctx->cu_count, policy, grid_cap); break;
+            case BU_TARGET_ETC2: bu_launch_sorted<BU_TGT_ETC2>(p, (unsigned)ctx->cu_count, policy, grid_cap); break;
+            case BU_TARGET_RGBA32: bu_launch_sorted_rgba(p, (unsigned)ctx->cu_count, policy, grid_cap); break;
+            default: return BU_ERR_ARGUMENT;
             }
-#undef BU_LAUNCH_SORTED
-#undef BU_GO
             BU_HIP(ctx, hipGetLastError());
         }
         return BU_OK;

@@ -9,6 +9,8 @@ constexpr int BU_WG = 256;            // 4 waves
 // wins for a handful of blocks (BC7: 1 block 2.3 vs 3.3 us, 8 blocks 4.2 vs 3.7 us, 64 blocks 7.8 vs 4.4 us,
 // 1024 blocks 16.1 vs 4.8 us; ETC1 at 128 blocks 38.6 vs 15.0 us).
 constexpr int BU_SORT_MIN_BLOCKS = 8;
+// shapes of the mode-sorted kernel whose tile size is a run-time argument (bu_balanced_tile): ETC1 / ETC2 on 4096-block tiles
+constexpr bool bu_dyn_tile(int target, int tile) { return (target == BU_TGT_ETC1 || target == BU_TGT_ETC2) && tile == 4096; }
 
 // ------------------------------------------------------------------------------------------------
 // LDS image of the tables of TARGET: [BuBc7Tables (BC7 only)][BuTables up to the end of the target's ranges]
@@ -144,11 +146,11 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // <= 64 blocks, and each wave then transcodes whole chunks with a wave-uniform mode (scalar branch,
 // no exec-mask divergence).  Results go back to LDS at the sorted slot and leave in original order,
 // so global loads and stores stay fully coalesced (1 KiB per wave instruction).
-//   LDS per workgroup: tile 16 B x BU_TILE + tables 5.9 KiB + 1 B x BU_TILE status + counters and the chunk list.
+//   LDS per workgroup: tile 16 B x BU_TILE + the target's tables + (ETC, RGBA32) 1 B x BU_TILE status + counters.
 // Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr, and
 // for the streamed ETC1S front door when every work item started and ended), BU_RUN_PIECE_MIB (piece size of the two-stream upload
 // pipeline, 0 = off), BU_ETC1S_ONE_LAUNCH (ETC1S files: decode everything, then one launch -- the round-3 path),
-// BU_ETC1S_ONE_THREAD (streamed ETC1S front door: every slice's symbol loop on one thread), BU_X_BCAP (tools/exp only).
+// BU_ETC1S_ONE_THREAD (streamed ETC1S front door: every slice's symbol loop on one thread).
 // inclusive add-scan over lanes 0..31 (and 32..63) with DPP row shifts: 5 VALU, no LDS round trips
 __device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
 {
@@ -160,80 +162,6 @@ __device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
     return v;
 }
 
-// WGS threads per workgroup, BPT blocks per thread: tile = WGS*BPT blocks
-constexpr int BU_SORT_WGS = 256, BU_SORT_BPT = 4;
-// The large-input configurations (>= 512 Ki blocks), per target; all A/B'd inside one run (tools/exp/ab.sh) on the
-// BC7 headline, a 4096^2 atlas = 4096 blocks per CU:
-//   1024 x 4 (4096-block tile), one workgroup per CU                          13.65 us
-//   512 x 4 (2048), two per CU (16 waves)                                     12.80    -- half-size workgroups overlap each
-//   + second half of the grid started ~1 us late (s_sleep 40)                 12.65       other's barrier-bound sort phases
-//   256x4 13.8, 512x8 16.2, 1024x2 15.9, 256x8 15.7 at the same register count
-// The kernels are built with machine-LICM off (basisu_rs_amd/build.py): hoisting every mode path's constants out of the
-// chunk loop cost ~30 VGPRs.  BC7 then needs 62 instead of 93, which allows 32 waves per CU:
-//   1024 x 2 (2048), two per CU (32 waves)                                    11.6
-//   512 x 2 (1024), four per CU (32 waves)                                    11.4     <- BC7, ASTC
-// ASTC reaches 63 VGPRs with its modes 3, 4 and 7 rewritten on packed digit strings (bu_uastc_astc.hpp).
-// ETC1 / ETC2 (84 / 106 VGPRs, 27 KiB of tables per workgroup): ONE 1024-thread workgroup per CU on a 4096-block tile -- 73
-// chunks per 4096 blocks where two 2048-block tiles have 83.  A/B in one run (tools/exp/ab.sh), round 2 with the leaner
-// block code: ETC1 512x4 two per CU 19.98 us, without the start skew 19.85, 1024x4 one per CU 19.45, 1024-block tiles
-// three per CU 22.3; ETC2 25.04 / 24.92 / 25.07 / 28.3, and with the table copy behind the first rank phase 23.79 (512x4)
-// against 23.45 (1024x4).  More waves do not help: 1024x2 two per CU (64 VGPRs, 6 / 45 spilled) 23.0 / 36.2.
-template <int TARGET>
-struct BuBigCfg {
-    // PREFETCH: a workgroup that walks several tiles (inputs above 4096 blocks per CU) loads tile k+1 while it transcodes
-    // tile k.  Nothing changes for one tile per workgroup (2^20 blocks: 19.17 / 19.11 us); 2^25 blocks ETC1 516 -> 474 us,
-    // ETC2 661 -> 613, BC7 227 -> 213 (0.63 of the HBM peak).  ASTC would cross 64 VGPRs (2^20 blocks: 9.55 -> 12.97 us).
-    static constexpr bool PREFETCH = true, DIRECT = false;
-#ifndef BU_XE_BPT  // experiment (round 4): ETC1 / ETC2 on smaller tiles walked by one workgroup per CU with every load up front
-#define BU_XE_BPT 4
-#define BU_XE_NT 1
-#endif
-    static constexpr int WGS = 1024, BPT = BU_XE_BPT, WG_PER_CU = 1, SKEW = 0, MINW = 1, NT = BU_XE_NT;
-    static constexpr bool DYN_TILE = BU_XE_NT == 1;    // the kernel takes the tile size at run time (bu_balanced_tile)
-    static constexpr bool ALL_SIZES = false;  // up to 3 Ki blocks per CU the launcher uses 512 x 2 (1024-block tiles, all resident): bu_launch_uastc
-};
-#ifndef BU_X_WGS
-#define BU_X_WGS 512
-#define BU_X_BPT 2
-#define BU_X_WGPCU 4
-#define BU_X_NT 1
-#endif
-template <>
-struct BuBigCfg<BU_TGT_BC7> {
-    static constexpr int WGS = BU_X_WGS, BPT = BU_X_BPT, WG_PER_CU = BU_X_WGPCU, SKEW = 0, MINW = (BU_X_WGS * BU_X_WGPCU >= 2048 && BU_X_WGS > 512) ? 8 : 1;
-    static constexpr int NT = BU_X_NT;  // tiles a workgroup walks with every load issued up front (launcher: exact grids only)
-    static constexpr bool ALL_SIZES = true;  // 8 waves on a 1024-block tile beat 4: 2^16 blocks 7.5 -> 5.7 us, 2^18 8.1 -> 6.3 us
-    static constexpr bool PREFETCH = true, DIRECT = false;  // 64 VGPRs with the next tile's two loads in flight: still four workgroups per CU
-    static constexpr bool DYN_TILE = false;
-};
-template <>
-struct BuBigCfg<BU_TGT_ASTC> {
-    static constexpr bool DYN_TILE = false;
-    static constexpr bool PREFETCH = true, DIRECT = false;  // round 3: 62 VGPRs with the prefetch (round 2: 67); 2^25 blocks 209.5 -> 198.2 us, 2^20 unchanged
-    static constexpr int WGS = 512, BPT = 2, WG_PER_CU = 4, SKEW = 0, MINW = 1, NT = 1;
-    static constexpr bool ALL_SIZES = true;
-};
-// RGBA32 configuration: 1024-block tiles, two workgroups per CU, 1024 x 1 or 512 x 2 threads x blocks by slice size (bu_launch_uastc)
-#define BU_RGBA_WG_PER_CU 2
-#ifndef BU_RGBA_PREFETCH
-#define BU_RGBA_PREFETCH true
-#endif
-#ifndef BU_RGBA_SKEW
-#define BU_RGBA_SKEW 0
-#endif
-
-
-#ifndef BU_STAMP
-#define BU_STAMP(k)
-#define BU_STAMP_ARG
-#define BU_STAMP_PASS
-#define BU_STAMP_FWD
-#define BU_STAMP_DECL
-#define BU_STAMP_NEXT
-#endif
-// DIRECT: results are stored to global memory straight from the chunk loop at the block's original
-// index (16-byte pieces, not coalesced across lanes) instead of returning through LDS.  Always used for
-// RGBA32 (64 B per block do not fit a second LDS tile; `bpr` = blocks per image row).
 // RECT: a tile is a BU_RECT_W x (tile / BU_RECT_W) RECTANGLE of the block grid (64 x 16 for the 1024-block tiles) instead of a strip
 // of consecutive blocks (the launcher picks it when blocks_per_row is a multiple of 64 and the slice is whole rows of such tiles,
 // bu_launch_uastc).  Texture content is coherent in two dimensions: a 1024-block strip of a 4096-px-wide image cuts an 8 x 8-block
@@ -271,18 +199,14 @@ struct BuTileDesc {
     uint64_t base;
 };
 enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1,
-          bool GLDS = false>
+// WGS threads per workgroup, BPT blocks per thread: tile = WGS * BPT blocks.  PREFETCH: a workgroup that walks several tiles
+// loads tile k+1 while it transcodes tile k (BPT more uint4 registers).
+template <int TARGET, int WGS, int BPT, bool PREFETCH, int LAYOUT>
 __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                      unsigned bpr, unsigned long long base, unsigned long long* status,
                                                      const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
-                                                     const BuRunTable* __restrict__ runs BU_STAMP_ARG)
+                                                     const BuRunTable* __restrict__ runs)
 {
-    BU_STAMP_DECL
-    BU_STAMP(0)
-    if constexpr (SKEW > 0) {
-        if (blockIdx.x >= gridDim.x / 2 && gridDim.x > 1) __builtin_amdgcn_s_sleep(SKEW);
-    }
     // Static priority by residency generation.  Workgroups are dealt breadth-first (b, b + CUs, b + 2 CUs, ... share a CU:
     // tools/exp/census.hip), and the instruction arbiter serves the OLDEST wave first, so the four tiles of a CU finish
     // 1.5 us apart and the last one runs its latency-bound chain with the vector units nearly idle (phase stamps,
@@ -292,23 +216,12 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // blocks: the one-tile workgroups of the second generation would run ahead of the two-tile ones, 15.75 against 14.24 us).
     // Round 3, on the leaner kernels: generation priorities 0, 3, 2, 1 beat 0, 1, 2, 3 for BC7 (9.13 -> 8.96 us) and ASTC (9.0 -> 8.8),
     // not for RGBA32 (15.85 -> 16.0); no priorities 9.14 / 9.04 / 17.4 (profiles/r03_ab_wave_priorities.txt).
-#ifdef BU_X_PRIO  // experiment: BU_X_PRIO = priorities of generations 0..3 as four decimal digits, BU_X_STAG1..3 = s_sleep counts in front of the tile loads
-    unsigned bu_gen = 0;
-    if (cus != 0) {
-        bu_gen = blockIdx.x >= 3 * cus ? 3u : (blockIdx.x >= 2 * cus ? 2u : (blockIdx.x >= cus ? 1u : 0u));
-        if (bu_gen == 3) __builtin_amdgcn_s_setprio((BU_X_PRIO) % 10);
-        else if (bu_gen == 2) __builtin_amdgcn_s_setprio((BU_X_PRIO) / 10 % 10);
-        else if (bu_gen == 1) __builtin_amdgcn_s_setprio((BU_X_PRIO) / 100 % 10);
-        else __builtin_amdgcn_s_setprio((BU_X_PRIO) / 1000 % 10);
-    }
-#else
     if (cus != 0) {  // (comparisons, not blockIdx / cus: a scalar division is ~25 instructions in front of the first load)
         constexpr bool ROT = TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC;
         if (blockIdx.x >= 3 * cus) __builtin_amdgcn_s_setprio(ROT ? 1 : 3);
         else if (blockIdx.x >= 2 * cus) __builtin_amdgcn_s_setprio(2);
         else if (blockIdx.x >= cus) __builtin_amdgcn_s_setprio(ROT ? 3 : 1);
     }
-#endif
     constexpr int BU_WG = WGS, BU_BPT = BPT, BU_TILE = WGS * BPT;
     __shared__ uint4 t_store[bu_lds_table_bytes(TARGET) / 16];  // the blob as far as TARGET reads it (BC7: its own tables in front)
     BuTables& T = *reinterpret_cast<BuTables*>(t_store + bu_lds_front(TARGET) / 16);
@@ -318,12 +231,8 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
     // which is what lets two workgroups share a CU.
     constexpr bool RECT = LAYOUT == BU_LAYOUT_RECT, MULTI = LAYOUT == BU_LAYOUT_MULTI;
-    static_assert(!MULTI || (!PREFETCH && !DIRECT), "the multi-slice layout is compiled for the plain one-tile-at-a-time shapes");
-    // NT > 1: the workgroup walks exactly NT tiles (tile, tile + grid, ...) and issues the loads of ALL of them before anything
-    // else, unconditionally (the launcher guarantees n_tiles == NT * gridDim.x, whole rectangular tiles): tile k's data are
-    // sorted and transcoded while the later tiles' loads are still in flight
-    static_assert(NT == 1 || LAYOUT == BU_LAYOUT_RECT, "tiles loaded up front: rectangular layout, exact grids");
-    constexpr bool BU_ALIAS = (TARGET == BU_TGT_RGBA && !DIRECT);
+    static_assert(!MULTI || !PREFETCH, "the multi-slice layout is compiled for the plain one-tile-at-a-time shapes");
+    constexpr bool BU_ALIAS = TARGET == BU_TGT_RGBA;
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
     static_assert(!BU_ALIAS || bu_lds_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
                   "the RGBA32 workgroup no longer fits twice per CU: shrink BuTables or stage it per target in LDS too");
@@ -332,30 +241,22 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     uint4* const sblk = BU_ALIAS ? sout : sblk_store;
     // BC7 and ASTC carry a failing block's status inside its result slot (a valid block of either format has a non-zero first
     // byte: BC7's unary mode prefix, ASTC's block mode / void-extent marker), the other targets in a byte per block
-    constexpr bool INBLOCK = (TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC) && !DIRECT;
-    __shared__ uint8_t sst[(DIRECT || INBLOCK) ? 16 : BU_TILE];
-    // GLDS (round 4): the tile goes from global memory straight into LDS (global_load_lds_dwordx4: no VGPRs, no ds_write_b128), in
-    // ORIGINAL order -- the LDS address of such a load is wave-uniform base + lane * 16, it cannot scatter.  The sort then moves
-    // 2-byte indices instead of 16-byte blocks: `sorig[sorted slot]` = the block's place in the tile; a chunk lane reads its block
-    // through it, and writes the result back to the SAME place, so the write-back phase reads LDS in order.  One tile per workgroup
-    // (the launcher's one-tile grids); BC7 and ASTC (status inside the result slot).
-    static_assert(!GLDS || ((TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC) && !PREFETCH && !DIRECT && NT == 1 && LAYOUT != BU_LAYOUT_MULTI),
-                  "direct-to-LDS tile loads: BC7 / ASTC, one tile per workgroup");
-    __shared__ uint16_t sorig[(DIRECT || GLDS) ? BU_TILE : 16];
+    constexpr bool INBLOCK = TARGET == BU_TGT_BC7 || TARGET == BU_TGT_ASTC;
+    __shared__ uint8_t sst[INBLOCK ? 16 : BU_TILE];
     // counters and the chunk ticket are double-buffered by tile parity: the buffer of tile t+1 is cleared during tile t,
     // after everyone has finished with its previous use (tile t-1), so no barrier is spent on the reset
     __shared__ uint32_t cnt[2][32], next_chunk[2];
     const unsigned tid = threadIdx.x, lane = tid & 63u;
-    // Blocks per tile.  The ETC shape is one workgroup per CU on tiles of up to 4096 blocks; with a fixed tile a slice of
+    // Blocks per tile.  The exclusive ETC shape is one workgroup per CU on tiles of up to 4096 blocks; with a fixed tile a slice of
     // 1.5 tiles per CU takes as long as one of 2 (1.5 Mi blocks 33.4 us, 2 Mi 34.2).  There the launcher sizes the tile so
     // that every CU gets the same number of equal tiles (`tile_rt` <= BU_TILE, a multiple of 64); threads past the end of
     // a shorter tile sit out like threads past the end of the slice.  Every other shape passes tile_rt = BU_TILE and
     // compiles to what it was.
-    constexpr bool DYN_TILE = (TARGET == BU_TGT_ETC1 || TARGET == BU_TGT_ETC2) && BU_TILE == 4096 && LAYOUT != BU_LAYOUT_RECT;
+    constexpr bool DYN_TILE = bu_dyn_tile(TARGET, BU_TILE) && LAYOUT != BU_LAYOUT_RECT;
     const unsigned tile_blocks = DYN_TILE ? tile_rt : (unsigned)BU_TILE;
     const unsigned n_tiles = (n_blocks + tile_blocks - 1) / tile_blocks;  // 32-bit indices: the host splits launches above 2^26 blocks
     auto in_tile = [&](unsigned l) { return !DYN_TILE || l < tile_blocks; };
-    static_assert(!RECT || (!DYN_TILE && BU_TILE % BU_RECT_W == 0), "rectangular tiles are BU_RECT_W blocks wide and of fixed size");
+    static_assert(!RECT || BU_TILE % BU_RECT_W == 0, "rectangular tiles are BU_RECT_W blocks wide and of fixed size");
     // slice index of block l of tile t.  RECT: `tile_rt` carries ceil(2^32 / tiles per row) + 0 (bu_launch_uastc), which makes
     // t / tpr one s_mul_hi_u32 (exact for t, tpr < 2^16: at most 2^26 blocks per launch, rows below 2^21 blocks)
     const unsigned tpr = RECT ? bpr / BU_RECT_W : 1u;  // tiles per row of tiles
@@ -410,10 +311,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // rest held in registers until the first tile's rank atomics are out (A/B: ETC1 19.45 -> 19.0 us in round 2; tables first
     // 19.2 -> 19.8 in round 3).
     constexpr BuTableRange TR = bu_table_range(TARGET);
-#ifndef BU_SPLIT_MIN
-#define BU_SPLIT_MIN 16384
-#endif
-    constexpr bool SPLIT = bu_lds_table_bytes(TARGET) > BU_SPLIT_MIN;
+    constexpr bool SPLIT = bu_lds_table_bytes(TARGET) > 16384;
     constexpr int TF = (int)bu_lds_front(TARGET) / 16, TV1 = (int)(TR.hi - TR.lo) / 16, TV2 = TR.lo2 < TR.hi2 ? (int)(TR.hi2 - TR.lo2) / 16 : 0;
     constexpr int TVT = TF + TV1 + TV2, TVN = (TVT + WGS - 1) / WGS;
     const uint4* const tsrc = reinterpret_cast<const uint4*>(TARGET == BU_TGT_BC7 ? reinterpret_cast<const void*>(tables) : reinterpret_cast<const void*>(&tables->t));
@@ -426,36 +324,10 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             tv[k] = i < TVT ? tsrc[tdst(i)] : make_uint4(0, 0, 0, 0);
         }
     }
-#if defined(BU_X_PRIO) && defined(BU_X_STAG1)
-    if (bu_gen == 1) __builtin_amdgcn_s_sleep(BU_X_STAG1);
-    else if (bu_gen == 2) __builtin_amdgcn_s_sleep(BU_X_STAG2);
-    else if (bu_gen == 3) __builtin_amdgcn_s_sleep(BU_X_STAG3);
-#endif
     uint4 v[BU_BPT];
-    if constexpr (GLDS) {
-        typedef const __attribute__((address_space(1))) void* bu_gptr;
-        typedef __attribute__((address_space(3))) void* bu_lptr;
-#ifndef BU_X_GLDS_AUX
-#define BU_X_GLDS_AUX 0
-#endif
 #pragma unroll
-        for (int j = 0; j < BU_BPT; j++) {
-            v[j] = make_uint4(0, 0, 0, 0);
-            if (RECT || blk_valid(tile, j * BU_WG + tid))  // (lanes without a block: exec off, their LDS slot keeps whatever it held)
-                __builtin_amdgcn_global_load_lds((bu_gptr)blk_src(tile, j * BU_WG + tid), (bu_lptr)(sblk + j * BU_WG + (tid & ~63u)), 16, 0, BU_X_GLDS_AUX);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < BU_BPT; j++)
-            v[j] = (RECT || blk_valid(tile, j * BU_WG + tid)) ? bu_ld_stream(blk_src(tile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is n_tiles)
-    }
-    uint4 vq[NT > 1 ? NT - 1 : 1][BU_BPT];
-    if constexpr (NT > 1) {
-#pragma unroll
-        for (int q = 0; q < NT - 1; q++)
-#pragma unroll
-            for (int j = 0; j < BU_BPT; j++) vq[q][j] = bu_ld_stream(blk_src(tile + (unsigned)(q + 1) * gridDim.x, j * BU_WG + tid));
-    }
+    for (int j = 0; j < BU_BPT; j++)
+        v[j] = (RECT || blk_valid(tile, j * BU_WG + tid)) ? bu_ld_stream(blk_src(tile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);  // (RECT: the grid is at most n_tiles)
     if constexpr (!SPLIT) {
 #pragma unroll
         for (int k = 0; k < TVN; k++) {
@@ -472,11 +344,9 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         if (tid < 32) reinterpret_cast<uint32_t*>(T.key_lut[TARGET])[tid] = reinterpret_cast<const uint32_t*>(tables->t.key_lut[TARGET])[tid];
     }
     bool tables_staged = !SPLIT;
-    BU_STAMP(11)
     if (tid < 64) (&cnt[0][0])[tid] = 0;
     if (tid < 2) next_chunk[tid] = 0;
     __syncthreads();
-    BU_STAMP(1)
     unsigned par = 0;
     for (; tile < n_tiles; tile += gridDim.x, par ^= 1u) {
         const unsigned tbase = tile * tile_blocks;
@@ -491,14 +361,9 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             const bool valid = RECT || (MULTI ? (unsigned)(j * BU_WG) + tid < td.n : (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid)));  // (RECT: whole tiles only)
-            if constexpr (GLDS) {
-                if (j == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's own two blocks have landed in LDS
-                v[j].x = valid ? sblk[j * BU_WG + tid].x : 0u;
-            }
             key[j] = valid ? T.key_lut[TARGET][v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
-        BU_STAMP(12)
         if (uniform) {
             uint32_t lead[BU_BPT];
 #pragma unroll
@@ -517,9 +382,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             }
             tables_staged = true;
         }
-        BU_STAMP(2)
         __syncthreads();  // (1) every rank is final; the tables are in LDS
-        BU_STAMP(3)
         // ---- B: run starts and the chunk map, derived by EVERY wave for itself ----
         // Lane k < 20 holds run k: blocks in the low half, 64-block chunks in the high half of one word; a DPP scan gives
         // every run's first slot and first chunk number.  No wave waits for another one here (the round-1 kernel had one
@@ -536,26 +399,18 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         for (int j = 0; j < BU_BPT; j++) {
             const uint32_t st = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key[j] << 2), (int)run_excl) & 0xFFFFu;
             dest[j] = has_block(key[j]) ? st + pos[j] : 0u;
-            if (has_block(key[j])) {
-                if constexpr (!GLDS) sblk[dest[j]] = v[j];
-                if constexpr (DIRECT || GLDS) sorig[dest[j]] = (uint16_t)(j * BU_WG + tid);
-            }
+            if (has_block(key[j])) sblk[dest[j]] = v[j];
         }
         // prefetch the next tile while this one is transcoded
         const unsigned ntile = tile + gridDim.x;
         uint4 vn[BU_BPT];
-        if constexpr (PREFETCH && NT == 1) {
+        if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 vn[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
             }
         }
-        BU_STAMP(4)
         __syncthreads();  // (2) the sorted tile is complete
-        BU_STAMP(5)
-#ifdef BU_X_DYNPRIO
-        __builtin_amdgcn_s_setprio(BU_X_DYNPRIO);
-#endif
         // ---- C: whole chunks, wave-uniform mode ----
         // dynamic chunk scheduling: waves take the next chunk as they free up (one LDS atomic per chunk).  The claim for the
         // FOLLOWING chunk is issued before the current one is transcoded, so its LDS round trip hides under the transcode.
@@ -572,8 +427,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             const uint32_t s0 = (r_ex & 0xFFFFu) + k64, left = (r_pk & 0xFFFFu) - k64, count = left < 64u ? left : 64u;
             const bool active = lane < count;
             const uint32_t slot = s0 + (active ? lane : 0u);
-            const uint32_t bslot = GLDS ? (uint32_t)sorig[slot] : slot;  // where the block is, and where its result goes
-            const uint4 bv = sblk[bslot];
+            const uint4 bv = sblk[slot];
             BuBlk b;
             b.w[0] = bv.x;
             b.w[1] = bv.y;
@@ -585,12 +439,6 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             for (int i = 0; i < NO; i++) o[i] = 0;
             int st = BU_ST_BAD_MODE;
             if (active) {
-#ifdef BU_X_REP0  // experiment: no block code (results wrong by construction) -- what the kernel costs around the mode paths
-                if (r < 19u) {
-                    o[0] = b.w[0] | 1u; o[1] = b.w[1]; o[2] = b.w[2]; o[3] = b.w[3];
-                    st = 0;
-                } else
-#endif
                 switch (r) {  // the run number IS the sort key: run k holds mode BU_COST_ORDER[k] (run 19: invalid mode codes)
 #define BU_CASE(k) \
     case k: st = bu_block_mode<TARGET, BU_COST_ORDER[TARGET][k]>(T, b, o); break;
@@ -600,100 +448,62 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                 default: break;
                 }
                 // (a failing block leaves o[] at the zeros it was initialised with: every path checks before it writes)
-                if constexpr (DIRECT) {
-                    const unsigned idx = gidx(tile, sorig[slot]);
-                    if (st) bu_report(status, base + idx, st);
-                    if constexpr (TARGET == BU_TGT_RGBA) {
-                        const unsigned by = idx / bpr, bx = idx - by * bpr;
-                        uint4* img = reinterpret_cast<uint4*>(out);
-#pragma unroll
-                        for (int r2 = 0; r2 < 4; r2++) img[(size_t)((4 * by + r2) * bpr + bx)] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
-                    } else if constexpr (TARGET == BU_TGT_ETC1) {
-                        reinterpret_cast<uint2*>(out)[idx] = make_uint2(o[0], o[1]);
-                    } else {
-                        reinterpret_cast<uint4*>(out)[idx] = make_uint4(o[0], o[1], o[2], o[3]);
-                    }
-                } else if constexpr (TARGET == BU_TGT_RGBA) {
+                if constexpr (TARGET == BU_TGT_RGBA) {
 #pragma unroll
                     for (int r2 = 0; r2 < 4; r2++) sout[r2 * BU_TILE + slot] = make_uint4(o[4 * r2], o[4 * r2 + 1], o[4 * r2 + 2], o[4 * r2 + 3]);
                     sst[slot] = (uint8_t)st;
                 } else if constexpr (INBLOCK) {
-                    sblk[bslot] = make_uint4(o[0], o[1], o[2], o[3] | (uint32_t)st);  // (a failing block's o[] is all zeros)
+                    sblk[slot] = make_uint4(o[0], o[1], o[2], o[3] | (uint32_t)st);  // (a failing block's o[] is all zeros)
                 } else {
                     sblk[slot] = make_uint4(o[0], o[1], o[2], o[3]);
                     sst[slot] = (uint8_t)st;
                 }
             }
         }
-        BU_STAMP(6)
-#ifdef BU_X_DYNPRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         __syncthreads();  // (3) every result is in LDS
-        BU_STAMP(7)
         // ---- D: results leave in original order ----
-        if constexpr (!DIRECT) {
 #pragma unroll
-            for (int j = 0; j < BU_BPT; j++) {
-                if (has_block(key[j])) {
-                    const unsigned idx = MULTI ? td.first + j * BU_WG + tid : gidx(tile, j * BU_WG + tid);  // (MULTI: inside the tile's slice)
-                    void* const out = td.out;                  // (the launch's `out` unless MULTI)
-                    const unsigned long long base = td.base;
-                    if constexpr (INBLOCK) {
-                        uint4 r = sblk[GLDS ? (uint32_t)(j * BU_WG + tid) : dest[j]];
-                        if ((r.x & 0xFFu) == 0u) {  // no valid block of these formats starts with a zero byte: word 3 is the status
-                            bu_report(status, base + idx, (int)r.w);
-                            r.w = 0;
-                        }
-                        bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
-                        continue;
+        for (int j = 0; j < BU_BPT; j++) {
+            if (has_block(key[j])) {
+                const unsigned idx = MULTI ? td.first + j * BU_WG + tid : gidx(tile, j * BU_WG + tid);  // (MULTI: inside the tile's slice)
+                void* const out = td.out;                  // (the launch's `out` unless MULTI)
+                const unsigned long long base = td.base;
+                if constexpr (INBLOCK) {
+                    uint4 r = sblk[dest[j]];
+                    if ((r.x & 0xFFu) == 0u) {  // no valid block of these formats starts with a zero byte: word 3 is the status
+                        bu_report(status, base + idx, (int)r.w);
+                        r.w = 0;
                     }
-                    const uint32_t st = sst[dest[j]];
-                    if (st) bu_report(status, base + idx, (int)st);
-                    if constexpr (TARGET == BU_TGT_RGBA) {
-                        unsigned by, bx;
-                        if constexpr (RECT) {  // block row and column straight from the tile coordinates: no division
-                            const unsigned l = j * BU_WG + tid;
-                            unsigned ty, tx;
-                            tile_xy(tile, ty, tx);
-                            by = (unsigned)(BU_TILE / BU_RECT_W) * ty + l / BU_RECT_W;
-                            bx = BU_RECT_W * tx + (l % BU_RECT_W);
-                        } else {
-                            by = idx / bpr;
-                            bx = idx - by * bpr;
-                        }
-                        uint4* img = reinterpret_cast<uint4*>(out);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)((4 * by + r) * bpr + bx), sout[r * BU_TILE + dest[j]]);
+                    bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
+                    continue;
+                }
+                const uint32_t st = sst[dest[j]];
+                if (st) bu_report(status, base + idx, (int)st);
+                if constexpr (TARGET == BU_TGT_RGBA) {
+                    unsigned by, bx;
+                    if constexpr (RECT) {  // block row and column straight from the tile coordinates: no division
+                        const unsigned l = j * BU_WG + tid;
+                        unsigned ty, tx;
+                        tile_xy(tile, ty, tx);
+                        by = (unsigned)(BU_TILE / BU_RECT_W) * ty + l / BU_RECT_W;
+                        bx = BU_RECT_W * tx + (l % BU_RECT_W);
                     } else {
-                        const uint4 r = sblk[dest[j]];
-                        if constexpr (TARGET == BU_TGT_ETC1) bu_st_stream(reinterpret_cast<uint2*>(out) + idx, make_uint2(r.x, r.y));
-                        else bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
+                        by = idx / bpr;
+                        bx = idx - by * bpr;
                     }
+                    uint4* img = reinterpret_cast<uint4*>(out);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bu_st_stream(img + (size_t)((4 * by + r) * bpr + bx), sout[r * BU_TILE + dest[j]]);
+                } else {
+                    const uint4 r = sblk[dest[j]];
+                    if constexpr (TARGET == BU_TGT_ETC1) bu_st_stream(reinterpret_cast<uint2*>(out) + idx, make_uint2(r.x, r.y));
+                    else bu_st_stream(reinterpret_cast<uint4*>(out) + idx, r);
                 }
             }
         }
-        if constexpr (NT > 1) {
-#pragma unroll
-            for (int j = 0; j < BU_BPT; j++) v[j] = vq[0][j];
-#pragma unroll
-            for (int q = 0; q + 1 < NT - 1; q++)
-#pragma unroll
-                for (int j = 0; j < BU_BPT; j++) vq[q][j] = vq[q + 1][j];
-        } else if constexpr (PREFETCH) {
+        if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
-        } else if constexpr (GLDS) {
-            // (a workgroup that walks several tiles: the next tile may only land once every result of this one has left LDS)
-            if (ntile < n_tiles) {
-                typedef const __attribute__((address_space(1))) void* bu_gptr;
-                typedef __attribute__((address_space(3))) void* bu_lptr;
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < BU_BPT; j++)
-                    if (RECT || blk_valid(ntile, j * BU_WG + tid))
-                        __builtin_amdgcn_global_load_lds((bu_gptr)blk_src(ntile, j * BU_WG + tid), (bu_lptr)(sblk + j * BU_WG + (tid & ~63u)), 16, 0, BU_X_GLDS_AUX);
-            }
         } else {
             load_desc(ntile);
 #pragma unroll
@@ -701,29 +511,26 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         }
         // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only
         // after its reads of this tile's results have completed
-        BU_STAMP(8)
-        BU_STAMP_NEXT
     }
 }
 
-template <int TARGET, int WGS, int BPT, int MINW = 1, bool PREFETCH = true, bool DIRECT = (TARGET == BU_TGT_RGBA), int SKEW = 0, int LAYOUT = BU_LAYOUT_STRIP, int NT = 1,
-          bool GLDS = false>
+// MINW: minimum waves per SIMD the register allocation must leave room for (the second __launch_bounds__ argument)
+template <int TARGET, int WGS, int BPT, int MINW, bool PREFETCH, int LAYOUT>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt BU_STAMP_ARG)
+                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt)
 {
     static_assert(LAYOUT != BU_LAYOUT_MULTI, "several runs per launch: bu_uastc_multi_kernel");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, MINW, PREFETCH, DIRECT, SKEW, LAYOUT, NT, GLDS>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr BU_STAMP_FWD);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr);
 }
 
 // several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value)
 template <int TARGET, int WGS, int BPT>
 __global__ __launch_bounds__(WGS, 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
-                                                             const BuTablesAll* __restrict__ tables BU_STAMP_ARG)
+                                                             const BuTablesAll* __restrict__ tables)
 {
     static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, 1, false, false, 0, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u,
-                                                                                &table BU_STAMP_FWD);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, false, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table);
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into

@@ -189,12 +189,7 @@ bu_status bu_ipc_close(bu_context* ctx, void* d_peer)
 }
 
 // streams of the concurrent pulls: extra_streams[0..6] of the context, created on first use
-static bu_status bu_peer_streams(bu_context* ctx, int n)
-{
-    for (int i = 0; i < n && i < 8; i++)
-        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
-    return BU_OK;
-}
+static bu_status bu_peer_streams(bu_context* ctx, int n) { return bu_ctx_streams(ctx, n < 8 ? n : 8); }
 
 bu_status bu_allgather_peer(bu_context* ctx, void* d_full, void* const* d_peer_full, int world, int rank, size_t shard_bytes,
                             void* stream)

@@ -65,14 +65,16 @@ def pmc_traffic():
 
 
 def pmc_child():
-    """`bench.py --pmc-child`: the program rocprofv3's counter passes run (live_traffic): the shipped BC7 kernel once over each of
-    24 cold A-gold atlases of the headline size, nothing else (BENCH_PMC_ROUNDS rounds over them: the kernel-trace pass asks for 16,
-    so that its per-kernel average is a steady-state one)"""
+    """`bench.py --pmc-child`: the program rocprofv3's child passes run (live_traffic): the headline BC7 kernel (launch policy from
+    BENCH_PMC_POLICY) over 24 cold A-gold atlases of the headline size, nothing else.  Counter passes: once over each atlas, one launch
+    at a time (the profiler serialises dispatches under --pmc anyway; bytes per launch do not depend on what runs beside it).  Trace pass
+    (BENCH_PMC_ROUNDS rounds): the timed region's own native loop, BENCH_PMC_STREAMS launches in flight on the context's streams."""
     import torch
 
     from basisu_rs_amd import Context, _lib, synth
 
     ctx = Context(0)
+    ctx.set_launch_policy(os.environ.get("BENCH_PMC_POLICY", "shared") == "shared")
     g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
     dev = torch.device("cuda", 0)
     gu = torch.from_numpy(g["uastc"]).to(dev)
@@ -84,6 +86,7 @@ def pmc_child():
         outs.append(torch.empty((N_BLOCKS, 16), dtype=torch.uint8, device=dev))
     torch.cuda.synchronize()
     rounds = max(1, int(os.environ.get("BENCH_PMC_ROUNDS", "1")))
+    streams = max(1, int(os.environ.get("BENCH_PMC_STREAMS", "1")))
     if rounds == 1:
         for k in range(24):
             ctx.transcode_device(_lib.BC7, ins[k], N_BLOCKS, outs[k], blocks_per_row=NBX)
@@ -91,9 +94,9 @@ def pmc_child():
         #    idle GPU between launches, and a kernel that starts on an idle chip takes ~1 us longer)
         lib = _lib.load()
         PtrArr = ctypes.c_void_p * 24
-        ms = ctypes.c_float(0)
-        st = lib.bu_time_uastc_launches(ctx.handle, _lib.BC7, PtrArr(*[t.data_ptr() for t in ins]), PtrArr(*[t.data_ptr() for t in outs]), 24, 0, N_BLOCKS, NBX,
-                                        24 * rounds, None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(ms))
+        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+        st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, PtrArr(*[t.data_ptr() for t in ins]), PtrArr(*[t.data_ptr() for t in outs]), 24, 0,
+                                                       N_BLOCKS, NBX, 0, 24 * rounds, streams, None, ctypes.byref(ev), ctypes.byref(host), None)
         assert st == 0
     torch.cuda.synchronize()
     ctx.close()
@@ -118,7 +121,7 @@ def _run_child(cmd, env, timeout_s):
         raise
 
 
-def live_traffic(timeout_s=90):
+def live_traffic(in_flight=1, policy="shared", timeout_s=90):
     """HBM bytes per launch of the BC7 kernel MEASURED IN THIS RUN: two child rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE,
     then WRITE_SIZE: separate passes, nothing but --kernel-trace beside --pmc, the program directly after `--`) over
     `bench.py --pmc-child`, run before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB; gfx950 reports half of
@@ -139,7 +142,7 @@ def live_traffic(timeout_s=90):
         return None, "this run is itself being profiled", None
     vals, t0 = {}, time.time()
     work = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BENCH_PMC_POLICY=policy, BENCH_PMC_STREAMS=str(in_flight))
     trace, note = None, None
     is_bc7 = lambda name: "bu_uastc_sorted_kernel<1," in name.replace("(int)", "")
     try:
@@ -152,18 +155,26 @@ def live_traffic(timeout_s=90):
             for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if is_bc7(row["Kernel_Name"]):
-                        rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+                        rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row.get("Queue_Id", "")))
             rows.sort()
             rows = rows[len(rows) // 4:]  # the first launches start from idle clocks
             if rc == 0 and len(rows) >= 64:
-                dur = [e - s_ for s_, e in rows]
+                dur = [e - s_ for s_, e, _ in rows]
                 per = [rows[i + 1][0] - rows[i][0] for i in range(len(rows) - 1)]
                 per = [x for x in per if x < 10 * (sum(dur) / len(dur))]  # (the host falls behind now and then: not a period)
-                trace = {"launches": len(rows), "kernel_avg_ns": round(sum(dur) / len(dur), 1), "kernel_min_ns": min(dur),
-                         "period_avg_ns": round(sum(per) / max(1, len(per)), 1),
+                ends = sorted(e for _, e, _ in rows)
+                eper = [ends[i + 1] - ends[i] for i in range(len(ends) - 1)]
+                eper = [x for x in eper if x < 10 * (sum(dur) / len(dur))]
+                wall = max(e for _, e, _ in rows) - rows[0][0]
+                trace = {"launches": len(rows), "launches_in_flight_requested": in_flight, "launch_policy": policy,
+                         "kernel_avg_ns": round(sum(dur) / len(dur), 1), "kernel_min_ns": min(dur),
+                         "period_avg_ns": round(sum(per) / max(1, len(per)), 1), "end_to_end_period_avg_ns": round(sum(eper) / max(1, len(eper)), 1),
                          "starts_before_previous_end": sum(1 for i in range(len(rows) - 1) if rows[i + 1][0] < rows[i][1]),
-                         "source": "child rocprofv3 --kernel-trace pass (no counters) over `bench.py --pmc-child`: 64 rounds x 24 cold atlases enqueued back to back "
-                                   "by bu_time_uastc_launches, the last three quarters counted; period = start-to-start of consecutive launches"}
+                         "avg_kernels_running": round(sum(dur) / max(1, wall), 2), "hardware_queues_used": len(set(q for _, _, q in rows)),
+                         "source": "child rocprofv3 --kernel-trace pass (no counters) over `bench.py --pmc-child`: 64 rounds x 24 cold atlases enqueued up front by "
+                                   "bu_time_uastc_launches_streams_window on %d context stream(s), the last three quarters counted; kernel_avg = span of one dispatch "
+                                   "(with several launches in flight a span is about that many periods); period = start-to-start of consecutive launches "
+                                   "(end_to_end: end-to-end); avg_kernels_running = sum of spans / wall time" % in_flight}
         except Exception as e:  # the trace pass is a cross-check: without it the counter passes still run
             trace = {"error": "%s: %s" % (type(e).__name__, e)}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -262,6 +273,13 @@ def main():
                     help="untimed launches BEFORE the W warm-up steps until this many milliseconds have passed: the GPU needs ~20 ms of "
                          "sustained work to reach its steady clocks (measured: 10.46 us per launch after --warmup 5, 9.8-9.9 after --warmup 2000 "
                          "or more); with it --warmup 5 --steps 20 and --warmup 64 --steps 512 agree.  0 disables")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="launches in flight: step i is issued on context stream i %% IN_FLIGHT (1..8).  One launch over a 4096^2 atlas waits ~3.4 us for "
+                         "HBM with the ALUs idle and then computes with HBM idle, and launches on ONE stream never overlap; independent atlases on several "
+                         "streams do.  1 = one launch at a time (the round 1-4 headline; always reported under extra.one_launch_at_a_time)")
+    ap.add_argument("--policy", choices=("shared", "exclusive"), default=None,
+                    help="launch policy of the context (bu_context_set_launch_policy): shared = a launch keeps at most half of every CU so that launches "
+                         "of different streams run side by side (default when --in-flight > 1), exclusive = a launch fills the chip by itself")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the verified, timed headline launches (no context rows, no CPU leg): the command profiled with rocprofv3, "
@@ -275,6 +293,10 @@ def main():
     if args.pmc_child:
         pmc_child()
         return
+    if not 1 <= args.in_flight <= 8:
+        raise SystemExit("bench: --in-flight must be 1..8")
+    if args.policy is None:
+        args.policy = "shared" if args.in_flight > 1 else "exclusive"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)  # does not return
     # roofline.traffic, measured: the counter passes are child processes, started before this process touches the GPU
@@ -283,7 +305,7 @@ def main():
     assert not torch.cuda.is_initialized()
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "atlas4096" and not args.headline_only and not args.no_live_traffic
             and os.environ.get("BENCH_FORCE_DIST") != "1"):
-        live = live_traffic()
+        live = live_traffic(args.in_flight, args.policy)
 
     # stdout carries exactly ONE line, the JSON result of rank 0: libraries print banners there (RCCL's version block lands
     # in the C stdio buffer and is flushed at exit, i.e. BEHIND a Python print when stdout is a pipe), so file descriptor 1
@@ -679,7 +701,7 @@ def run_atlas4096(env):
             gen = torch.Generator(device=dev)
             gen.manual_seed(1000 * rank + k)
             idx = torch.randint(0, 608, (N_BLOCKS,), device=dev, generator=gen)
-        idxs.append(idx if k < 2 else None)
+        idxs.append(idx)
         ins.append(g_uastc[idx].contiguous())
         outs.append(torch.empty((N_BLOCKS, 16), dtype=torch.uint8, device=dev))
     status = torch.empty(1, dtype=torch.int64, device=dev)
@@ -710,14 +732,29 @@ def run_atlas4096(env):
         rot[0] += lead + launches
         return ev.value / 1e3 / launches
 
-    def run_window(lead, launches):
+    def run_window(lead, launches, in_flight=None):
+        """the timed region: `lead` untimed launches, event 0, `launches` timed ones, step i on context stream i % in_flight, end event per stream"""
         ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
-        st = lib.bu_time_uastc_launches_window(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, lead, launches,
-                                               ctypes.c_void_p(status.data_ptr()), sp, ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+        st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, lead, launches,
+                                                       in_flight or args.in_flight, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
         if st != 0:
-            raise RuntimeError("bu_time_uastc_launches_window: " + lib.bu_status_string(st).decode())
+            raise RuntimeError("bu_time_uastc_launches_streams_window: " + lib.bu_status_string(st).decode())
         rot[0] += lead + launches
         return ev.value, host.value, late.value
+
+    def srow(launches, in_flight, shared, target=_lib.BC7, inp=in_ptrs, outp=out_ptrs, nb=nbuf, lead=64):
+        """seconds per atlas of a context row with `in_flight` launches in flight under the given launch policy (the headline's method)"""
+        ctx.set_launch_policy(shared)
+        try:
+            ev, host = ctypes.c_float(0), ctypes.c_float(0)
+            st = lib.bu_time_uastc_launches_streams_window(ctx.handle, target, inp, outp, nb, rot[0] % nb, N_BLOCKS, NBX, lead, launches, in_flight,
+                                                           ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None)
+            if st != 0:
+                raise RuntimeError("bu_time_uastc_launches_streams_window: " + lib.bu_status_string(st).decode())
+            rot[0] += lead + launches
+            return max(ev.value, host.value) / 1e3 / launches
+        finally:
+            ctx.set_launch_policy(policy_now[0])
 
     def ramp(**kw):
         """untimed launches of the row's own kernel for --prewarm-ms (at least 64): the rows after the host-side phases
@@ -727,12 +764,16 @@ def run_atlas4096(env):
         while args.prewarm_ms > 0 and (time.perf_counter() - t0) * 1e3 < args.prewarm_ms:
             run(128, **kw)
 
-    # ---- correctness gate before any timing: full-size, self-verifying ----
+    # ---- correctness gate before any timing: full-size, self-verifying, through the headline's own path (policy, streams) ----
+    policy_now = [args.policy == "shared"]  # the context's launch policy outside srow()
+    ctx.set_launch_policy(policy_now[0])
     ctx.status_word_reset(status)
-    run(min(2, nbuf))
+    torch.cuda.synchronize()  # (the context's streams do not wait for torch's)
+    run_window(0, nbuf)       # one launch per atlas, round-robin over the streams
+    rot[0] = 0
     torch.cuda.synchronize()
     ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
-    for k in range(min(2, nbuf)):
+    for k in range(nbuf):
         if not torch.equal(outs[k], g_bc7[idxs[k]]):
             raise SystemExit("bench: BC7 output of atlas %d differs from the known-answer vectors" % k)
 
@@ -740,10 +781,10 @@ def run_atlas4096(env):
     prewarm_launches = 0
     t_pre = time.perf_counter()
     while args.prewarm_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        run(256)
+        run_window(0, 256)
         prewarm_launches += 256
     if args.warmup > 0:
-        run(args.warmup)
+        run_window(0, args.warmup)
     torch.cuda.synchronize()
 
     def warm_async(i, ssp):  # an untimed launch on the side stream, rotating like the timed ones
@@ -774,10 +815,16 @@ def run_atlas4096(env):
 
     total_blocks = world * args.steps * N_BLOCKS
     value = total_blocks / dt_max / 1e6
-    kern_s = ev_max / args.steps  # average launch duration (slowest rank), HIP events
-    achieved = BYTES_PER_BLOCK * N_BLOCKS / kern_s / 1e9
+    period_s = ev_max / args.steps  # launch-to-launch period of the timed region (slowest rank), HIP events
+    achieved = BYTES_PER_BLOCK * N_BLOCKS / period_s / 1e9
 
-    # per-launch distribution (outside the timed region): one event between every two launches of another K steps
+    # ---- the round 1-4 headline, kept as a row: ONE launch at a time (exclusive policy, one stream), same window method ----
+    policy_now[0] = False
+    ctx.set_launch_policy(False)
+    run_window(0, 256, in_flight=1)
+    one_ev, one_host, _ = run_window(lead, args.steps, in_flight=1)
+    one_s = max(one_ev, one_host) / 1e3 / args.steps
+    # per-launch distribution: one event between every two launches of another K steps
     each = (ctypes.c_float * args.steps)()
     st = lib.bu_time_uastc_launches_each(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, args.steps,
                                          ctypes.c_void_p(status.data_ptr()), sp, each)
@@ -787,9 +834,11 @@ def run_atlas4096(env):
         v = np.sort(np.array(list(each), dtype=np.float64))
         per_launch = {"median_us": round(float(np.median(v)), 3), "min_us": round(float(v[0]), 3), "p90_us": round(float(v[int(0.9 * (len(v) - 1))]), 3),
                       "max_us": round(float(v[-1]), 3),
-                      "note": "event-to-event time of each launch in a separate pass of K steps (the event packets between launches are "
-                              "included; the mean above comes from one event pair around the K timed steps; rocprofv3's per-kernel "
-                              "durations under profiles/ are the authority for kernel-only time)"}
+                      "note": "event-to-event time of each launch in a separate pass of K steps, one launch at a time (the event packets between launches are included)"}
+    one_row = {"us_per_launch": round(one_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / one_s / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / one_s / 1e9, 1),
+               "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / one_s / 1e9 / HBM_PEAK_GBS, 4), "launch_policy": "exclusive", "per_launch": per_launch,
+               "note": "the headline of rounds 1-4: K launches back to back on ONE stream, exclusive launch policy (a launch fills the chip by itself); "
+                       "consecutive launches of one stream do not overlap, so this is also one launch's own duration"}
 
     extra = {}
     if rank == 0 and not args.headline_only:
@@ -807,14 +856,41 @@ def run_atlas4096(env):
         hot_s = row(max(args.steps, 64), inp=one_in, outp=one_out, nb=1)
         extra["hot_cache"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / hot_s / 1e9, 1), "us_per_launch": round(hot_s * 1e6, 3),
                               "note": "same atlas every launch (32 MiB working set sits in the 256 MiB Infinity Cache) -- NOT the headline"}
-        # independent atlases in flight on several streams (how a production loop over slices would run): throughput row
-        for ns in (2, 4):
-            ms = ctypes.c_float(0)
-            lib.bu_time_uastc_launches_streams(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, N_BLOCKS, NBX, 64, ns, ctypes.byref(ms))
-            lib.bu_time_uastc_launches_streams(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, N_BLOCKS, NBX, args.steps, ns, ctypes.byref(ms))
-            ss = ms.value / 1e3 / args.steps
-            extra["streams_%d" % ns] = {"us_per_atlas": round(ss * 1e6, 3), "mblocks_s": round(N_BLOCKS / ss / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / ss / 1e9, 1),
-                                        "note": "%d HIP streams, launches of independent atlases overlap; wall clock; not the roofline row" % ns}
+        # launches in flight x launch policy (the headline's cell among its neighbours; same window method, same rotation, 256 timed launches)
+        try:
+            mat = {}
+            for pol in ("exclusive", "shared"):
+                mat[pol] = {}
+                for nfl in (1, 2, 3, 4):
+                    srow(64, nfl, pol == "shared")
+                    mat[pol][str(nfl)] = round(srow(256, nfl, pol == "shared") * 1e6, 3)
+            torch.cuda.synchronize()
+            extra["launches_in_flight_matrix"] = {"us_per_atlas": mat, "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
+                                                  "note": "UASTC->BC7, 2^20 blocks per launch, step i on context stream i % n; rows = launch policy, columns = launches in flight; "
+                                                          "every one of the %d rotated outputs compared with the known answers afterwards" % nbuf}
+            # cross-check of the overlap claim through the product's other route to it: TWO atlases in ONE launch (bu_uastc_transcode_batch_device
+            # merges nothing here -- separate allocations -- so the run-table kernel walks both), one launch at a time on one stream
+            VP2, SZ2 = ctypes.c_void_p * 2, ctypes.c_size_t * 2
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def two(k):
+                a, b = (2 * k) % nbuf, (2 * k + 1) % nbuf
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, 2, VP2(in_ptrs[a], in_ptrs[b]), SZ2(N_BLOCKS, N_BLOCKS), VP2(out_ptrs[a], out_ptrs[b]),
+                                                           NBX, None, None, sp) == 0
+
+            for k in range(64):
+                two(k)
+            e0.record(stream)
+            for k in range(128):
+                two(k)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            two_s = e0.elapsed_time(e1) / 1e3 / 256
+            extra["atlases_2_one_launch"] = {"us_per_atlas": round(two_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / two_s / 1e6, 1),
+                                             "verified": bool(torch.equal(outs[0], g_bc7[idxs[0]])) and bool(torch.equal(outs[1], g_bc7[idxs[1]])),
+                                             "note": "two atlases per call of bu_uastc_transcode_batch_device (one kernel launch over both), calls back to back on one stream"}
+        except Exception as e:  # secondary rows must never break the headline line
+            extra["launches_in_flight_matrix_error"] = repr(e)
         # a loop over 64 independent slices of 65 536 blocks (256 x 256 blocks: a 1024 x 1024 px mip), the shape of the per-slice
         # loops of basis.rs:246-257: launches back to back on one stream, round-robin on 2 and 4 streams (the rejected alternatives),
         # the batch entry point on separate allocations (ONE launch per 96 runs on the caller's stream, the run table in the kernel
@@ -959,12 +1035,28 @@ def run_atlas4096(env):
                                            "note": "bu_host_alloc buffers: kernels read/write host memory directly over PCIe (no staging copies) -- never the headline value"}
         ctx.host_free(pin_in)
         ctx.host_free(pin_out)
-        # the other block-linear targets of the same atlas (secondary rows; cold rotation over the same buffers)
+        # the other block-linear targets of the same atlas (secondary rows; cold rotation over the same buffers): one launch at a time under
+        # the exclusive policy, and four in flight under the shared policy (the headline's method), both verified against the known answers
         for tname, tcode, bpb in (("astc", _lib.ASTC, 32), ("etc1", _lib.ETC1, 24), ("etc2", _lib.ETC2, 32)):
+            g_t = torch.from_numpy(golden[tname]).to(dev)
+
+            def t_ok():
+                torch.cuda.synchronize()
+                got = [outs[k] if bpb != 24 else outs[k].view(-1)[: N_BLOCKS * 8].view(N_BLOCKS, 8) for k in (0, 1, nbuf - 1)]
+                return all(bool(torch.equal(g_, g_t[idxs[k]])) for g_, k in zip(got, (0, 1, nbuf - 1)))
+
             ramp(target=tcode)
             ts = row(256, target=tcode)
+            ok1 = t_ok()
+            srow(128, 4, True, target=tcode)
+            t4 = srow(256, 4, True, target=tcode)
+            ok4 = t_ok()
             extra["uastc_to_" + tname] = {"gb_s": round(bpb * N_BLOCKS / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3),
-                                          "mblocks_s": round(N_BLOCKS / ts / 1e6, 1), "bytes_per_block": bpb}
+                                          "mblocks_s": round(N_BLOCKS / ts / 1e6, 1), "bytes_per_block": bpb, "frac_of_hbm_peak": round(bpb * N_BLOCKS / ts / 1e9 / HBM_PEAK_GBS, 4),
+                                          "verified": ok1,
+                                          "in_flight_4_shared": {"us_per_atlas": round(t4 * 1e6, 3), "mblocks_s": round(N_BLOCKS / t4 / 1e6, 1), "gb_s": round(bpb * N_BLOCKS / t4 / 1e9, 1),
+                                                                 "frac_of_hbm_peak": round(bpb * N_BLOCKS / t4 / 1e9 / HBM_PEAK_GBS, 4), "verified": ok4}}
+            del g_t
         # config 4 shape: ETC1S 2048x2048 (512x512 blocks), 4096-entry endpoint / 8192-entry selector codebooks
         try:
             from basisu_rs_amd import etc1s_selector_from_rows
@@ -1121,7 +1213,16 @@ def run_atlas4096(env):
         extra["uastc_to_rgba32"] = {"gb_s": round(80 * N_BLOCKS / rg_s / 1e9, 1), "us_per_launch": round(rg_s * 1e6, 3),
                                     "mblocks_s": round(N_BLOCKS / rg_s / 1e6, 1), "bytes_per_block": 80,
                                     "frac_of_hbm_peak": round(80 * N_BLOCKS / rg_s / 1e9 / HBM_PEAK_GBS, 4), "verified": rg_ok,
-                                    "note": "BASELINE config 3: 4096x4096 UASTC -> RGBA32 (16 B in + 64 B out per block), cold rotation over 16 atlases"}
+                                    "note": "BASELINE config 3: 4096x4096 UASTC -> RGBA32 (16 B in + 64 B out per block), cold rotation over 16 atlases, one launch at a time"}
+        try:
+            srow(64, 3, False, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
+            rg3 = srow(256, 3, False, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
+            torch.cuda.synchronize()
+            rg3_ok = bool(torch.equal(rg_out[1].view(NBY, 4, NBX, 16).permute(0, 2, 1, 3).reshape(N_BLOCKS, 64), torch.from_numpy(golden["rgba"]).to(dev)[idxs[1]]))
+            extra["uastc_to_rgba32"]["in_flight_3_exclusive"] = {"us_per_atlas": round(rg3 * 1e6, 3), "gb_s": round(80 * N_BLOCKS / rg3 / 1e9, 1),
+                                                                 "frac_of_hbm_peak": round(80 * N_BLOCKS / rg3 / 1e9 / HBM_PEAK_GBS, 4), "verified": rg3_ok}
+        except Exception as e:
+            extra["uastc_to_rgba32"]["in_flight_error"] = repr(e)
         del rg_out
 
 
@@ -1138,19 +1239,28 @@ def run_atlas4096(env):
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "UASTC->BC7, 4096x4096 px (1 048 576 blocks) per GPU per step, A-gold atlas "
+        "config": {"workload": "UASTC->BC7, 4096x4096 px (1 048 576 blocks) per GPU per step, ONE launch per step, A-gold atlas "
                                "(block i = reference known-answer block h(i) mod 608, uniform mix of the 19 modes), "
-                               "%d distinct atlases rotated (cold cache)" % nbuf,
+                               "%d distinct atlases rotated (cold cache); %s" % (
+                                   nbuf, ("%d launches in flight on %d streams (step i on context stream i %% %d), %s launch policy" % (
+                                       args.in_flight, args.in_flight, args.in_flight, args.policy)) if args.in_flight > 1 else "one launch at a time on one stream, %s launch policy" % args.policy),
+                   "launches_in_flight": args.in_flight, "launch_policy": args.policy,
                    "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1),
                    "prewarm": {"launches": prewarm_launches, "ms": args.prewarm_ms,
                                "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"},
                    "timed_region": {"lead_launches": lead, "host_ms": round(host_ms, 6), "event_ms": round(ev_ms, 6), "host_started_late": bool(late),
-                                    "note": "barrier + synchronize, then lead untimed launches, event 0, K timed launches, event 1 enqueued back to "
-                                            "back; host clock from event 0 seen complete to event 1 seen complete; value uses max(host, event)"}},
+                                    "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, "
+                                            "event 0 in front of the first timed launch on its stream, K timed launches, one end event per stream; the window "
+                                            "closes when the LAST end event completes (the pipeline's drain is inside it); host clock from event 0 seen complete "
+                                            "to every end event seen complete; value uses max(host, event)"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                     "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
-                     "bytes_per_launch": BYTES_PER_BLOCK * N_BLOCKS, "per_launch": per_launch},
+                     "kernel": "bu_uastc_sorted_kernel<BC7> (%s-policy shape)" % args.policy,
+                     "launches_in_flight": args.in_flight, "period_ns": round(period_s * 1e9, 1), "us_per_launch": round(period_s * 1e6, 3),
+                     "bytes_per_launch": BYTES_PER_BLOCK * N_BLOCKS,
+                     "note": "achieved = algorithmic bytes per launch / launch-to-launch PERIOD of the K timed launches (HIP events on the launch streams); with "
+                             "several launches in flight one launch's own span is longer than the period -- kernel_span_ns below, from this run's rocprofv3 "
+                             "kernel trace -- and the chip works on about span / period launches at a time"},
     }
     tr = pmc_traffic()
     if tr:
@@ -1160,10 +1270,11 @@ def run_atlas4096(env):
     if tr3:
         line["roofline"]["rocprofv3_this_run"] = tr3
         if tr3.get("kernel_avg_ns"):
-            # two clocks, both reported: `frac` above = bytes / (event time of the K timed launches / K), a throughput-of-a-stream
-            # figure; this one = bytes / rocprofv3's per-kernel average of the same kernel in this run's child trace pass
-            line["roofline"]["kernel_avg_ns_this_run"] = tr3["kernel_avg_ns"]
-            line["roofline"]["frac_by_rocprofv3_kernel_avg"] = round(BYTES_PER_BLOCK * N_BLOCKS / tr3["kernel_avg_ns"] / HBM_PEAK_GBS, 4)
+            # two clocks, both reported: `frac` above = bytes / (event time of the K timed launches / K); the child trace pass of this run gives
+            # the span of one dispatch and the start-to-start period of the same launches under the profiler
+            line["roofline"]["kernel_span_ns"] = tr3["kernel_avg_ns"]
+            line["roofline"]["period_ns_by_rocprofv3"] = tr3["period_avg_ns"]
+            line["roofline"]["frac_by_rocprofv3_period"] = round(BYTES_PER_BLOCK * N_BLOCKS / tr3["end_to_end_period_avg_ns"] / HBM_PEAK_GBS, 4)
     if env.live_traffic[0] is not None:
         line["roofline"]["traffic"] = env.live_traffic[0]
         line["roofline"]["traffic_source"] = env.live_traffic[1]
@@ -1176,9 +1287,10 @@ def run_atlas4096(env):
             # measured in-kernel from s_memtime / s_memrealtime)
             simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
             peak = simds * 2.35e9 / 4.2 / 1e9
-            rate = tr[2] / kern_s / 1e9
+            rate = tr[2] / period_s / 1e9
             extra["valu_issue"] = {"wave_instructions_per_launch": int(tr[2]), "achieved_g_per_s": round(rate, 1), "peak_g_per_s": round(peak, 1),
                                    "frac": round(rate / peak, 3), "source": tr[1] + " (SQ_INSTS_VALU of the committed counter pass -- read from that file, NOT measured in this run)"}
+    extra["one_launch_at_a_time"] = one_row
     line["extra"] = extra
     allgather = None
     if use_dist:

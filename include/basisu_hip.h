@@ -77,6 +77,31 @@ const char* bu_last_error(const bu_context* ctx);
 /* bytes per output block: 16, 16, 8, 16, 64 (uastc.rs:13-17); 0 for an unknown target */
 size_t bu_target_block_bytes(bu_target target);
 
+/* ---- launch policy -------------------------------------------------------------------------------
+ * How much of the chip ONE large launch of the slice-level transcode takes (a property of the context, read by
+ * bu_uastc_transcode_device / _batch_device and everything built on them at the moment they enqueue; results never depend on it).
+ * The reference's slice loop (uastc.rs:112-165, basis.rs:246-257) runs slices one after another; on the GPU a launch over one
+ * 4096 x 4096 slice spends its first ~3.4 us waiting for HBM with the ALUs idle and the rest computing with HBM idle, and launches
+ * queued on ONE stream never overlap (the queue drains between two dispatches).  A caller with several independent slices gets
+ * both resources busy by issuing them round-robin on 2-4 streams:
+ *   BU_LAUNCH_EXCLUSIVE (default)  a launch is shaped to fill the chip by itself: lowest latency for a single slice (UASTC->BC7,
+ *                                  2^20 blocks: 8.4 us); 6.3-6.7 us per slice with 2-3 streams (head / tail overlap only)
+ *   BU_LAUNCH_SHARED               a launch keeps at most half of every CU's wave slots, registers and LDS, so launches from different
+ *                                  streams run side by side on each CU: 5.9-6.1 us per slice with 3-4 streams (BC7), ETC1 17.7 -> 12.2,
+ *                                  ETC2 22.1 -> 15.2; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
+ * Figures: profiles/r05_ab_*_shapes_x_streams*.txt.  Small launches (at most one 1024-block tile per CU) are the same under both. */
+typedef enum bu_launch_policy { BU_LAUNCH_EXCLUSIVE = 0, BU_LAUNCH_SHARED = 1 } bu_launch_policy;
+bu_status bu_context_set_launch_policy(bu_context* ctx, bu_launch_policy policy);
+bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* out_policy);
+/* The context's own streams, index 0..7 (hipStream_t, created on first use, destroyed with the context): what a caller that wants
+ * several launches in flight can issue them on.  Launches only overlap when their streams sit on DIFFERENT hardware queues, and the
+ * HIP runtime multiplexes all streams of a process over GPU_MAX_HW_QUEUES (default 4) queues per priority level -- two streams that
+ * share one run their kernels strictly one after the other.  These streams are spread over the priority levels in pairs (0, 1 normal;
+ * 2, 3 high; 4, 5 low; 6, 7 normal) so that streams 0..3 land on four different queues under the runtime's defaults.  A caller that
+ * brings its own streams should create them the same way or run with GPU_MAX_HW_QUEUES >= streams + 2 in the environment.  The
+ * streams are non-blocking: they do not synchronise with the NULL stream. */
+bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream);
+
 /* ---- UASTC slice level, host pointers ------------------------------------------------------- */
 
 /* uastc::Decoder::transcode / _transcode_into (uastc.rs:112-146): n = in_bytes/16 blocks in
@@ -342,6 +367,17 @@ bu_status bu_time_uastc_launches_each(bu_context* ctx, bu_target target, const v
 bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                          size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches, int n_streams,
                                          float* out_ms);
+/* bu_time_uastc_launches_window with SEVERAL launches in flight: launch i (lead and timed) goes to context-owned stream
+ * i % n_streams (1..8), everything enqueued up front.  Event 0 sits on the stream of the first timed launch, directly in front of
+ * it -- the other streams' last lead launches are still running when it fires, the window opens on a full pipeline --; every stream
+ * gets an end event behind its last timed launch and the window closes when the LAST of them has completed, so the drain of the
+ * pipeline is inside it.  *out_event_ms = max over streams of hipEventElapsedTime(event 0, that stream's end event); *out_host_ms =
+ * host steady clock from "event 0 seen complete" to "every end event seen complete"; *out_late as above.  The per-atlas figure
+ * (window / launches) is a launch-to-launch PERIOD; one launch's own span is longer (about n_streams periods). */
+bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
+                                                size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,
+                                                int lead, int launches, int n_streams, uint64_t* d_status, float* out_event_ms,
+                                                float* out_host_ms, int* out_late);
 /* The reference's micro-benchmark shape (benches/benchmark.rs:66-98): `reps` passes over `n_blocks` blocks, one per-block API
  * call per block (RGBA32: bu_unpack_uastc_block_to_rgba), host steady clock around the loop; nanoseconds per call. */
 bu_status bu_time_block_api(bu_context* ctx, bu_target target, const uint8_t* blocks, size_t n_blocks, int reps, uint8_t* out,

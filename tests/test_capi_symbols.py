@@ -88,7 +88,7 @@ def test_rust_facade_declarations_match_the_header():
 
 # ---- type-level check of the uncompiled Rust binding -------------------------------------------------------------------------
 _C_SCALARS = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "int": "c_int", "float": "f32",
-              "char": "c_char", "void": "c_void", "bu_status": "c_int", "bu_target": "c_int", "bu_read_target": "c_int",
+              "char": "c_char", "void": "c_void", "bu_status": "c_int", "bu_target": "c_int", "bu_read_target": "c_int", "bu_launch_policy": "c_int",
               "bu_context": "bu_context", "bu_comm": "bu_comm", "bu_basis_header": "bu_basis_header", "bu_slice_desc": "bu_slice_desc",
               "bu_image": "bu_image"}
 

@@ -1,0 +1,148 @@
+"""Round-5 GPU tests: the shared launch policy (bu_context_set_launch_policy: half-CU shapes of the mode-sorted kernel, meant for several
+launches in flight on different streams) must give the exclusive policy's bytes and status words on every target, on both tile layouts,
+on ragged sizes and through the oracle on random blocks; the multi-stream timing window of bench.py must really run every launch on
+every stream.  Everything goes through the C ABI; bit-exact.  Run on the GPU box: pytest -m gpu."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from basisu_rs_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+TB = {"astc": (_lib.ASTC, 16), "bc7": (_lib.BC7, 16), "rgba": (_lib.RGBA32, 64), "etc1": (_lib.ETC1, 8), "etc2": (_lib.ETC2, 16)}
+
+
+def _unrgba(a, rows, bpr):
+    return a.reshape(rows, 4, bpr, 16).transpose(0, 2, 1, 3).reshape(rows * bpr, 64)
+
+
+@pytest.mark.parametrize("target", ["astc", "bc7", "rgba", "etc1", "etc2"])
+def test_shared_policy_known_answers_both_layouts_and_first_error(golden, target):
+    """every slice size here takes the LARGE shape of its target (more than one tile per CU; ETC: more than three), so the shared
+    policy's own instantiations run: rectangular tiles, strips, ragged tails, pieces that do not fill the last workgroup's walk"""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    ctx.set_launch_policy(True)
+    t, bb = TB[target]
+    shapes = [(1024, 1024), (1024, 1056), (2048, 512), (512, 2080), (0, (1 << 20) + 12345), (96, 11000), (1024, 1400)]
+    for bpr, rows in shapes:
+        n = (bpr or 1) * rows
+        idx = synth.gold_indices(n, seed=501 + bpr + rows)
+        blocks = golden["uastc"][idx].copy()
+        d_in = torch.from_numpy(blocks).cuda()
+        if target == "rgba":
+            if bpr == 0:
+                continue
+            d_out = torch.zeros((rows * 4, bpr * 16), dtype=torch.uint8, device="cuda")
+        else:
+            d_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+        ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr)
+        torch.cuda.synchronize()
+        got = _unrgba(d_out.cpu().numpy(), rows, bpr) if target == "rgba" else d_out.cpu().numpy()
+        assert (got == golden[target][idx]).all(), (target, bpr, rows)
+        bad_hi, bad_lo = n - 2, (n * 3) // 8 + 5
+        blocks[bad_hi, 0] = 69  # the one invalid 7-bit mode code (uastc.rs:560-577)
+        blocks[bad_lo, 0] = 69
+        d_in = torch.from_numpy(blocks).cuda()
+        st = torch.empty(1, dtype=torch.int64, device="cuda")
+        ctx.status_word_reset(st)
+        ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr, d_status=st)
+        torch.cuda.synchronize()
+        with pytest.raises(BasisuError) as e:
+            ctx.status_word_check(int(st.item()))
+        assert e.value.status == _lib.ERR_INVALID_MODE and e.value.first_bad_block == bad_lo, (target, bpr, rows)
+        got = _unrgba(d_out.cpu().numpy(), rows, bpr) if target == "rgba" else d_out.cpu().numpy()
+        assert not got[bad_lo].any() and not got[bad_hi].any()  # a failing block's result is zeros under either policy
+    ctx.close()
+
+
+@pytest.mark.parametrize("target", ["astc", "bc7", "etc1", "etc2", "rgba"])
+def test_shared_policy_against_the_oracle_on_random_and_high_contrast_blocks(oracle, target):
+    """what the known answers do not reach (partitions, BC7 mode-5 fallback, etc2tm == 0, saturating selector lanes): 1.25 Mi random
+    valid blocks and a high-contrast atlas through the shared policy's shapes against the CPU restatement of the reference"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    ctx.set_launch_policy(True)
+    t, bb = TB[target]
+    n = (1 << 20) + (1 << 18)
+    blocks = np.concatenate([synth.atlas_rand(1 << 20, seed=55), synth.atlas_contrast(1 << 18, seed=56)])
+    d_in = torch.from_numpy(blocks).cuda()
+    bpr = 1024
+    if target == "rgba":
+        d_out = torch.zeros((n // bpr * 4, bpr * 16), dtype=torch.uint8, device="cuda")
+    else:
+        d_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+    ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr)
+    torch.cuda.synchronize()
+    if target == "rgba":
+        st, _, want = oracle.decode_to_rgba(blocks.tobytes(), bpr)
+        assert st == 0
+        assert (d_out.cpu().numpy().reshape(-1) == np.asarray(want).reshape(-1)).all()
+    else:
+        want, st = oracle.batch(target, blocks)
+        assert (st == 0).all()
+        assert (d_out.cpu().numpy() == want.reshape(n, bb)).all()
+    ctx.close()
+
+
+def test_policy_round_trip_and_argument_check():
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    lib = ctx._lib
+    p = ctypes.c_int(-1)
+    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 0
+    assert lib.bu_context_set_launch_policy(ctx.handle, 1) == 0
+    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 1
+    assert lib.bu_context_set_launch_policy(ctx.handle, 7) == _lib.ERR_ARGUMENT
+    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 1
+    assert lib.bu_context_set_launch_policy(ctx.handle, 0) == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("streams", [1, 3, 4])
+def test_streams_window_runs_every_launch_on_every_stream(golden, shared, streams):
+    """bu_time_uastc_launches_streams_window: lead + timed launches round-robin over the context's streams; afterwards EVERY rotated
+    output holds the known answers (a launch skipped, or two launches racing on one buffer, would show), the two clocks agree, and the
+    per-launch period is in the range a 2^20-block BC7 launch can have"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    ctx.set_launch_policy(shared)
+    lib = ctx._lib
+    n, nbuf = 1 << 20, 12
+    vp = ctypes.c_void_p
+    idxs = [synth.gold_indices(n, seed=900 + k) for k in range(nbuf)]
+    ins = [torch.from_numpy(golden["uastc"][i]).cuda() for i in idxs]
+    outs = [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    A = vp * nbuf
+    ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+    lead, launches = 5, 19  # (neither a multiple of the stream counts: every stream carries lead and timed launches, unevenly)
+    st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 3, n, 1024,
+                                                   lead, launches, streams, vp(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+    assert st == 0, lib.bu_status_string(st)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(golden["bc7"]).cuda()
+    for k in range(nbuf):  # 24 launches over 12 buffers from buffer 3 on: every buffer was written
+        assert torch.equal(outs[k], want[torch.from_numpy(idxs[k]).cuda()]), k
+    ctx.status_word_check(int(status.item()))
+    us = ev.value * 1e3 / launches
+    assert 3.0 < us < 40.0, us
+    assert abs(host.value - ev.value) < 0.5 * ev.value + 0.05, (host.value, ev.value)
+    # argument checks
+    assert lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 0, n, 1024,
+                                                     0, 4, 9, None, ctypes.byref(ev), ctypes.byref(host), None) == _lib.ERR_ARGUMENT
+    ctx.close()
