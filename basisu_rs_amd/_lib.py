@@ -185,8 +185,8 @@ def load():
     lib.bu_memcpy.restype = c.c_int
     lib.bu_time_uastc_launches_streams.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, c.c_int, c.POINTER(c.c_float)]
     lib.bu_time_uastc_launches_streams.restype = c.c_int
-    lib.bu_time_uastc_launches_streams_window.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, c.c_int, c.c_int, vp,
-                                                          c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_int)]
+    lib.bu_time_uastc_launches_streams_window.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, c.c_int, c.c_int, c.c_int, vp,
+                                                          c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_int)]
     lib.bu_time_uastc_launches_streams_window.restype = c.c_int
     lib.bu_time_copy_launches.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, c.c_int, vp, c.POINTER(c.c_float)]
     lib.bu_time_copy_launches.restype = c.c_int

@@ -139,22 +139,31 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
     return BU_OK;
 }
 
-// The window of bu_time_uastc_launches_window with SEVERAL launches in flight: launch i (lead and timed alike) goes to context
-// stream i % n_streams, everything is enqueued up front with no host synchronisation in between.  Streams advance independently, so the
-// window is taken over ALL of them: every stream gets a start event directly in front of its first timed launch and an end event
-// behind its last one, and
-//     event_ms = (latest end event) - (earliest start event)
+// The window of bu_time_uastc_launches_window with SEVERAL launches in flight: launch i (lead, timed and tail alike) goes to context
+// stream i % n_streams, everything is enqueued up front with no host synchronisation in between.  n launches in flight are a pipeline:
+// launch j starts about one period after launch j - 1 and is under way for about n periods, so "first instruction of the first timed
+// launch to last instruction of the last" spans launches + n - 1 periods, whatever runs before and behind.  Throughput is counted the
+// way a pipeline's is, in COMPLETIONS: every stream gets a start event behind its last lead launch (= in front of its first timed
+// launch) and an end event behind its last timed launch, and
+//     event_ms = (latest end event) - (latest start event)
 // on the device's clock (each measured from one reference event at the head of the call, which every stream waits for before its
-// first launch).  The window therefore opens on a full pipeline -- the other streams are in the middle of lead launches when the first
-// start event fires -- covers every timed launch from its first instruction to its last, and holds the drain of the pipeline (the final
-// launches running with fewer partners).  If the streams drift apart the window only gets LONGER (it then also spans lead launches of
-// the streams that lag).  host_ms = steady clock from "a start event first seen complete" to "every end event seen complete".
-// n_streams == 1 is bu_time_uastc_launches_window on a context stream.
+// first launch): from the moment the LAST LEAD launch has completed to the moment the LAST TIMED launch has completed -- in between,
+// exactly the `launches` timed launches complete.  With lead >= n_streams and tail >= n_streams (untimed launches behind the end
+// events, one per stream) the pipeline is full at both instants: the part of the first timed launches that was done before the window
+// opened (they run beside the last lead launches) is what the tail launches get done before it closes, so event_ms / launches is the
+// steady-state period.  (Without tail launches that balance is gone: the head start of the first timed launches is credited, nothing is
+// debited, and the figure comes out too SHORT -- use the strict bracket below for a run with nothing behind it.)
+// *out_fill_drain_ms (optional) = latest end event - EARLIEST start event: first instruction of the first timed launch to last
+// instruction of the last one, the strict bracket around the timed launches; launches + n_streams - 1 periods in a full pipeline, and
+// with lead = tail = 0 the whole run from an idle chip to an idle chip.
+// host_ms = steady clock from "every start event seen complete" to "every end event seen complete".
+// n_streams == 1, tail == 0 is bu_time_uastc_launches_window on a context stream.
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
-                                                size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches, int n_streams,
-                                                uint64_t* d_status, float* out_event_ms, float* out_host_ms, int* out_late)
+                                                size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches, int tail,
+                                                int n_streams, uint64_t* d_status, float* out_event_ms, float* out_host_ms, float* out_fill_drain_ms,
+                                                int* out_late)
 {
-    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || lead < 0 || !out_event_ms || !out_host_ms || n_streams < 1 || n_streams > 8)
+    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || lead < 0 || tail < 0 || !out_event_ms || !out_host_ms || n_streams < 1 || n_streams > 8)
         return BU_ERR_ARGUMENT;
     BU_HIP(ctx, hipSetDevice(ctx->device));
     {
@@ -169,43 +178,38 @@ bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target targe
     BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->extra_streams[0]));  // the reference point of every time below
     for (int i = 1; i < n_streams; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
     bool used[8] = {false, false, false, false, false, false, false, false};
-    for (int i = 0; i < lead + launches; i++) {
+    int last_timed[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // the number of each stream's last timed launch
+    for (int i = lead; i < lead + launches; i++) last_timed[i % n_streams] = i;
+    for (int i = 0; i < lead + launches + tail; i++) {
         const int si = i % n_streams;
         hipStream_t s = ctx->extra_streams[si];
-        if (i >= lead && !used[si]) {
+        if (i >= lead && i < lead + launches && !used[si]) {
             BU_HIP(ctx, hipEventRecord(ctx->ev_start[si], s));
             used[si] = true;
         }
         const size_t k = (first_buffer + (size_t)i) % n_buffers;
         bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, s);
         if (st) return st;
+        if (i == last_timed[si]) BU_HIP(ctx, hipEventRecord(ctx->ev_end[si], s));
     }
-    for (int i = 0; i < n_streams; i++)
-        if (used[i]) BU_HIP(ctx, hipEventRecord(ctx->ev_end[i], ctx->extra_streams[i]));
-    // host bracket: from the first start event seen complete ...
+    // host bracket: from every start event seen complete to every end event seen complete
     std::chrono::steady_clock::time_point t0, t1, t;
-    {
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(BU_SPIN_SECONDS);
-        bool seen = false;
-        for (unsigned n = 0; !seen; n++) {
-            for (int i = 0; i < n_streams && !seen; i++) {
-                if (!used[i]) continue;
-                const hipError_t q = hipEventQuery(ctx->ev_start[i]);
-                if (q == hipSuccess) seen = true;
-                else if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
-            }
-            if (n == 0 && out_late) *out_late = seen ? 1 : 0;
-            if (!seen && (n & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) {
-                snprintf(ctx->err, sizeof(ctx->err), "hipEventQuery: no start event after %.0f s", BU_SPIN_SECONDS);
-                return BU_ERR_HIP;
-            }
+    bool first_query = true;
+    for (int i = 0; i < n_streams; i++) {
+        if (!used[i]) continue;
+        if (first_query) {
+            const hipError_t q = hipEventQuery(ctx->ev_start[i]);
+            if (q != hipSuccess && q != hipErrorNotReady) return bu_fail(ctx, q, "hipEventQuery");
+            (void)hipGetLastError();
+            if (out_late) *out_late = q == hipSuccess ? 1 : 0;
+            first_query = false;
         }
-        t0 = std::chrono::steady_clock::now();
-        (void)hipGetLastError();
+        bu_status st = bu_spin_event(ctx, ctx->ev_start[i], &t);
+        if (st) return st;
+        if (i == 0 || t > t0) t0 = t;
     }
-    // ... to the last end event seen complete; device clock: latest end - earliest start, both measured from the reference event
     t1 = t0;
-    float first_start = 0, last_end = 0;
+    float first_start = 0, last_start = 0, last_end = 0;
     bool any = false;
     for (int i = 0; i < n_streams; i++) {
         if (!used[i]) continue;
@@ -216,15 +220,16 @@ bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target targe
         BU_HIP(ctx, hipEventElapsedTime(&ms_s, ctx->ev0, ctx->ev_start[i]));
         BU_HIP(ctx, hipEventElapsedTime(&ms_e, ctx->ev0, ctx->ev_end[i]));
         if (!any || ms_s < first_start) first_start = ms_s;
+        if (!any || ms_s > last_start) last_start = ms_s;
         if (!any || ms_e > last_end) last_end = ms_e;
         any = true;
     }
-    // (lead launches on streams that carry no timed launch -- more streams than timed launches -- finish before we return)
-    for (int i = 0; i < n_streams; i++)
-        if (!used[i]) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[i]));
+    // (tail launches, and lead launches on streams that carry no timed launch, finish before we return)
+    for (int i = 0; i < n_streams; i++) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[i]));
     drain.armed = false;
     *out_host_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    *out_event_ms = last_end - first_start;
+    *out_event_ms = last_end - last_start;
+    if (out_fill_drain_ms) *out_fill_drain_ms = last_end - first_start;
     return BU_OK;
 }
 

@@ -227,15 +227,20 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
     for (size_t r0 = 0; r0 < runs.size();) {
         BuRunTable tb;
         size_t k = 0, n_tiles = 0;
+        // A run of more than one tile per CU fills the chip by itself: it goes out as the plain launch, in the shape tuned for its size
+        // (prefetching persistent workgroups, rectangular tiles, the context's launch policy) -- through the run table two 2^20-block
+        // runs took 9.2-10.2 us each where two plain launches take 8.4-8.5 (round 5, bench.py extra.atlases_2_one_launch before this rule)
+        const size_t big = (size_t)1024 * (size_t)ctx->cu_count;
         for (; r0 + k < runs.size() && k < BU_MULTI_RUNS; k++) {
             const Run& r = runs[r0 + k];
+            if (r.n > big) break;
             const size_t t = (r.n + 1023) / 1024;
             if (n_tiles + t >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
             tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, 0u};
             tb.first_tile[k] = (uint32_t)n_tiles;
             n_tiles += t;
         }
-        if (k <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
+        if (k <= 1) {  // a run on its own (a large one, the last one of a long batch, or one of 2^32 blocks): the plain launch
             bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s);
             if (st) return st;
             r0 += 1;

@@ -63,37 +63,22 @@ struct BuDrain {
     }
 };
 
-// The context's own streams 0..n-1 (n <= 8), created on first use.  The HIP runtime multiplexes a process's streams over a small pool
-// of hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), and launches on two streams that share a hardware queue
-// run one after the other exactly as on one stream (kernel trace, profiles/r05_streams_sharing_a_hardware_queue_serialise.txt: with
-// six streams at one priority in a process whose default stream and context stream already hold two queues, four of them shared two
-// queues and "4 launches in flight" ran as 2).  So the streams are spread over the priority levels in pairs -- 0, 1 normal; 2, 3 high;
-// 4, 5 low; 6, 7 normal -- which puts streams 0..3 (what the multi-stream callers use) on four different queues with the runtime's
-// defaults; measured the same as GPU_MAX_HW_QUEUES=8 with every stream at normal priority (BC7, 4 in flight: 6.04-6.23 against
-// 5.94-6.21 us per atlas).  The priorities only decide whose workgroups the dispatcher places first; nothing here depends on them.
+// The context's own streams 0..n-1 (n <= 8), created on first use: plain non-blocking streams at normal priority.
+// Whether launches on two of them overlap is decided by the HIP runtime, which multiplexes ALL streams of a process over a pool of
+// hardware queues per priority level (GPU_MAX_HW_QUEUES, 4 by default); two streams that share a hardware queue run their kernels one
+// after the other exactly as one stream would (kernel trace: profiles/r05_streams_sharing_a_hardware_queue_serialise.txt -- in a
+// process whose default stream and context stream already hold two of the four queues, four more streams landed on the other two and
+// "4 launches in flight" ran as 2: 7.3 instead of 5.9 us per atlas).  Measured ways out, all equivalent in throughput
+// (profiles/r05_stream_creation_modes_queues_and_drift.txt): GPU_MAX_HW_QUEUES=8 in the environment before the process first touches
+// HIP (what bench.py does and INTEGRATION.md recommends: equal priorities keep the streams in step), streams spread over the priority
+// levels (each level has its own pool; the high-priority streams then run ahead of the others), streams created with a full CU mask
+// (a dedicated queue each, but blocking with respect to the NULL stream).
 bu_status bu_ctx_streams(bu_context* ctx, int n)
 {
     if (n < 0 || n > 8) return BU_ERR_ARGUMENT;
     std::lock_guard<std::mutex> g(ctx->stream_lock);
-    int least = 0, greatest = 0;
-    bool have_range = false;
-    for (int i = 0; i < n; i++) {
-        if (ctx->extra_streams[i]) continue;
-        if (!have_range) {
-            BU_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            have_range = true;
-        }
-        const int level = (i / 2) % 3;  // 0 normal, 1 high, 2 low
-        const int prio = level == 1 ? greatest : (level == 2 ? least : (least + greatest) / 2);
-        const char* tm = getenv("BU_TEST_STREAMS");
-        const int mode = tm ? atoi(tm) : 1;
-        if (mode == 2) {
-            uint32_t mask[16];
-            for (auto& m : mask) m = 0xFFFFFFFFu;
-            BU_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->extra_streams[i], (uint32_t)((ctx->cu_count + 31) / 32), mask));
-        } else
-        BU_HIP(ctx, hipStreamCreateWithPriority(&ctx->extra_streams[i], hipStreamNonBlocking, mode == 1 ? prio : (least + greatest) / 2));
-    }
+    for (int i = 0; i < n; i++)
+        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
     return BU_OK;
 }
 

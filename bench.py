@@ -96,7 +96,7 @@ def pmc_child():
         PtrArr = ctypes.c_void_p * 24
         ev, host = ctypes.c_float(0), ctypes.c_float(0)
         st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, PtrArr(*[t.data_ptr() for t in ins]), PtrArr(*[t.data_ptr() for t in outs]), 24, 0,
-                                                       N_BLOCKS, NBX, 0, 24 * rounds, streams, None, ctypes.byref(ev), ctypes.byref(host), None)
+                                                       N_BLOCKS, NBX, 0, 24 * rounds, 0, streams, None, ctypes.byref(ev), ctypes.byref(host), None, None)
         assert st == 0
     torch.cuda.synchronize()
     ctx.close()
@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--nbuf", type=int, default=64, help="distinct atlas buffers rotated through (cold cache)")
-    ap.add_argument("--prewarm-ms", type=float, default=25.0,
+    ap.add_argument("--prewarm-ms", type=float, default=40.0,
                     help="untimed launches BEFORE the W warm-up steps until this many milliseconds have passed: the GPU needs ~20 ms of "
                          "sustained work to reach its steady clocks (measured: 10.46 us per launch after --warmup 5, 9.8-9.9 after --warmup 2000 "
                          "or more); with it --warmup 5 --steps 20 and --warmup 64 --steps 512 agree.  0 disables")
@@ -290,6 +290,11 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    # Launches on different streams overlap only when the streams sit on different HARDWARE queues, and the HIP runtime hands a process
+    # GPU_MAX_HW_QUEUES (default 4) of them per priority level, two of which torch's NULL stream and the context's internal stream already
+    # hold: with the default, 4 launches "in flight" run as 2 (profiles/r05_hip_hw_queue_knobs_vs_streams.txt).  The runtime reads the
+    # variable when it initialises, so it is set here, before torch is imported and before any child is started; a value the caller set wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.pmc_child:
         pmc_child()
         return
@@ -732,14 +737,21 @@ def run_atlas4096(env):
         rot[0] += lead + launches
         return ev.value / 1e3 / launches
 
-    def run_window(lead, launches, in_flight=None):
-        """the timed region: `lead` untimed launches, event 0, `launches` timed ones, step i on context stream i % in_flight, end event per stream"""
-        ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
-        st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, lead, launches,
-                                                       in_flight or args.in_flight, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+    fill_drain = [0.0]  # out_fill_drain_ms of the last run_window call
+
+    def run_window(lead, launches, in_flight=None, tail=None):
+        """the timed region: step i on context stream i % in_flight; `lead` untimed launches, start event per stream, `launches` timed ones, end event
+        per stream, `tail` untimed launches (default: one per stream when the pipeline was filled by lead launches)"""
+        nfl = in_flight or args.in_flight
+        if tail is None:
+            tail = nfl if (nfl > 1 and lead >= nfl) else 0
+        ev, host, fd, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+        st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, lead, launches, tail,
+                                                       nfl, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(fd), ctypes.byref(late))
         if st != 0:
             raise RuntimeError("bu_time_uastc_launches_streams_window: " + lib.bu_status_string(st).decode())
-        rot[0] += lead + launches
+        rot[0] += lead + launches + tail
+        fill_drain[0] = fd.value
         return ev.value, host.value, late.value
 
     def srow(launches, in_flight, shared, target=_lib.BC7, inp=in_ptrs, outp=out_ptrs, nb=nbuf, lead=64):
@@ -747,11 +759,12 @@ def run_atlas4096(env):
         ctx.set_launch_policy(shared)
         try:
             ev, host = ctypes.c_float(0), ctypes.c_float(0)
-            st = lib.bu_time_uastc_launches_streams_window(ctx.handle, target, inp, outp, nb, rot[0] % nb, N_BLOCKS, NBX, lead, launches, in_flight,
-                                                           ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None)
+            tail = in_flight if in_flight > 1 else 0
+            st = lib.bu_time_uastc_launches_streams_window(ctx.handle, target, inp, outp, nb, rot[0] % nb, N_BLOCKS, NBX, lead, launches, tail, in_flight,
+                                                           ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None)
             if st != 0:
                 raise RuntimeError("bu_time_uastc_launches_streams_window: " + lib.bu_status_string(st).decode())
-            rot[0] += lead + launches
+            rot[0] += lead + launches + tail
             return max(ev.value, host.value) / 1e3 / launches
         finally:
             ctx.set_launch_policy(policy_now[0])
@@ -818,6 +831,10 @@ def run_atlas4096(env):
     period_s = ev_max / args.steps  # launch-to-launch period of the timed region (slowest rank), HIP events
     achieved = BYTES_PER_BLOCK * N_BLOCKS / period_s / 1e9
 
+    # the strict bracket: the same K steps with NOTHING behind them, from the first instruction of the first timed launch to the last instruction
+    # of the last one (the pipeline's fill is credited to nobody and its drain -- the last launches running with fewer and fewer partners -- is inside)
+    run_window(lead, args.steps, tail=0)
+    strict_s = fill_drain[0] / 1e3 / args.steps
     # ---- the round 1-4 headline, kept as a row: ONE launch at a time (exclusive policy, one stream), same window method ----
     policy_now[0] = False
     ctx.set_launch_policy(False)
@@ -866,29 +883,36 @@ def run_atlas4096(env):
                     mat[pol][str(nfl)] = round(srow(256, nfl, pol == "shared") * 1e6, 3)
             torch.cuda.synchronize()
             extra["launches_in_flight_matrix"] = {"us_per_atlas": mat, "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
-                                                  "note": "UASTC->BC7, 2^20 blocks per launch, step i on context stream i % n; rows = launch policy, columns = launches in flight; "
+                                                  "note": "UASTC->BC7, 2^20 blocks per launch, step i on context stream i %% n; rows = launch policy, columns = launches in flight; "
                                                           "every one of the %d rotated outputs compared with the known answers afterwards" % nbuf}
-            # cross-check of the overlap claim through the product's other route to it: TWO atlases in ONE launch (bu_uastc_transcode_batch_device
-            # merges nothing here -- separate allocations -- so the run-table kernel walks both), one launch at a time on one stream
+            # cross-check of the overlap claim through the product's other route to it: TWO atlases in ONE launch -- two slices that are contiguous in
+            # memory handed to bu_uastc_transcode_batch_device, which merges them into one plain launch of 2^21 blocks (exclusive policy, one stream,
+            # one launch at a time): inside that launch the second atlas' loads overlap the first one's compute
+            n_pairs = 12
+            pin = [torch.cat([ins[2 * k], ins[2 * k + 1]]).contiguous() for k in range(n_pairs)]
+            pout = [torch.empty((2 * N_BLOCKS, 16), dtype=torch.uint8, device=dev) for _ in range(n_pairs)]
             VP2, SZ2 = ctypes.c_void_p * 2, ctypes.c_size_t * 2
+            pargs = [(VP2(pin[k].data_ptr(), pin[k].data_ptr() + N_BLOCKS * 16), SZ2(N_BLOCKS, N_BLOCKS), VP2(pout[k].data_ptr(), pout[k].data_ptr() + N_BLOCKS * 16))
+                     for k in range(n_pairs)]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
             def two(k):
-                a, b = (2 * k) % nbuf, (2 * k + 1) % nbuf
-                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, 2, VP2(in_ptrs[a], in_ptrs[b]), SZ2(N_BLOCKS, N_BLOCKS), VP2(out_ptrs[a], out_ptrs[b]),
-                                                           NBX, None, None, sp) == 0
+                a_, n_, o_ = pargs[k % n_pairs]
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, 2, a_, n_, o_, NBX, None, None, sp) == 0
 
-            for k in range(64):
+            for k in range(48):
                 two(k)
             e0.record(stream)
-            for k in range(128):
+            for k in range(96):
                 two(k)
             e1.record(stream)
             torch.cuda.synchronize()
-            two_s = e0.elapsed_time(e1) / 1e3 / 256
+            two_s = e0.elapsed_time(e1) / 1e3 / 192
             extra["atlases_2_one_launch"] = {"us_per_atlas": round(two_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / two_s / 1e6, 1),
-                                             "verified": bool(torch.equal(outs[0], g_bc7[idxs[0]])) and bool(torch.equal(outs[1], g_bc7[idxs[1]])),
-                                             "note": "two atlases per call of bu_uastc_transcode_batch_device (one kernel launch over both), calls back to back on one stream"}
+                                             "verified": bool(torch.equal(pout[1][:N_BLOCKS], g_bc7[idxs[2]])) and bool(torch.equal(pout[1][N_BLOCKS:], g_bc7[idxs[3]])),
+                                             "note": "two contiguous atlases per call of bu_uastc_transcode_batch_device = one 2^21-block launch, calls back to back on one "
+                                                     "stream, exclusive policy, cold rotation over %d pairs" % n_pairs}
+            del pin, pout
         except Exception as e:  # secondary rows must never break the headline line
             extra["launches_in_flight_matrix_error"] = repr(e)
         # a loop over 64 independent slices of 65 536 blocks (256 x 256 blocks: a 1024 x 1024 px mip), the shape of the per-slice
@@ -1245,22 +1269,32 @@ def run_atlas4096(env):
                                    nbuf, ("%d launches in flight on %d streams (step i on context stream i %% %d), %s launch policy" % (
                                        args.in_flight, args.in_flight, args.in_flight, args.policy)) if args.in_flight > 1 else "one launch at a time on one stream, %s launch policy" % args.policy),
                    "launches_in_flight": args.in_flight, "launch_policy": args.policy,
+                   "hip_runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                    "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1),
                    "prewarm": {"launches": prewarm_launches, "ms": args.prewarm_ms,
                                "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"},
                    "timed_region": {"lead_launches": lead, "host_ms": round(host_ms, 6), "event_ms": round(ev_ms, 6), "host_started_late": bool(late),
-                                    "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, "
-                                            "event 0 in front of the first timed launch on its stream, K timed launches, one end event per stream; the window "
-                                            "closes when the LAST end event completes (the pipeline's drain is inside it); host clock from event 0 seen complete "
-                                            "to every end event seen complete; value uses max(host, event)"}},
+                                    "tail_launches": args.in_flight if args.in_flight > 1 else 0,
+                                    "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, a start "
+                                            "event per stream behind its last lead launch, K timed launches, an end event per stream behind its last timed launch, one untimed "
+                                            "tail launch per stream.  Launches in flight are a pipeline, so the K steps are counted as completions: window = from the LAST "
+                                            "start event (every lead launch has completed) to the LAST end event (every timed launch has completed) on the device clock; "
+                                            "host clock from every start event seen complete to every end event seen complete; value uses max(host, event).  The pipeline "
+                                            "is full at both instants (what the first timed launches got done beside the last lead launches, the tail launches get done "
+                                            "beside the last timed ones).  --steps 512 gives the same figure with the ends weighing 25 times less"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                      "kernel": "bu_uastc_sorted_kernel<BC7> (%s-policy shape)" % args.policy,
                      "launches_in_flight": args.in_flight, "period_ns": round(period_s * 1e9, 1), "us_per_launch": round(period_s * 1e6, 3),
+                     "strict_bracket_ns_per_step": round(strict_s * 1e9, 1),
+                     "frac_by_strict_bracket": round(BYTES_PER_BLOCK * N_BLOCKS / strict_s / 1e9 / HBM_PEAK_GBS, 4),
                      "bytes_per_launch": BYTES_PER_BLOCK * N_BLOCKS,
-                     "note": "achieved = algorithmic bytes per launch / launch-to-launch PERIOD of the K timed launches (HIP events on the launch streams); with "
-                             "several launches in flight one launch's own span is longer than the period -- kernel_span_ns below, from this run's rocprofv3 "
-                             "kernel trace -- and the chip works on about span / period launches at a time"},
+                     "note": "achieved = algorithmic bytes per launch / launch-to-launch PERIOD of the K timed launches = (HIP event behind the last timed launch - HIP "
+                             "event behind the last lead launch, latest over the streams) / K: K launches complete in that window and the pipeline is full at both ends.  "
+                             "With several launches in flight one launch's own span is longer than the period (kernel_span_ns below, from this run's rocprofv3 kernel "
+                             "trace) and the chip works on about span / period launches at a time.  strict_bracket_ns_per_step: a separate pass of K steps with nothing "
+                             "launched behind them, first instruction of the first timed launch to last instruction of the last one, / K -- a window that holds "
+                             "K + in_flight - 1 periods of a full pipeline and its drain (at --steps 512 the two figures meet)"},
     }
     tr = pmc_traffic()
     if tr:

@@ -93,13 +93,12 @@ size_t bu_target_block_bytes(bu_target target);
 typedef enum bu_launch_policy { BU_LAUNCH_EXCLUSIVE = 0, BU_LAUNCH_SHARED = 1 } bu_launch_policy;
 bu_status bu_context_set_launch_policy(bu_context* ctx, bu_launch_policy policy);
 bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* out_policy);
-/* The context's own streams, index 0..7 (hipStream_t, created on first use, destroyed with the context): what a caller that wants
- * several launches in flight can issue them on.  Launches only overlap when their streams sit on DIFFERENT hardware queues, and the
- * HIP runtime multiplexes all streams of a process over GPU_MAX_HW_QUEUES (default 4) queues per priority level -- two streams that
- * share one run their kernels strictly one after the other.  These streams are spread over the priority levels in pairs (0, 1 normal;
- * 2, 3 high; 4, 5 low; 6, 7 normal) so that streams 0..3 land on four different queues under the runtime's defaults.  A caller that
- * brings its own streams should create them the same way or run with GPU_MAX_HW_QUEUES >= streams + 2 in the environment.  The
- * streams are non-blocking: they do not synchronise with the NULL stream. */
+/* The context's own streams, index 0..7 (hipStream_t, non-blocking, normal priority, created on first use, destroyed with the
+ * context): what a caller that wants several launches in flight can issue them on.  Launches only overlap when their streams sit on
+ * DIFFERENT hardware queues, and the HIP runtime multiplexes all streams of a process over GPU_MAX_HW_QUEUES (default 4) queues per
+ * priority level -- two streams that share one run their kernels strictly one after the other.  A process that wants four launches in
+ * flight should start with GPU_MAX_HW_QUEUES=8 in its environment (set before the first HIP call; bench.py does): with the default a
+ * process's NULL stream and the context's internal stream already hold two of the four queues. */
 bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream);
 
 /* ---- UASTC slice level, host pointers ------------------------------------------------------- */
@@ -367,17 +366,22 @@ bu_status bu_time_uastc_launches_each(bu_context* ctx, bu_target target, const v
 bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                          size_t n_buffers, size_t n_blocks, size_t blocks_per_row, int launches, int n_streams,
                                          float* out_ms);
-/* bu_time_uastc_launches_window with SEVERAL launches in flight: launch i (lead and timed) goes to context-owned stream
- * i % n_streams (1..8), everything enqueued up front.  Event 0 sits on the stream of the first timed launch, directly in front of
- * it -- the other streams' last lead launches are still running when it fires, the window opens on a full pipeline --; every stream
- * gets an end event behind its last timed launch and the window closes when the LAST of them has completed, so the drain of the
- * pipeline is inside it.  *out_event_ms = max over streams of hipEventElapsedTime(event 0, that stream's end event); *out_host_ms =
- * host steady clock from "event 0 seen complete" to "every end event seen complete"; *out_late as above.  The per-atlas figure
- * (window / launches) is a launch-to-launch PERIOD; one launch's own span is longer (about n_streams periods). */
+/* bu_time_uastc_launches_window with SEVERAL launches in flight: launch i (lead, timed, tail) goes to context-owned stream
+ * i % n_streams (1..8), everything enqueued up front.  n launches in flight are a pipeline (launch j starts one period after launch
+ * j - 1 and is under way for about n periods), so throughput is counted in completions: every stream gets a start event behind its
+ * last lead launch (in front of its first timed one) and an end event behind its last timed launch; *out_event_ms = latest end event -
+ * LATEST start event on the device clock, i.e. from "the last lead launch has completed" to "the last timed launch has completed" --
+ * exactly `launches` launches complete in between.  With lead >= n_streams and tail >= n_streams (untimed launches behind the end
+ * events) the pipeline is full at both instants and *out_event_ms / launches is the steady-state launch-to-launch period (without tail
+ * launches the head start of the first timed launches is credited and nothing debited: too short -- use the strict bracket).
+ * *out_fill_drain_ms (optional) = latest end event - EARLIEST start event, the strict bracket: first instruction of the first timed
+ * launch to last instruction of the last one (launches + n_streams - 1 periods in a full pipeline; with lead = tail = 0 the whole run
+ * from an idle chip to an idle chip).  *out_host_ms = host steady clock from "every start event seen complete" to "every end event seen complete"; *out_late
+ * (optional) = 1 if the first start event had already completed when the host finished enqueueing. */
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,
-                                                int lead, int launches, int n_streams, uint64_t* d_status, float* out_event_ms,
-                                                float* out_host_ms, int* out_late);
+                                                int lead, int launches, int tail, int n_streams, uint64_t* d_status,
+                                                float* out_event_ms, float* out_host_ms, float* out_fill_drain_ms, int* out_late);
 /* The reference's micro-benchmark shape (benches/benchmark.rs:66-98): `reps` passes over `n_blocks` blocks, one per-block API
  * call per block (RGBA32: bu_unpack_uastc_block_to_rgba), host steady clock around the loop; nanoseconds per call. */
 bu_status bu_time_block_api(bu_context* ctx, bu_target target, const uint8_t* blocks, size_t n_blocks, int reps, uint8_t* out,

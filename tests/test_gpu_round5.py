@@ -108,8 +108,8 @@ def test_policy_round_trip_and_argument_check():
 
 
 @pytest.mark.parametrize("shared", [False, True])
-@pytest.mark.parametrize("streams", [1, 3, 4])
-def test_streams_window_runs_every_launch_on_every_stream(golden, shared, streams):
+@pytest.mark.parametrize("streams,tail", [(1, 0), (3, 0), (3, 3), (4, 4)])
+def test_streams_window_runs_every_launch_on_every_stream(golden, shared, streams, tail):
     """bu_time_uastc_launches_streams_window: lead + timed launches round-robin over the context's streams; afterwards EVERY rotated
     output holds the known answers (a launch skipped, or two launches racing on one buffer, would show), the two clocks agree, and the
     per-launch period is in the range a 2^20-block BC7 launch can have"""
@@ -129,10 +129,10 @@ def test_streams_window_runs_every_launch_on_every_stream(golden, shared, stream
     ctx.status_word_reset(status)
     torch.cuda.synchronize()
     A = vp * nbuf
-    ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
-    lead, launches = 5, 19  # (neither a multiple of the stream counts: every stream carries lead and timed launches, unevenly)
+    ev, host, fd, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+    lead, launches = 5, 19 - tail  # (neither a multiple of the stream counts: every stream carries lead and timed launches, unevenly)
     st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 3, n, 1024,
-                                                   lead, launches, streams, vp(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+                                                   lead, launches, tail, streams, vp(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(fd), ctypes.byref(late))
     assert st == 0, lib.bu_status_string(st)
     torch.cuda.synchronize()
     want = torch.from_numpy(golden["bc7"]).cuda()
@@ -142,7 +142,8 @@ def test_streams_window_runs_every_launch_on_every_stream(golden, shared, stream
     us = ev.value * 1e3 / launches
     assert 3.0 < us < 40.0, us
     assert abs(host.value - ev.value) < 0.5 * ev.value + 0.05, (host.value, ev.value)
+    assert fd.value >= ev.value - 1e-4  # the earliest start event is not later than the latest one
     # argument checks
     assert lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 0, n, 1024,
-                                                     0, 4, 9, None, ctypes.byref(ev), ctypes.byref(host), None) == _lib.ERR_ARGUMENT
+                                                     0, 4, 0, 9, None, ctypes.byref(ev), ctypes.byref(host), None, None) == _lib.ERR_ARGUMENT
     ctx.close()

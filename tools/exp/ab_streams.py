@@ -18,6 +18,7 @@ ap.add_argument("--n", type=int, default=1 << 20)
 ap.add_argument("--bpr", type=int, default=1024)
 ap.add_argument("--launches", type=int, default=240)
 ap.add_argument("--lead", type=int, default=64)
+ap.add_argument("--tail", type=int, default=-1)  # untimed launches behind the end events; -1 = one per stream
 ap.add_argument("--policy", default="")  # comma list of launch policies to set per cell (libraries that export bu_context_set_launch_policy)
 a = ap.parse_args()
 vp = ctypes.c_void_p
@@ -43,8 +44,8 @@ for path in a.libs:
     L = ctypes.CDLL(os.path.abspath(path))
     L.bu_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.bu_time_uastc_launches_streams_window.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
-                                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float),
-                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+                                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float),
+                                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     h = vp(); assert L.bu_context_create(0, ctypes.byref(h)) == 0, path
     pols = [None]
     if a.policy and hasattr(L, "bu_context_set_launch_policy"):
@@ -55,7 +56,7 @@ for path in a.libs:
 def run(L, h, pol, ns, first, lead, launches):
     if pol is not None: assert L.bu_context_set_launch_policy(h, pol) == 0
     ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
-    st = L.bu_time_uastc_launches_streams_window(h, t, ip, op, NBUF, first, N, a.bpr, lead, launches, ns, None, ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late))
+    st = L.bu_time_uastc_launches_streams_window(h, t, ip, op, NBUF, first, N, a.bpr, lead, launches, (ns if a.tail < 0 else a.tail) if lead else 0, ns, None, ctypes.byref(ev), ctypes.byref(host), None, ctypes.byref(late))
     assert st == 0, st
     return max(ev.value, host.value) / launches * 1e3, ev.value / launches * 1e3, late.value
 def check():
