@@ -18,6 +18,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #include <mutex>
 #include <string>
 #include <thread>
@@ -60,9 +63,19 @@ class Pool {
     }
 
 public:
+    // helper threads worth starting: the CPUs this process may actually run on (its affinity mask -- a container pinned to a few
+    // cores reports the machine's count through hardware_concurrency(), and helpers that only spin on each other's progress then compete
+    // with the one thread that makes it), at most 32
     static unsigned capacity()
     {
         unsigned hw = std::thread::hardware_concurrency();
+#if defined(__linux__)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            const int n = CPU_COUNT(&set);
+            if (n > 0 && (hw == 0 || (unsigned)n < hw)) hw = (unsigned)n;
+        }
+#endif
         if (hw == 0) hw = 1;
         return hw < 32u ? hw : 32u;
     }
@@ -80,8 +93,9 @@ public:
     }
     // the two halves of run() for a caller that has something else to do meanwhile (bu_read_to feeds the GPU while pool threads
     // decode): begin() starts up to `helpers` copies of f on pool threads and returns how many it started (0: no thread could
-    // be had -- the caller must run f itself); end() waits for them.  The pool is reserved from begin() to end(); f must stay
-    // alive until end() returns.
+    // be had -- the caller must run f itself); end() waits for them.  The pool is reserved from begin() to end() -- ONE job at a time
+    // per process: a begin() on another thread WAITS here until the current job's end() (concurrent whole-file calls on different
+    // contexts therefore take turns on the host side of their work).  f must stay alive until end() returns.
     unsigned begin(unsigned helpers, const std::function<void()>& f)
     {
         run_m.lock();

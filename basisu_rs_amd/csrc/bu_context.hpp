@@ -66,10 +66,10 @@ struct BuDrain {
 // The context's own streams 0..n-1 (n <= 8), created on first use: plain non-blocking streams at normal priority.
 // Whether launches on two of them overlap is decided by the HIP runtime, which multiplexes ALL streams of a process over a pool of
 // hardware queues per priority level (GPU_MAX_HW_QUEUES, 4 by default); two streams that share a hardware queue run their kernels one
-// after the other exactly as one stream would (kernel trace: profiles/r05_streams_sharing_a_hardware_queue_serialise.txt -- in a
+// after the other exactly as one stream would (kernel trace: profiles/r05_stream_creation_modes_queues_and_drift.txt -- in a
 // process whose default stream and context stream already hold two of the four queues, four more streams landed on the other two and
 // "4 launches in flight" ran as 2: 7.3 instead of 5.9 us per atlas).  Measured ways out, all equivalent in throughput
-// (profiles/r05_stream_creation_modes_queues_and_drift.txt): GPU_MAX_HW_QUEUES=8 in the environment before the process first touches
+// (same file, profiles/r05_hip_hw_queue_knobs_vs_streams.txt): GPU_MAX_HW_QUEUES=8 in the environment before the process first touches
 // HIP (what bench.py does and INTEGRATION.md recommends: equal priorities keep the streams in step), streams spread over the priority
 // levels (each level has its own pool; the high-priority streams then run ahead of the others), streams created with a full CU mask
 // (a dedicated queue each, but blocking with respect to the NULL stream).

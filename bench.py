@@ -16,13 +16,21 @@
 A step = one launch of the UASTC->BC7 kernel over one 4096x4096 synthetic atlas already resident in
 HBM.  Atlases rotate through NBUF distinct input/output buffer pairs (>= 1 GiB each way) so neither L2
 nor the 256 MiB Infinity Cache can serve a launch (cold-cache protocol).
+Step i is issued on context stream i % IN_FLIGHT (--in-flight, default 4) under the shared launch policy
+(bu_context_set_launch_policy): launches queued on one stream never overlap, and one launch over an atlas
+waits ~3.4 us for HBM with the ALUs idle and then computes with HBM idle; independent atlases on several
+streams use both at once.  `value` = K x 2^20 blocks / the time in which the K timed launches COMPLETE in a
+full pipeline (lead launches in front, one tail launch per stream behind); beside it the
+line carries the strict bracket around the same K steps and the one-launch-at-a-time figure of rounds 1-4.
+GPU_MAX_HW_QUEUES=8 is set before HIP initialises (a stream needs a hardware queue of its own to overlap).
 Every rank owns its own atlases (weak scaling: in the texture-array reading of the config each rank
 holds 16 slices of 1024x1024 px); the transcode needs no data-path collective.  The all-gather that
 reassembles the array is timed separately and reported under "allgather" -- never folded into `value`.
 
 Prints ONE JSON line (rank 0): metric/value per the driver contract plus
-  roofline      algorithmic bytes (32 B/block x blocks per launch) / average kernel duration measured
-                with hipEvents on the launch stream over the timed region, against the 8 TB/s HBM peak
+  roofline      algorithmic bytes (32 B/block x blocks per launch) / launch-to-launch period measured with
+                hipEvents on the launch streams over the timed region, against the 8 TB/s HBM peak; one launch's
+                own span and the HBM traffic from this run's child rocprofv3 passes
   cpu_baseline  the oracle (C restatement of the reference CPU path, kind "port") timed on this box's
                 host cores on a bounded sample of the same atlas
 """
@@ -126,7 +134,7 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
     then WRITE_SIZE: separate passes, nothing but --kernel-trace beside --pmc, the program directly after `--`) over
     `bench.py --pmc-child`, run before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB; gfx950 reports half of
     a wide coalesced read stream (MI355X_MICROARCH.md, HBM section): bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.
-    A third child pass (--kernel-trace only, no counters, 16 rounds over the 24 atlases) gives what rocprofv3 says about the same
+    A third child pass (--kernel-trace only, no counters, 64 rounds over the 24 atlases, `in_flight` launches in flight) gives what rocprofv3 says about the same
     launches unperturbed by counters: the per-kernel average duration, the launch-to-launch period of the back-to-back launches and
     how many launches started before their predecessor had ended.
     Returns (bytes, note, trace) or (None, reason, trace); trace is a dict or None."""

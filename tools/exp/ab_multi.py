@@ -1,6 +1,6 @@
 """A/B of whole-library kernel variants inside ONE process (atlases built once, variants interleaved round by round):
     python tools/exp/ab_multi.py [--targets bc7,copy] [--rounds 3] [--n 1048576] lib_a.so lib_b.so ...
-Each library is a full libbasisu_hip.so (tools/exp/build_variant.sh / build_x.sh) loaded under its own path with its own context.
+Each library is a full libbasisu_hip.so (tools/exp/build_variant.sh) loaded under its own path with its own context.
 One line per library and round: us per launch (mean of 256 cold-rotated launches between two events); buffer 0 of every target is
 checked against the reference's known answers."""
 import argparse, ctypes, os, sys

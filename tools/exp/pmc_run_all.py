@@ -1,5 +1,6 @@
-"""a few launches of EVERY shipped kernel (five UASTC targets, both ETC1S kernels, the copy ceiling) on cold-rotated
-inputs, for the rocprofv3 --kernel-trace / --pmc passes of tools/gpu_pmc.sh"""
+"""a few launches of EVERY shipped kernel (five UASTC targets under BOTH launch policies -- the exclusive and the shared shapes are different
+instantiations --, both ETC1S kernels, the copy ceiling, and `array512`: BASELINE config 5's 2^25-block BC7 launch) on cold-rotated inputs, for
+the rocprofv3 --kernel-trace / --pmc passes of tools/gpu_pmc.sh.  One launch at a time on one stream (counter passes serialise dispatches anyway)."""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,20 +19,36 @@ for k in range(NBUF):
 outs = [torch.empty((N, 16), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
 sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
-for name, t in (("bc7", _lib.BC7), ("astc", _lib.ASTC), ("etc1", _lib.ETC1), ("etc2", _lib.ETC2)):
-    if only and name not in only: continue
-    # back-to-back launches from the C timing helper (a Python call per launch leaves the GPU idle between kernels and the
-    # traced durations come out ~15 % long)
-    A = ctypes.c_void_p * NBUF
-    ms = ctypes.c_float(0)
-    assert lib.bu_time_uastc_launches(ctx.handle, t, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), NBUF, 0, N, 1024, NBUF * REPS, None, sp, ctypes.byref(ms)) == 0
-    torch.cuda.synchronize()
+for shared in (False, True):
+    ctx.set_launch_policy(shared)
+    if only == ["array512"]: break
+    for name, t in (("bc7", _lib.BC7), ("astc", _lib.ASTC), ("etc1", _lib.ETC1), ("etc2", _lib.ETC2)):
+        if only and name not in only: continue
+        # back-to-back launches from the C timing helper (a Python call per launch leaves the GPU idle between kernels and the
+        # traced durations come out ~15 % long)
+        A = ctypes.c_void_p * NBUF
+        ms = ctypes.c_float(0)
+        assert lib.bu_time_uastc_launches(ctx.handle, t, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), NBUF, 0, N, 1024, NBUF * REPS, None, sp, ctypes.byref(ms)) == 0
+        torch.cuda.synchronize()
+ctx.set_launch_policy(False)
 if not only or "rgba" in only:
     ro = [torch.empty((N, 64), dtype=torch.uint8, device=dev) for _ in range(8)]
     A8 = ctypes.c_void_p * 8
     ms = ctypes.c_float(0)
     assert lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, A8(*[x.data_ptr() for x in ins[:8]]), A8(*[x.data_ptr() for x in ro]), 8, 0, N, 1024, NBUF * REPS, None, sp, ctypes.byref(ms)) == 0
     torch.cuda.synchronize(); del ro
+if "array512" in only:  # (its own rocprofv3 passes: the persistent grid is the 2^20-block launch's, the summaries could not tell them apart)
+    # BASELINE config 5's kernel: the 512-slice array (2^25 blocks, 512 MiB in + 512 MiB out) in ONE launch, two pairs rotated
+    nbig = 1 << 25
+    bi, bo = [], []
+    for k in range(2):
+        gen = torch.Generator(device=dev); gen.manual_seed(9000 + k)
+        bi.append(gu[torch.randint(0, 608, (nbig,), device=dev, generator=gen)].contiguous())
+        bo.append(torch.empty((nbig, 16), dtype=torch.uint8, device=dev))
+    A2 = ctypes.c_void_p * 2
+    ms = ctypes.c_float(0)
+    assert lib.bu_time_uastc_launches(ctx.handle, _lib.BC7, A2(*[x.data_ptr() for x in bi]), A2(*[x.data_ptr() for x in bo]), 2, 0, nbig, 256, 4 * REPS if REPS > 1 else 4, None, sp, ctypes.byref(ms)) == 0
+    torch.cuda.synchronize(); del bi, bo
 if not only or "copy" in only:
     A = ctypes.c_void_p * NBUF
     ms = ctypes.c_float(0)

@@ -1,6 +1,7 @@
 # round-end evidence, part B: the rocprofv3 kernel trace of the headline bench, kernel trace + counter passes over every kernel, size sweeps
 set -u
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8   # (bench.py sets it itself, but under rocprofv3 the HIP runtime is initialised before python starts)
 TAG=${TAG:-v}
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -11,7 +12,7 @@ rm -rf $O/prof
 head -5 $O/rocprofv3_kernel_stats.csv | cut -c1-200
 timeout 1500 bash tools/gpu_pmc.sh > $O/gpu_pmc.log 2>&1
 cp gpurun_out/pmc/kernel_stats.csv $O/rocprofv3_kernel_stats_all_kernels.csv
-cp gpurun_out/pmc/pmc_all.json gpurun_out/pmc/pmc_bc7.json gpurun_out/pmc/pmc_summary.txt $O/
+cp gpurun_out/pmc/pmc_all.json gpurun_out/pmc/pmc_bc7.json gpurun_out/pmc/pmc_bc7_array512.json gpurun_out/pmc/pmc_summary.txt gpurun_out/pmc/pmc_summary_array512.txt gpurun_out/pmc/kernel_stats_array512.csv $O/
 rm -rf gpurun_out/pmc/trace gpurun_out/pmc/lds gpurun_out/pmc/sq gpurun_out/pmc/sq2 gpurun_out/pmc/fetch gpurun_out/pmc/write gpurun_out/pmc/grbm
 LG_LO=10 LG_HI=23 timeout 600 python tools/exp/size_sweep_all.py > $O/size_sweep_all_targets.txt 2>&1
 tail -3 $O/size_sweep_all_targets.txt
