@@ -227,20 +227,15 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
     for (size_t r0 = 0; r0 < runs.size();) {
         BuRunTable tb;
         size_t k = 0, n_tiles = 0;
-        // A run of more than one tile per CU fills the chip by itself: it goes out as the plain launch, in the shape tuned for its size
-        // (prefetching persistent workgroups, rectangular tiles, the context's launch policy) -- through the run table two 2^20-block
-        // runs took 9.2-10.2 us each where two plain launches take 8.4-8.5 (round 5, bench.py extra.atlases_2_one_launch before this rule)
-        const size_t big = (size_t)1024 * (size_t)ctx->cu_count;
         for (; r0 + k < runs.size() && k < BU_MULTI_RUNS; k++) {
             const Run& r = runs[r0 + k];
-            if (r.n > big) break;
             const size_t t = (r.n + 1023) / 1024;
             if (n_tiles + t >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
             tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, 0u};
             tb.first_tile[k] = (uint32_t)n_tiles;
             n_tiles += t;
         }
-        if (k <= 1) {  // a run on its own (a large one, the last one of a long batch, or one of 2^32 blocks): the plain launch
+        if (k <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
             bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s);
             if (st) return st;
             r0 += 1;
@@ -248,15 +243,22 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
         }
         for (size_t i = k; i < BU_MULTI_RUNS + 32; i++) tb.first_tile[i] = 0xFFFFFFFFu;
         for (size_t i = k; i < BU_MULTI_RUNS; i++) tb.run[i] = BuRunDesc{nullptr, nullptr, 0, 0u, 0u};
+        // Shapes, as the plain launcher picks them by size (bu_context.hpp): at most one tile per CU 1024 threads on it; beyond that 512 x 2.
+        // BC7 / ASTC / RGBA32 batches of more tiles than fit the chip at once run as a PERSISTENT grid (four / four / two workgroups per CU)
+        // whose workgroups walk the tiles of all runs with the next tile's loads in flight -- a batch of large slices in separate
+        // allocations is then one long launch that overlaps its own loads and compute (two 2^20-block slices 7.9 us each, eight 6.4, against
+        // 8.4 for plain launches one after another and 9.2-10.2 through the round-4 table kernel without the prefetch); ETC1 / ETC2 keep
+        // the one-tile-at-a-time shape (their large shape sorts 4096-block tiles, the table numbers 1024-block ones).
         const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
-        const size_t cap = (size_t)ctx->cu_count * 7;  // beyond seven workgroups per CU they walk the tiles (as bu_launch_uastc)
-        const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
         auto go = [&](auto tgt) {
             constexpr int T = decltype(tgt)::value;
+            constexpr bool PERSIST = T == BU_TGT_BC7 || T == BU_TGT_ASTC || T == BU_TGT_RGBA;
+            const size_t cap = (size_t)ctx->cu_count * (PERSIST ? (T == BU_TGT_RGBA ? 2 : 4) : 7);  // (beyond seven workgroups per CU they walk the tiles, as bu_launch_uastc)
+            const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
             if (one_per_cu)
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
             else
-                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
+                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
         };
         switch (target) {
         case BU_TARGET_ASTC: go(std::integral_constant<int, BU_TGT_ASTC>()); break;

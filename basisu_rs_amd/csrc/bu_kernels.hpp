@@ -231,7 +231,6 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
     // which is what lets two workgroups share a CU.
     constexpr bool RECT = LAYOUT == BU_LAYOUT_RECT, MULTI = LAYOUT == BU_LAYOUT_MULTI;
-    static_assert(!MULTI || !PREFETCH, "the multi-slice layout is compiled for the plain one-tile-at-a-time shapes");
     constexpr bool BU_ALIAS = TARGET == BU_TGT_RGBA;
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
     static_assert(!BU_ALIAS || bu_lds_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
@@ -278,8 +277,10 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     auto has_block = [&](uint32_t k) { return RECT || k < 20u; };
     unsigned tile = blockIdx.x;
     // MULTI: the current tile's descriptor (wave-uniform: scalar loads); every other layout addresses the one slice of the launch
-    BuTileDesc td = {in, out, 0u, 0u, base};
-    auto load_desc = [&](unsigned t) {
+    // `td` = the descriptor of the tile being sorted / transcoded / written back; `tl` = the descriptor of the tile whose blocks are being
+    // LOADED (the same tile, or with PREFETCH the next one: its loads are in flight while `td`'s tile is transcoded)
+    BuTileDesc td = {in, out, 0u, 0u, base}, tl = td;
+    auto desc_of = [&](unsigned t, BuTileDesc& d) {
         if constexpr (MULTI) {
             if (t < n_tiles) {
                 // runs 0..r start at or before tile t: r = (number of first-tile entries <= t) - 1; the unused entries are ~0
@@ -292,15 +293,16 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                 r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
                 const BuRunDesc rd = runs->run[r];
                 const uint32_t first = (t - runs->first_tile[r]) * (uint32_t)BU_TILE, left = rd.n - first;
-                td = BuTileDesc{rd.in, rd.out, first, left < (uint32_t)BU_TILE ? left : (uint32_t)BU_TILE, rd.base};
+                d = BuTileDesc{rd.in, rd.out, first, left < (uint32_t)BU_TILE ? left : (uint32_t)BU_TILE, rd.base};
             }
         }
     };
-    load_desc(tile);
-    // block l of tile t: where it is loaded from, whether it exists
-    auto blk_src = [&](unsigned t, unsigned l) { return MULTI ? td.in + (td.first + l) : in + gidx(t, l); };
+    desc_of(tile, td);
+    tl = td;
+    // block l of tile t (whose descriptor is `tl`): where it is loaded from, whether it exists
+    auto blk_src = [&](unsigned t, unsigned l) { return MULTI ? tl.in + (tl.first + l) : in + gidx(t, l); };
     auto blk_valid = [&](unsigned t, unsigned l) {
-        if constexpr (MULTI) return t < n_tiles && l < td.n;
+        if constexpr (MULTI) return t < n_tiles && l < tl.n;
         else return RECT ? t < n_tiles : (t < n_tiles && gidx(t, l) < n_blocks && in_tile(l));
     };
     // Table staging.  The staged 16-byte pieces of the LDS image are numbered 0..TVT-1: BC7's own tables, then the target's one or
@@ -405,6 +407,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         const unsigned ntile = tile + gridDim.x;
         uint4 vn[BU_BPT];
         if constexpr (PREFETCH) {
+            desc_of(ntile, tl);
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) {
                 vn[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
@@ -504,8 +507,10 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) v[j] = vn[j];
+            td = tl;
         } else {
-            load_desc(ntile);
+            desc_of(ntile, tl);
+            td = tl;
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) v[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
         }
@@ -524,13 +529,15 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
     bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr);
 }
 
-// several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value)
-template <int TARGET, int WGS, int BPT>
+// several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value).
+// PREFETCH: the launch is a persistent grid whose workgroups walk many tiles (batches of large slices): the next tile's blocks -- of
+// whatever run it belongs to -- are loaded while the current tile is transcoded, as in the one-slice kernel.
+template <int TARGET, int WGS, int BPT, bool PREFETCH = false>
 __global__ __launch_bounds__(WGS, 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
                                                              const BuTablesAll* __restrict__ tables)
 {
     static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, false, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table);
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into

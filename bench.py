@@ -921,6 +921,28 @@ def run_atlas4096(env):
                                              "note": "two contiguous atlases per call of bu_uastc_transcode_batch_device = one 2^21-block launch, calls back to back on one "
                                                      "stream, exclusive policy, cold rotation over %d pairs" % n_pairs}
             del pin, pout
+            # the reference's loop over slices (basis.rs:246-257) on EIGHT atlases in separate allocations through ONE call of the batch entry point:
+            # one launch of a persistent grid that walks the tiles of all eight runs with the next tile's loads in flight (run table in the kernel arguments)
+            VP8, SZ8 = ctypes.c_void_p * 8, ctypes.c_size_t * 8
+            b8 = [(VP8(*[in_ptrs[(8 * k + j) % nbuf] for j in range(8)]), SZ8(*([N_BLOCKS] * 8)), VP8(*[out_ptrs[(8 * k + j) % nbuf] for j in range(8)])) for k in range(nbuf // 8)]
+
+            def eight(k):
+                a_, n_, o_ = b8[k % len(b8)]
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, 8, a_, n_, o_, NBX, None, None, sp) == 0
+
+            for k in range(16):
+                eight(k)
+            e0.record(stream)
+            for k in range(32):
+                eight(k)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            b8_s = e0.elapsed_time(e1) / 1e3 / 256
+            extra["batch_8_atlases_separate_allocations"] = {"us_per_atlas": round(b8_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / b8_s / 1e6, 1),
+                                                             "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / b8_s / 1e9 / HBM_PEAK_GBS, 4),
+                                                             "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
+                                                             "note": "one call of bu_uastc_transcode_batch_device per eight 2^20-block slices in separate allocations = ONE launch over 2^23 blocks, "
+                                                                     "calls back to back on one stream, exclusive policy; every rotated output compared afterwards"}
         except Exception as e:  # secondary rows must never break the headline line
             extra["launches_in_flight_matrix_error"] = repr(e)
         # a loop over 64 independent slices of 65 536 blocks (256 x 256 blocks: a 1024 x 1024 px mip), the shape of the per-slice

@@ -156,7 +156,9 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
  * up to 96 runs at unrelated addresses are ONE kernel launch with the run table in its kernel arguments (nothing is allocated,
  * copied or freed behind the call; longer batches go out as one launch per 96 runs) -- 64 slices of 65 536 blocks in separate
  * allocations take ~46 us call + synchronize where 64 launches take 290 us on one stream and 230-260 us on two to eight: a loop
- * of launches is bound by the host's ~4 us per launch, not by the GPU.  Small batches (a 1-slice "batch") cost what
+ * of launches is bound by the host's ~4 us per launch, not by the GPU.  A batch of LARGE slices at unrelated addresses (BC7, ASTC, RGBA32)
+ * is one launch of a persistent grid that walks all the runs' tiles with the next tile's loads in flight: eight 2^20-block slices in
+ * separate allocations ~6.4 us each where eight launches one after another take 8.4.  Small batches (a 1-slice "batch") cost what
  * bu_uastc_transcode_device costs.  RGBA32: every slice uses the same blocks_per_row. */
 bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
                                           const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,

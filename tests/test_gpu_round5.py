@@ -147,3 +147,108 @@ def test_streams_window_runs_every_launch_on_every_stream(golden, shared, stream
     assert lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 0, n, 1024,
                                                      0, 4, 0, 9, None, ctypes.byref(ev), ctypes.byref(host), None, None) == _lib.ERR_ARGUMENT
     ctx.close()
+
+
+def _batch_args(ins, outs, sizes):
+    n_s = len(sizes)
+    VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+    return n_s, VP(*[t.data_ptr() for t in ins]), SZ(*sizes), VP(*[t.data_ptr() for t in outs])
+
+
+@pytest.mark.parametrize("target", ["bc7", "etc1", "etc2", "rgba"])
+def test_batch_of_large_runs_in_separate_allocations(ctx, golden, target):
+    """bu_uastc_transcode_batch_device with several runs of more than one tile per CU in separate allocations, small ones between them: one
+    launch of a persistent grid whose workgroups walk the tiles of ALL runs with the next tile's loads in flight (BC7 / ASTC / RGBA32; the
+    prefetch crosses run boundaries, ragged last tiles included).  Same bytes as the known answers, in stream order with the caller's own
+    work in front of and behind the call, and block errors numbered through the whole batch."""
+    import torch
+
+    from basisu_rs_amd import BasisuError
+
+    lib = _lib.load()
+    t, bb = TB[target]
+    bpr = 512
+    sizes = [bpr * 640 + 0, 4096, bpr * 601, bpr * 1024, 70000 // bpr * bpr, bpr * 700, bpr * 523, bpr * 8]  # five large runs (> 262 144 blocks, ragged last tiles), three small
+    idx = [synth.gold_indices(n, seed=1500 + k) for k, n in enumerate(sizes)]
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    want = torch.from_numpy(golden[target]).cuda()
+    s = torch.cuda.Stream()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    ins = [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for n in sizes]
+    outs = [torch.zeros((n, bb), dtype=torch.uint8, device="cuda") for n in sizes]
+    sums = torch.zeros(len(sizes), dtype=torch.int64, device="cuda")
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    n_s, pi, pn, po = _batch_args(ins, outs, sizes)
+    with torch.cuda.stream(s):
+        # the inputs are WRITTEN on the caller's stream right in front of the call, the outputs are READ on it right behind
+        for k in range(len(sizes)):
+            ins[k].copy_(gu[torch.from_numpy(idx[k]).cuda()])
+        ctx.status_word_reset(status, stream=s)
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, n_s, pi, pn, po, bpr, None, ctypes.c_void_p(status.data_ptr()), sp) == 0
+        for k in range(len(sizes)):
+            sums[k] = outs[k].to(torch.int64).sum()
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()))
+    for k, n in enumerate(sizes):
+        got = outs[k]
+        if target == "rgba":
+            got = got.view(n // bpr, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64)
+        exp = want[torch.from_numpy(idx[k]).cuda()]
+        assert torch.equal(got, exp), (target, k)
+        assert int(sums[k].item()) == int(exp.to(torch.int64).sum().item()), (target, k)  # what the caller's stream saw behind the call
+    # two failing blocks in different large runs: the lower batch-wide index is reported
+    ins[3][12345, 0] = 69
+    ins[5][7, 0] = 69
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, n_s, pi, pn, po, bpr, None, ctypes.c_void_p(status.data_ptr()), sp) == 0
+    torch.cuda.synchronize()
+    with pytest.raises(BasisuError) as e:
+        ctx.status_word_check(int(status.item()))
+    assert e.value.first_bad_block == sum(sizes[:3]) + 12345
+
+
+def test_batch_of_large_runs_replays_from_a_hip_graph(ctx, golden):
+    """the persistent multi-run launch carries its run table in the kernel arguments like the small one: capture on a stream, change the
+    inputs, replay, compare"""
+    import torch
+
+    lib = _lib.load()
+    sizes = [300000, 2048, 280000, 310000]
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    ins = [torch.empty((n, 16), dtype=torch.uint8, device="cuda") for n in sizes]
+    outs = [torch.empty((n, 16), dtype=torch.uint8, device="cuda") for n in sizes]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.Stream()
+    n_s, pi, pn, po = _batch_args(ins, outs, sizes)
+
+    def fill(seed):
+        idx = [torch.from_numpy(synth.gold_indices(n, seed=seed + k)).cuda() for k, n in enumerate(sizes)]
+        for t_, i in zip(ins, idx):
+            t_.copy_(gu[i])
+        return idx
+
+    def call():
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, n_s, pi, pn, po, 0, None, ctypes.c_void_p(status.data_ptr()), ctypes.c_void_p(s.cuda_stream)) == 0
+
+    fill(2900)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ctx.status_word_reset(status, stream=s)
+        call()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ctx.status_word_reset(status, stream=s)
+        call()
+    for seed in (2910, 2920):
+        idx = fill(seed)
+        for t_ in outs:
+            t_.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+        for k in range(n_s):
+            assert (outs[k].cpu().numpy() == golden["bc7"][idx[k].cpu().numpy()]).all(), k
