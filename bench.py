@@ -72,6 +72,29 @@ def pmc_traffic():
         return None
 
 
+def pmc_array512():
+    """rocprofv3's per-kernel average and the HBM traffic of BASELINE config 5's 2^25-block launch from the committed passes (tools/gpu_pmc.sh:
+    --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs), or None"""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_bc7_array512.json")), key=lambda p: [int(x) for x in re.findall(r"\d+", os.path.basename(p))])
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        out = {"profile": os.path.relpath(files[-1], ROOT) + " (committed rocprofv3 passes over this launch; not measured in this run)"}
+        if "trace_avg_ns" in d:
+            out["kernel_avg_ns"] = round(d["trace_avg_ns"], 1)
+            out["frac_by_rocprofv3_kernel_avg"] = round(BYTES_PER_BLOCK * (1 << 25) / d["trace_avg_ns"] / HBM_PEAK_GBS, 4)
+        if "hbm_bytes_per_launch" in d:
+            out["traffic"] = int(d["hbm_bytes_per_launch"])
+            out["traffic_over_algorithmic"] = round(d["hbm_bytes_per_launch"] / (BYTES_PER_BLOCK * (1 << 25)), 4)
+        return out
+    except Exception:
+        return None
+
+
 def pmc_child():
     """`bench.py --pmc-child`: the program rocprofv3's child passes run (live_traffic): the headline BC7 kernel (launch policy from
     BENCH_PMC_POLICY) over 24 cold A-gold atlases of the headline size, nothing else.  Counter passes: once over each atlas, one launch
@@ -1045,6 +1068,9 @@ def run_atlas4096(env):
                                             "verified": big_ok,
                                             "note": "BASELINE config 5 on ONE GPU: 512 slices x 65 536 blocks contiguous, one launch per step, cold (two 1 GiB "
                                                     "pairs rotated), 8 lead + 40 timed launches between events; `--config array512` is the sharded form"}
+            a512 = pmc_array512()
+            if a512:  # rocprofv3's own view of this launch: committed kernel-trace and counter passes (tools/gpu_pmc.sh), NOT measured in this run
+                extra["array512_one_launch"].update(a512)
             del big_in, big_out, big_idx0
         except Exception as e:
             extra["array512_one_launch_error"] = repr(e)
