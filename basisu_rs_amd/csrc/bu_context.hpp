@@ -132,7 +132,7 @@ struct BuShape {
 // launch's load phase (3.4 us with the vector ALUs idle when it is alone) lies under another one's chunk phase (ALUs saturated, HBM
 // idle).  A launch takes at most half of a CU's wave slots, registers and LDS (round 5, profiles/r05_ab_*_shapes_x_streams*.txt;
 // us per 4096^2 atlas with 1 / 2 / 3 / 4 launches in flight):
-//   BC7 / ASTC  256 x 4, two per CU (8 waves, 56 KiB)              11.8 / 7.35 / 6.25 / 5.95   (exclusive shape: 8.5 / 6.7 / 6.3 / 6.5)
+//   BC7 / ASTC  256 x 4, two per CU (8 waves, 56 KiB), no wave priorities   11.8 / 6.8 / 6.0 / 5.45-5.55   (exclusive shape: 8.4 / 6.7 / 6.2 / 6.2)
 //   ETC1        512 x 4, one per CU (8 waves, <= 128 VGPRs, 63 KiB) 20.1 / 13.3 / 12.2 / 12.4   (17.7 / 15.5 / 15.2 / 15.7)
 //   ETC2        the same without the prefetch (115 VGPRs)           25.4 / 16.4 / 15.2 / 15.2   (22.1 / 19.7 / 19.3 / 20.4)
 // Alone on the chip a shared-policy launch is 15-40 % slower than an exclusive one: the policy is for callers that keep >= 2
@@ -192,16 +192,20 @@ void bu_go(const BuPiece& p, unsigned grid, unsigned cus, unsigned tile_rt)
                        (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, tile_rt);
 }
 
-// a large launch in shape S: persistent workgroups, PER_CU per CU, walking equal shares of the tiles
+// a large launch in shape S: persistent workgroups, PER_CU per CU, walking equal shares of the tiles.  `priorities`: the static wave
+// priorities by residency generation (kernel, `cus`).  They serve a launch that is ALONE on the chip (BC7 8.57 -> 8.37 us) and hurt as
+// soon as launches of several streams share the CUs -- the generations of different launches then compete through the same four levels:
+// shared shape, four in flight 5.72-5.79 -> 5.44-5.56 us per atlas without them (the exclusive shape on two streams 6.70 -> 5.97:
+// profiles/r05_ab_wave_priorities_with_launches_in_flight.txt) -- so the shared policy launches without.
 template <int TARGET, class S>
-void bu_go_big(const BuPiece& p, unsigned cu_count)
+void bu_go_big(const BuPiece& p, unsigned cu_count, bool priorities)
 {
     const size_t slots = (size_t)cu_count * S::PER_CU;
     const size_t tile_rt = bu_balanced_tile((size_t)S::TILE, p.nb, slots, bu_dyn_tile(TARGET, S::TILE));
     const size_t tiles = (p.nb + tile_rt - 1) / tile_rt;
     // generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per
     // slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0)
-    const unsigned cus = (tiles <= slots || tiles % slots == 0) ? cu_count : 0u;
+    const unsigned cus = (priorities && (tiles <= slots || tiles % slots == 0)) ? cu_count : 0u;
     bu_go<TARGET, S>(p, (unsigned)(tiles < slots ? tiles : slots), cus, (unsigned)tile_rt);
 }
 
@@ -214,8 +218,8 @@ void bu_launch_sorted(const BuPiece& p, unsigned cu_count, int policy, unsigned 
     } else if (p.nb <= (size_t)BU_HOST_TILE * cu_count) {
         bu_go<TARGET, BuOneTileShape<TARGET>>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
     } else if (bu_big_from_one_tile_per_cu(TARGET) || p.nb > (size_t)3 * BU_HOST_TILE * cu_count) {
-        if (policy == BU_POLICY_SHARED) bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_SHARED>>(p, cu_count);
-        else bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_EXCLUSIVE>>(p, cu_count);
+        if (policy == BU_POLICY_SHARED) bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_SHARED>>(p, cu_count, false);
+        else bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_EXCLUSIVE>>(p, cu_count, true);
     } else {
         bu_go<TARGET, BuEtcMidShape>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
     }
@@ -233,7 +237,7 @@ void bu_launch_sorted_rgba(const BuPiece& p, unsigned cu_count, int policy, unsi
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     // generation priorities only when every workgroup walks at least two tiles (2^19 blocks 10.7 -> 10.3 us and
     // 786 432 blocks 15.75 -> 14.24 without them, 2^20 blocks 16.7 against 18.7 with them)
-    const unsigned cus = tiles >= 2 * (size_t)grid ? cu_count : 0u;
+    const unsigned cus = (policy != BU_POLICY_SHARED && tiles >= 2 * (size_t)grid) ? cu_count : 0u;
     if (grid_cap == 0 && p.nb <= ((size_t)3 << 20)) bu_go<BU_TGT_RGBA, BuShape<1024, 1, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
     else bu_go<BU_TGT_RGBA, BuShape<512, 2, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
 }

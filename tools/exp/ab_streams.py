@@ -19,6 +19,7 @@ ap.add_argument("--bpr", type=int, default=1024)
 ap.add_argument("--launches", type=int, default=240)
 ap.add_argument("--lead", type=int, default=64)
 ap.add_argument("--tail", type=int, default=-1)  # untimed launches behind the end events; -1 = one per stream
+ap.add_argument("--prewarm_ms", type=float, default=0.0)  # untimed windows of the same cell for this long in front of every measurement (clocks)
 ap.add_argument("--policy", default="")  # comma list of launch policies to set per cell (libraries that export bu_context_set_launch_policy)
 a = ap.parse_args()
 vp = ctypes.c_void_p
@@ -79,6 +80,9 @@ for r in range(a.rounds):
     for name, L, h, p in libs:
         res = []
         for ns in streams:
+            import time as _t
+            t0 = _t.perf_counter()
+            while a.prewarm_ms and (_t.perf_counter() - t0) * 1e3 < a.prewarm_ms: run(L, h, p, ns, first, 0, 256)
             us, ev, late = run(L, h, p, ns, first, a.lead, a.launches)
             first = (first + a.lead + a.launches) % NBUF
             res.append("S%d %.2f (ev %.2f%s)%s" % (ns, us, ev, " LATE" if late else "", "" if bad[(name, ns)] == 0 else " WRONG:%d" % bad[(name, ns)]))
