@@ -607,17 +607,29 @@ def run_array512(env):
     fulls = [RawDeviceBuffer(env, world * shard_bytes) for _ in range(nrot)]
     status = torch.empty(1, dtype=torch.int64, device=dev)
     ctx.status_word_reset(status)
-    PtrArr = ctypes.c_void_p * nrot
-    in_ptrs = PtrArr(*[t.data_ptr() for t in ins])
-    out_ptrs = PtrArr(*[f.ptr + rank * shard_bytes for f in fulls])
-    rot = [0]
+    # A rank issues its range of slices as P equal pieces on P context streams under the shared launch policy (--in-flight, default 4): launches
+    # queued on one stream never overlap and even a 2^25-block launch leaves a seventh of the HBM rate unused (one launch 189 us = 0.71 of the
+    # roofline; four launches of 2^23 blocks in flight 167 us = 0.80).  P = 1 (ragged splits, --in-flight 1): one launch over the range.
+    P = args.in_flight if (args.in_flight > 1 and (hi - lo) % args.in_flight == 0) else 1
+    ctx.set_launch_policy(P > 1 and args.policy == "shared")
+    npiece = nb // P
+    PtrArr = ctypes.c_void_p * (nrot * P)
+    in_ptrs = PtrArr(*[t.data_ptr() + q * npiece * 16 for t in ins for q in range(P)])
+    out_ptrs = PtrArr(*[f.ptr + rank * shard_bytes + q * npiece * 16 for f in fulls for q in range(P)])
+    rot = [0]  # in steps; step r uses buffer entries r*P .. r*P + P - 1
+
+    def window(lead_steps, steps):
+        """`steps` passes over this rank's range (P launches each), behind `lead_steps` untimed ones; (event ms, host ms) of the timed part"""
+        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+        tail = P if (P > 1 and lead_steps > 0) else 0
+        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, env._lib.BC7, in_ptrs, out_ptrs, nrot * P, (rot[0] % nrot) * P, npiece, 256, lead_steps * P, steps * P,
+                                                             tail, P, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None),
+              "bu_time_uastc_launches_streams_window")
+        rot[0] = (rot[0] + lead_steps + steps + (1 if tail else 0)) % nrot
+        return ev.value, host.value
 
     def run(launches):
-        ms = ctypes.c_float(0)
-        check(env, lib.bu_time_uastc_launches(ctx.handle, env._lib.BC7, in_ptrs, out_ptrs, nrot, rot[0], nb, 256, launches,
-                                              ctypes.c_void_p(status.data_ptr()), env.sp, ctypes.byref(ms)), "bu_time_uastc_launches")
-        rot[0] = (rot[0] + launches) % nrot
-        return ms.value
+        return window(0, launches)[0]
 
     def expect(s):
         return env.g_bc7[slice_idx(s)]
@@ -643,19 +655,16 @@ def run_array512(env):
     torch.cuda.synchronize()
 
     def warm_async(i, ssp):
-        k = (rot[0] + i) % nrot
-        lib.bu_uastc_transcode_device(ctx.handle, env._lib.BC7, ctypes.c_void_p(in_ptrs[k]), nb, ctypes.c_void_p(out_ptrs[k]), 256, 0, None, ssp)
+        k = ((rot[0] + i) % nrot) * P
+        lib.bu_uastc_transcode_device(ctx.handle, env._lib.BC7, ctypes.c_void_p(in_ptrs[k]), npiece, ctypes.c_void_p(out_ptrs[k]), 256, 0, None, ssp)
 
     busy_barrier(env, warm_async, max(2, 12 // world))  # ~3 ms of work
-    # timed region as in run_atlas4096: lead untimed launches, event 0, K timed launches, event 1, no host sync in between
+    # timed region as in run_atlas4096: lead untimed steps, K timed steps, (P > 1: one tail launch per stream), no host sync in between;
+    # the window runs from the last lead launch's completion to the last timed launch's completion
     lead = 16
-    ev_c, host_c, late_c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
-    check(env, lib.bu_time_uastc_launches_window(ctx.handle, env._lib.BC7, in_ptrs, out_ptrs, nrot, rot[0], nb, 256, lead, args.steps,
-                                                 ctypes.c_void_p(status.data_ptr()), env.sp, ctypes.byref(ev_c), ctypes.byref(host_c),
-                                                 ctypes.byref(late_c)), "bu_time_uastc_launches_window")
-    rot[0] = (rot[0] + lead + args.steps) % nrot
+    ev_ms, host_ms = window(lead, args.steps)
     torch.cuda.synchronize()
-    ev_ms, dt = ev_c.value, max(host_c.value, ev_c.value) / 1e3
+    dt = max(host_ms, ev_ms) / 1e3
     if env.use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -679,14 +688,15 @@ def run_array512(env):
         "ms_per_step": round(dt_max / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "UASTC->BC7, texture array of 512 slices x 65 536 blocks (512 MiB in, 512 MiB out) per step; rank r owns "
-                               "slices [r*512/N, (r+1)*512/N), one launch over its contiguous range; A-gold blocks; %d rotated "
-                               "input shards / full output buffers per rank" % nrot,
+                               "slices [r*512/N, (r+1)*512/N) and issues its contiguous range as %d launch(es) of %d blocks on %d context stream(s) (%s launch "
+                               "policy); A-gold blocks; %d rotated input shards / full output buffers per rank" % (P, npiece, P, "shared" if (P > 1 and args.policy == "shared") else "exclusive", nrot),
+                   "launches_in_flight": P,
                    "blocks_per_step": total, "slices_per_gpu": hi - lo, "gb_s_in": round(value * 16 / 1e3, 1),
                    "prewarm": {"launches": prewarm_launches, "ms": 4 * args.prewarm_ms,
                                "note": "untimed launches ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}},
         "transcode_only": {"mblocks_s": round(total / kern_s / 1e6, 1), "us_per_step_kernel_max_over_ranks": round(kern_s * 1e6, 3),
                            "us_per_step_kernel_per_rank": per_rank_kernel_us,
-                           "note": "all blocks / slowest rank's kernel time (hipEvents on the launch stream)"},
+                           "note": "all blocks / slowest rank's time per step (hipEvents on the launch streams: last lead launch complete -> last timed launch complete)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "bu_uastc_sorted_kernel<BC7>", "us_per_launch": round(kern_s * 1e6, 3),
                      "bytes_per_launch": BYTES_PER_BLOCK * nb, "note": "per GPU, on its shard"},
@@ -1075,6 +1085,34 @@ def run_atlas4096(env):
                                             "verified": big_ok,
                                             "note": "BASELINE config 5 on ONE GPU: 512 slices x 65 536 blocks contiguous, one launch per step, cold (two 1 GiB "
                                                     "pairs rotated), 8 lead + 40 timed launches between events; `--config array512` is the sharded form"}
+            # the same array as FOUR launches of 2^23 blocks in flight on four context streams (shared policy): what `--config array512` does per rank
+            try:
+                bi4 = (ctypes.c_void_p * 8)(*[t.data_ptr() + q * (nbig // 4) * 16 for t in big_in for q in range(4)])
+                bo4 = (ctypes.c_void_p * 8)(*[t.data_ptr() + q * (nbig // 4) * 16 for t in big_out for q in range(4)])
+                ctx.set_launch_policy(True)
+
+                def big4(lead_steps, steps):
+                    ev, host = ctypes.c_float(0), ctypes.c_float(0)
+                    check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, bi4, bo4, 8, 0, nbig // 4, 256, 4 * lead_steps, 4 * steps, 4 if lead_steps else 0, 4,
+                                                                         ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None), "bu_time_uastc_launches_streams_window")
+                    return max(ev.value, host.value) / 1e3 / steps
+
+                for t_ in big_out:
+                    t_.zero_()
+                torch.cuda.synchronize()
+                big4(0, 2)
+                torch.cuda.synchronize()
+                big4_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0]))
+                t_big = time.perf_counter()
+                while args.prewarm_ms > 0 and (time.perf_counter() - t_big) * 1e3 < 4 * args.prewarm_ms:
+                    big4(0, 8)
+                b4_s = big4(8, 40)
+                extra["array512_four_launches_in_flight"] = {"blocks": nbig, "us_per_array": round(b4_s * 1e6, 2), "mblocks_s": round(nbig / b4_s / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * nbig / b4_s / 1e9, 1),
+                                                             "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / b4_s / 1e9 / HBM_PEAK_GBS, 4), "verified": big4_ok,
+                                                             "note": "the 512-slice array as four launches of 128 slices (2^23 blocks) each on four context streams, shared launch policy; 8 lead + 40 "
+                                                                     "timed passes over the array, window from the last lead launch's completion to the last timed launch's"}
+            finally:
+                ctx.set_launch_policy(policy_now[0])
             a512 = pmc_array512()
             if a512:  # rocprofv3's own view of this launch: committed kernel-trace and counter passes (tools/gpu_pmc.sh), NOT measured in this run
                 extra["array512_one_launch"].update(a512)
