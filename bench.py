@@ -1340,11 +1340,11 @@ def run_atlas4096(env):
                                     "frac_of_hbm_peak": round(80 * N_BLOCKS / rg_s / 1e9 / HBM_PEAK_GBS, 4), "verified": rg_ok,
                                     "note": "BASELINE config 3: 4096x4096 UASTC -> RGBA32 (16 B in + 64 B out per block), cold rotation over 16 atlases, one launch at a time"}
         try:
-            sramp(3, False, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
-            rg3 = srow(256, 3, False, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
+            sramp(4, True, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
+            rg3 = srow(256, 4, True, target=_lib.RGBA32, inp=rg_in, outp=rg_outp, nb=rg_n)
             torch.cuda.synchronize()
             rg3_ok = bool(torch.equal(rg_out[1].view(NBY, 4, NBX, 16).permute(0, 2, 1, 3).reshape(N_BLOCKS, 64), torch.from_numpy(golden["rgba"]).to(dev)[idxs[1]]))
-            extra["uastc_to_rgba32"]["in_flight_3_exclusive"] = {"us_per_atlas": round(rg3 * 1e6, 3), "gb_s": round(80 * N_BLOCKS / rg3 / 1e9, 1),
+            extra["uastc_to_rgba32"]["in_flight_4_shared"] = {"us_per_atlas": round(rg3 * 1e6, 3), "gb_s": round(80 * N_BLOCKS / rg3 / 1e9, 1),
                                                                  "frac_of_hbm_peak": round(80 * N_BLOCKS / rg3 / 1e9 / HBM_PEAK_GBS, 4), "verified": rg3_ok}
         except Exception as e:
             extra["uastc_to_rgba32"]["in_flight_error"] = repr(e)
