@@ -301,10 +301,13 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     };
     // (a job runs on a pool thread: an exception -- std::bad_alloc from a vector sized by a hostile file -- must become a status there,
     // it cannot unwind through the pool)
-    auto run_slice = [&](Job& j) {
+    // publish_rows = false: the slice is decoded AGAIN after a two-thread attempt gave up (settle_split).  The resolver has already published
+    // rows -- final ones, which this pass writes again with the same values -- and the feeder may have launched bands over them: the row
+    // counter must not fall back to 1 and climb a second time, so this pass publishes nothing and the feeder picks the rest up from `done`.
+    auto run_slice = [&](Job& j, bool publish_rows = true) {
         if (st_tables == BU_OK && !abort.load(std::memory_order_relaxed)) {
             try {
-                j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx, &j.rows, &abort);
+                j.st = lz.decode_slice(j.nbx, j.nby, j.data, j.len, j.idx, publish_rows ? &j.rows : nullptr, &abort);
             } catch (...) {
                 j.st = BU_ERR_BOUNDS;
             }
@@ -320,7 +323,7 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             j.st = BU_OK;
             j.done.store(1, std::memory_order_release);
         } else {
-            run_slice(j);  // an irregular stream (or an abort): the ordinary loops, from the slice's first bit
+            run_slice(j, false);  // an irregular stream (or an abort): the ordinary loops, from the slice's first bit
         }
     };
     auto run_lex = [&](Job& j) {

@@ -269,7 +269,8 @@ bu_status bu_read_query(bu_read_target target, const uint8_t* file, size_t len, 
 /* read_to_{rgba,etc1,etc2,uastc,astc,bc7}: every slice of the file (every colour/alpha pair for RGBA from an
  * ETC1S file with alpha) becomes one bu_image whose bytes are written to `out`.  header_out may be NULL.
  * Reference quirks are reproduced: the data CRC covers bytes[77..EOF]; total_selectors sizes BOTH ETC1S
- * codebooks (basis.rs:289-291); ETC1S RGBA images report stride 16*orig_width (basis.rs:46,64). */
+ * codebooks (basis.rs:289-291); ETC1S RGBA images report stride 16*orig_width (basis.rs:46,64).
+ * On an error return the contents of `out` are undefined (parts of it may already have been written). */
 bu_status bu_read_to(bu_context* ctx, bu_read_target target, const uint8_t* file, size_t len, bu_basis_header* header_out,
                      bu_image* images, size_t max_images, size_t* n_images, uint8_t* out, size_t out_bytes);
 /* Host-only BasisLZ decode of an ETC1S file (basis_lz/mod.rs:64-95, 188-458): the two codebooks in the layouts

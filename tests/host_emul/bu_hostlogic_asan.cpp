@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <functional>
 
@@ -41,6 +42,37 @@ static int process(const uint8_t* f, size_t len, int target)
         seq[k].assign((size_t)s.num_blocks_x * s.num_blocks_y + 1, 0);
         seq_st = lz.decode_slice(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, seq[k].data());
         if (!seq_st) seq_decoded = k + 1;
+        // decode_slice is the fast loop with the exact loop (round 1's, status for status the oracle's) as its fallback: compare the two
+        // DIRECTLY on every slice -- the exact loop's status is the verdict, and wherever the fast loop claims a regular stream its indices
+        // are the exact loop's; rows it published before giving up are final and must match too
+        {
+            const size_t n = (size_t)s.num_blocks_x * s.num_blocks_y;
+            std::vector<uint32_t> ex(n + 1, 0), fa(n + 1, 0);
+            const bu_status ex_st = lz.decode_slice_exact(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, ex.data());
+            if (ex_st != seq_st) {
+                fprintf(stderr, "decode_slice status %d, decode_slice_exact %d in slice %zu\n", (int)seq_st, (int)ex_st, k);
+                abort();
+            }
+            if (!ex_st && ex != seq[k]) {
+                fprintf(stderr, "decode_slice differs from decode_slice_exact in slice %zu\n", k);
+                abort();
+            }
+            if (s.num_blocks_x && s.num_blocks_y) {
+                std::atomic<uint32_t> rows{0};
+                const bool fast_ok = lz.decode_slice_fast(s.num_blocks_x, s.num_blocks_y, f + s.file_ofs, s.file_size, fa.data(), &rows);
+                if (fast_ok && (ex_st != BU_OK || fa != ex)) {
+                    fprintf(stderr, "decode_slice_fast accepts slice %zu and disagrees with the exact loop (status %d)\n", k, (int)ex_st);
+                    abort();
+                }
+                if (!ex_st) {  // rows published before a give-up (or all of them) are the exact loop's
+                    const size_t pub = (size_t)rows.load() * s.num_blocks_x;
+                    if (pub > n || !std::equal(fa.begin(), fa.begin() + (long)pub, ex.begin())) {
+                        fprintf(stderr, "rows published by decode_slice_fast differ from the exact loop in slice %zu\n", k);
+                        abort();
+                    }
+                }
+            }
+        }
     }
     // ... and on 4 threads, as bu_read_to does it (threading forced: these files are tiny): same status, same indices
     std::vector<bu_host::SliceJob> jobs;
