@@ -50,6 +50,7 @@ NBX = NBY = 1024  # 4096x4096 px
 N_BLOCKS = NBX * NBY
 BYTES_PER_BLOCK = 32  # 16 read + 16 written
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ETC1S_UNPINNED = "unpinned: the reference holds no ETC1S / BasisLZ vectors (tests/corpus_tests.rs:54-73 are #[ignore]d, the corpus absent); checked against the oracle's reading of the source"
 
 
 def pmc_traffic():
@@ -1213,7 +1214,7 @@ def run_atlas4096(env):
                 torch.cuda.synchronize()
                 ts = e0.elapsed_time(e1) / 1e3 / reps
                 extra[name] = {"gb_s": round(bpb * nbl / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3), "mblocks_s": round(nbl / ts / 1e6, 1),
-                               "bytes_per_block": bpb, "blocks": nbl}
+                               "bytes_per_block": bpb, "blocks": nbl, "parity": ETC1S_UNPINNED}
             del d_idx, d_o8, d_o64
             # the same kernels on a large slice (2^22 blocks, 2048 x 2048 blocks): the codebooks are staged in LDS from 2^19 blocks up
             nbl2 = 1 << 22
@@ -1233,7 +1234,7 @@ def run_atlas4096(env):
                 torch.cuda.synchronize()
                 ts = e0.elapsed_time(e1) / 1e3 / reps
                 extra[name] = {"gb_s": round(bpb * nbl2 / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3), "mblocks_s": round(nbl2 / ts / 1e6, 1),
-                               "bytes_per_block": bpb, "blocks": nbl2, "frac_of_hbm_peak": round(bpb * nbl2 / ts / 1e9 / HBM_PEAK_GBS, 3)}
+                               "bytes_per_block": bpb, "blocks": nbl2, "frac_of_hbm_peak": round(bpb * nbl2 / ts / 1e9 / HBM_PEAK_GBS, 3), "parity": ETC1S_UNPINNED}
             del d_idx2, d_o8b, d_o64b
         except Exception as e:  # secondary rows must never break the headline line
             extra["etc1s_error"] = repr(e)
@@ -1260,6 +1261,7 @@ def run_atlas4096(env):
             extra["etc1s_file_read_to_rgba"] = {"slices": 16, "blocks": 16 * 16384, "file_bytes": len(fbytes), "ms_per_file": round(file_s * 1e3, 3),
                                                 "mblocks_s": round(16 * 16384 / file_s / 1e6, 1),
                                                 "ms_slice_by_slice_host_decode_only": round(seq_s * 1e3, 3),
+                                                "parity": ETC1S_UNPINNED,
                                                 "note": "whole-file API: parse + CRC + BasisLZ decode of all slices on the host cores + GPU decode + download"}
             # config 4 as stated: ONE slice of 512 x 512 blocks (the entropy decode of a single slice is serial: one host core)
             fone, _, _ = bb.etc1s_file(np.random.default_rng(45), [(512, 512)], n_codebook=4096)
@@ -1278,7 +1280,7 @@ def run_atlas4096(env):
                 bu.basislz_decode(fone, 0)
                 times.append(time.perf_counter() - t0)
             lz_s = sorted(times)[len(times) // 2]
-            row4 = {"blocks": 512 * 512, "file_bytes": len(fone), "ms_per_file": round(one_s * 1e3, 3), "mblocks_s": round(512 * 512 / one_s / 1e6, 1),
+            row4 = {"parity": ETC1S_UNPINNED, "blocks": 512 * 512, "file_bytes": len(fone), "ms_per_file": round(one_s * 1e3, 3), "mblocks_s": round(512 * 512 / one_s / 1e6, 1),
                     "ms_basislz_decode_of_the_slice_on_one_host_thread": round(lz_s * 1e3, 3),
                     "note": "BASELINE config 4 at its stated size through the whole-file API (read_to_rgba, page-locked output).  The slice's entropy "
                             "decode is one serial bit stream; inside the call it runs on two host threads (bit-serial lexer + index resolver, "
@@ -1410,6 +1412,11 @@ def run_atlas4096(env):
             line["roofline"]["kernel_span_ns"] = tr3["kernel_avg_ns"]
             line["roofline"]["period_ns_by_rocprofv3"] = tr3["period_avg_ns"]
             line["roofline"]["frac_by_rocprofv3_period"] = round(BYTES_PER_BLOCK * N_BLOCKS / tr3["end_to_end_period_avg_ns"] / HBM_PEAK_GBS, 4)
+            line["roofline"]["rocprofv3_note"] = ("the trace pass is the evidence for the OVERLAP (dispatch spans of several periods, dispatches starting before their predecessor ends, one "
+                                                  "hardware queue per stream); its period is NOT the unprofiled one and cannot be: under rocprofv3 --kernel-trace an empty kernel completes "
+                                                  "once per 6.3-6.6 us and a 5 us whole-chip kernel once per 7.8-8.1 us whatever the number of streams (plain: 1.5 / 4.85 us; "
+                                                  "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt) -- the profiler's own cost per dispatch exceeds the period being measured.  The "
+                                                  "HIP events and the host clock of this unprofiled run agree (timed_region.event_ms / host_ms); --steps 512 repeats it on a 3 ms window")
     if env.live_traffic[0] is not None:
         line["roofline"]["traffic"] = env.live_traffic[0]
         line["roofline"]["traffic_source"] = env.live_traffic[1]
