@@ -315,6 +315,16 @@ bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream)
     return BU_OK;
 }
 
+bu_status bu_context_synchronize(bu_context* ctx)
+{
+    if (!ctx) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->stream) BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t es : ctx->extra_streams)
+        if (es) BU_HIP(ctx, hipStreamSynchronize(es));
+    return BU_OK;
+}
+
 // ---- per-block API (lib.rs:29-53) -----------------------------------------------------------------------------------------------
 // One 16-byte block is not worth a kernel launch (upload + 1-block launch + download: tens of microseconds; the reference's own
 // benchmark calls these 32 000 times, benches/benchmark.rs:66-98).  They run the product's OWN block code -- the mode-templated

@@ -100,6 +100,9 @@ bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* 
  * flight should start with GPU_MAX_HW_QUEUES=8 in its environment (set before the first HIP call; bench.py does): with the default a
  * process's NULL stream and the context's internal stream already hold two of the four queues. */
 bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream);
+/* waits until everything enqueued on the context's own streams (bu_context_stream) and on its internal stream has completed: the
+ * host-side join for a caller without a HIP binding of its own (examples/slices_in_flight.c) */
+bu_status bu_context_synchronize(bu_context* ctx);
 
 /* ---- UASTC slice level, host pointers ------------------------------------------------------- */
 

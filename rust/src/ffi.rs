@@ -100,6 +100,7 @@ extern "C" {
     pub fn bu_context_get_launch_policy(ctx: *const bu_context, out_policy: *mut c_int) -> c_int;
     // the context's own streams (hipStream_t), index 0..7, on different hardware queues: for several launches in flight
     pub fn bu_context_stream(ctx: *mut bu_context, index: c_int, out_stream: *mut *mut c_void) -> c_int;
+    pub fn bu_context_synchronize(ctx: *mut bu_context) -> c_int;
     // slice level, host pointers (uastc.rs:89-146)
     pub fn bu_uastc_transcode(ctx: *mut bu_context, target: c_int, input: *const u8, in_bytes: usize, out: *mut u8, out_bytes: usize,
                               first_bad_block: *mut u64) -> c_int;

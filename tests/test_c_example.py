@@ -80,3 +80,53 @@ def test_c_example_output_equals_the_oracle(tmp_path, golden, oracle, kind, targ
     if kind == "etc1s" and target == "rgba":
         r = subprocess.run([EXE, "bc7", str(path), str(outp)], capture_output=True, text=True)
         assert r.returncode == 10 + 17
+
+
+# ---- examples/slices_in_flight.c: a texture array's slices, four launches in flight, no HIP header on the caller's side ----------------
+EXE2 = os.path.join(ROOT, "examples", "slices_in_flight")
+
+
+def _build2():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "slices_in_flight"], check=True, capture_output=True)
+
+
+def test_slices_in_flight_compiles_as_c99_and_fails_loudly_without_a_device(tmp_path, golden):
+    import torch
+
+    _build2()
+    idx = synth.gold_indices(6 * 512, seed=21)
+    inp = tmp_path / "a.uastc"
+    inp.write_bytes(golden["uastc"][idx].tobytes())
+    r = subprocess.run([EXE2, "bc7", str(inp), "6", str(tmp_path / "o.bin")], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+    else:
+        assert r.returncode == 10 + 7 and "no usable gfx950 HIP device" in r.stderr
+        assert not (tmp_path / "o.bin").exists()
+    r = subprocess.run([EXE2, "bc7", str(inp), "7", str(tmp_path / "o.bin")], capture_output=True, text=True)  # 6 * 512 blocks are not 7 equal slices
+    assert r.returncode == 2
+    r = subprocess.run([EXE2, "rgba", str(inp), "6", str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2"])
+def test_slices_in_flight_output_equals_the_known_answers(tmp_path, golden, target):
+    """ten slices of 300 000 blocks (large launches: the shared policy's shapes), four in flight on the context's streams, joined by
+    bu_context_synchronize; then a failing block in slice 7: the array-wide index and the reference's message"""
+    _build2()
+    n_slices, n = 10, 300000
+    idx = synth.gold_indices(n_slices * n, seed=22)
+    blocks = golden["uastc"][idx].copy()
+    inp, outp = tmp_path / "a.uastc", tmp_path / "o.bin"
+    inp.write_bytes(blocks.tobytes())
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([EXE2, target, str(inp), str(n_slices), str(outp)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert outp.read_bytes() == golden[target][idx].tobytes()
+    blocks[7 * n + 1234, 0] = 69  # the one invalid 7-bit mode code (uastc.rs:560-577)
+    blocks[9 * n + 5, 0] = 69
+    inp.write_bytes(blocks.tobytes())
+    r = subprocess.run([EXE2, target, str(inp), str(n_slices), str(outp)], capture_output=True, text=True, env=env)
+    assert r.returncode == 10 + 1, r.stdout + r.stderr  # BU_ERR_INVALID_MODE
+    assert "block %d of the array (slice 7)" % (7 * n + 1234) in r.stderr
