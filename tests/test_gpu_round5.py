@@ -252,3 +252,32 @@ def test_batch_of_large_runs_replays_from_a_hip_graph(ctx, golden):
         ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
         for k in range(n_s):
             assert (outs[k].cpu().numpy() == golden["bc7"][idx[k].cpu().numpy()]).all(), k
+
+
+def test_context_streams_and_synchronize(golden):
+    """bu_context_stream hands out eight distinct streams that stay the same on every call; work enqueued on them is complete when
+    bu_context_synchronize returns (no torch synchronisation in between)"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    lib = ctx._lib
+    hs = [ctx.stream(i) for i in range(8)]
+    assert len(set(hs)) == 8 and all(hs) and hs == [ctx.stream(i) for i in range(8)]
+    p = ctypes.c_void_p(0)
+    assert lib.bu_context_stream(ctx.handle, 8, ctypes.byref(p)) == _lib.ERR_ARGUMENT
+    assert lib.bu_context_stream(ctx.handle, -1, ctypes.byref(p)) == _lib.ERR_ARGUMENT
+    n = 1 << 19
+    idx = [synth.gold_indices(n, seed=1700 + k) for k in range(8)]
+    ins = [torch.from_numpy(golden["uastc"][i]).cuda() for i in idx]
+    outs = [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    ctx.set_launch_policy(True)
+    for k in range(8):
+        ctx.transcode_device(_lib.ASTC, ins[k], n, outs[k], blocks_per_row=512, stream=hs[k])
+    assert lib.bu_context_synchronize(ctx.handle) == 0
+    host = [o.cpu().numpy() for o in outs]  # (a device-to-host copy on torch's stream: ordered behind nothing of ours -- the join above is what counts)
+    for k in range(8):
+        assert (host[k] == golden["astc"][idx[k]]).all(), k
+    ctx.close()
