@@ -188,7 +188,9 @@ bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target targe
             used[si] = true;
         }
         const size_t k = (first_buffer + (size_t)i) % n_buffers;
-        bu_status st = bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, s);
+        // (target BU_TIME_COPY_CEILING: the uint4 -> uint4 copy kernel instead of a transcode -- the HBM ceiling of the same pipeline)
+        bu_status st = (int)target == BU_TIME_COPY_CEILING ? bu_copy_ceiling_device(ctx, d_in[k], n_blocks, d_out[k], s)
+                                                             : bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, s);
         if (st) return st;
         if (i == last_timed[si]) BU_HIP(ctx, hipEventRecord(ctx->ev_end[si], s));
     }

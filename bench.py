@@ -917,7 +917,18 @@ def run_atlas4096(env):
         rot[0] += copy_n
         copy_s = ms.value / 1e3 / copy_n
         extra["copy_ceiling"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / copy_s / 1e9, 1), "us_per_launch": round(copy_s * 1e6, 3),
-                                 "note": "uint4->uint4 copy kernel in its fastest known shape (512 threads x 4 elements, nontemporal), same cold-cache rotation"}
+                                 "note": "uint4->uint4 copy kernel in its fastest known one-launch shape (512 threads x 4 elements, nontemporal), same cold-cache rotation, one "
+                                         "launch at a time.  NOT a ceiling for launches in flight: this kernel gains nothing from company (in_flight rows), the transcoder's "
+                                         "persistent workgroups stream faster (single-mode BC7 atlases, four in flight: 5.2 us = 6.4 TB/s)"}
+        try:
+            COPY = 100  # BU_TIME_COPY_CEILING
+            for nfl in (2, 4):
+                srow(64, nfl, False, target=COPY)
+                extra["copy_ceiling"]["in_flight_%d_us_per_launch" % nfl] = round(srow(256, nfl, False, target=COPY) * 1e6, 3)
+            torch.cuda.synchronize()
+            extra["copy_ceiling"]["verified"] = bool(torch.equal(outs[3], ins[3]))
+        except Exception as e:
+            extra["copy_ceiling"]["in_flight_error"] = repr(e)
         one_in, one_out = (ctypes.c_void_p * 1)(ins[0].data_ptr()), (ctypes.c_void_p * 1)(outs[0].data_ptr())
         hot_s = row(max(args.steps, 64), inp=one_in, outp=one_out, nb=1)
         extra["hot_cache"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / hot_s / 1e9, 1), "us_per_launch": round(hot_s * 1e6, 3),

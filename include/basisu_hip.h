@@ -384,6 +384,7 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
  * launch to last instruction of the last one (launches + n_streams - 1 periods in a full pipeline; with lead = tail = 0 the whole run
  * from an idle chip to an idle chip).  *out_host_ms = host steady clock from "every start event seen complete" to "every end event seen complete"; *out_late
  * (optional) = 1 if the first start event had already completed when the host finished enqueueing. */
+#define BU_TIME_COPY_CEILING 100 /* as `target` of the call below: the uint4 -> uint4 copy kernel (bu_copy_ceiling_device) in place of a transcode */
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,
                                                 int lead, int launches, int tail, int n_streams, uint64_t* d_status,

@@ -23,13 +23,13 @@ ap.add_argument("--prewarm_ms", type=float, default=0.0)  # untimed windows of t
 ap.add_argument("--policy", default="")  # comma list of launch policies to set per cell (libraries that export bu_context_set_launch_policy)
 a = ap.parse_args()
 vp = ctypes.c_void_p
-TGT = {"astc": 0, "bc7": 1, "etc1": 2, "etc2": 3, "rgba": 4}
+TGT = {"astc": 0, "bc7": 1, "etc1": 2, "etc2": 3, "rgba": 4, "copy": 100}
 t = TGT[a.target]
 N = a.n; NBUF = 64 if N <= (1 << 20) else 8
 dev = torch.device("cuda", 0)
 g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
 gu = torch.from_numpy(g["uastc"]).to(dev)
-gw = torch.from_numpy(g[a.target]).to(dev)
+gw = torch.from_numpy(g[a.target]).to(dev) if a.target != "copy" else None
 ins, idxs = [], []
 for k in range(NBUF):
     gen = torch.Generator(device=dev); gen.manual_seed(k + 1)
@@ -65,7 +65,7 @@ def check():
     bad = 0
     for k in range(NBUF):
         got = outs[k].view(N // a.bpr, 4, a.bpr, 16).permute(0, 2, 1, 3).reshape(N, 64) if a.target == "rgba" else outs[k]
-        if not torch.equal(got, gw[idxs[k]]): bad += 1
+        if not torch.equal(got, ins[k] if a.target == "copy" else gw[idxs[k]]): bad += 1
     return bad
 streams = [int(x) for x in a.streams.split(",")]
 bad = {}
