@@ -130,11 +130,13 @@ struct BuShape {
 //   RGBA32      1024-block tiles (64 KiB of LDS for the four pixel rows), two workgroups per CU, 1024 x 1 up to 3 Mi blocks then 512 x 2.
 // BU_LAUNCH_SHARED -- several launches from different streams are in flight and should run SIDE BY SIDE on every CU, so that one
 // launch's load phase (3.4 us with the vector ALUs idle when it is alone) lies under another one's chunk phase (ALUs saturated, HBM
-// idle).  A launch takes at most half of a CU's wave slots, registers and LDS (round 5, profiles/r05_ab_*_shapes_x_streams*.txt;
+// idle).  A launch takes at most half of a CU's wave slots, registers and LDS (round 5, profiles/r05_ab_bc7_two_launches_in_flight.txt,
+// r05_ab_etc_shared_shapes_x_streams.txt, r05_ab_wave_priorities_with_launches_in_flight.txt;
 // us per 4096^2 atlas with 1 / 2 / 3 / 4 launches in flight):
 //   BC7 / ASTC  256 x 4, two per CU (8 waves, 56 KiB), no wave priorities   11.8 / 6.8 / 6.0 / 5.45-5.55   (exclusive shape: 8.4 / 6.7 / 6.2 / 6.2)
-//   ETC1        512 x 4, one per CU (8 waves, <= 128 VGPRs, 63 KiB) 20.1 / 13.3 / 12.2 / 12.4   (17.7 / 15.5 / 15.2 / 15.7)
-//   ETC2        the same without the prefetch (115 VGPRs)           25.4 / 16.4 / 15.2 / 15.2   (22.1 / 19.7 / 19.3 / 20.4)
+//   ETC1        512 x 4, one per CU (8 waves, <= 128 VGPRs, 63 KiB) 20.1 / 13.1 / 12.1 / 12.2   (17.7 / 15.5 / 15.2 / 15.7)
+//   ETC2        the same without the prefetch (115 VGPRs)           25.4 / 16.3 / 15.0 / 15.0   (22.1 / 19.7 / 19.3 / 20.4)
+//   RGBA32      1024 x 1, one per CU (16 waves, 69 KiB)             19.6 / 14.7 / 13.4 / 13.1   (14.7 / 14.2 / 13.8 / 13.6)
 // Alone on the chip a shared-policy launch is 15-40 % slower than an exclusive one: the policy is for callers that keep >= 2
 // streams busy (bu_context_set_launch_policy).
 enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1 };

@@ -87,9 +87,9 @@ size_t bu_target_block_bytes(bu_target target);
  *   BU_LAUNCH_EXCLUSIVE (default)  a launch is shaped to fill the chip by itself: lowest latency for a single slice (UASTC->BC7,
  *                                  2^20 blocks: 8.4 us); 6.3-6.7 us per slice with 2-3 streams (head / tail overlap only)
  *   BU_LAUNCH_SHARED               a launch keeps at most half of every CU's wave slots, registers and LDS, so launches from different
- *                                  streams run side by side on each CU: 5.9-6.1 us per slice with 3-4 streams (BC7), ETC1 17.7 -> 12.2,
- *                                  ETC2 22.1 -> 15.2; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
- * Figures: profiles/r05_ab_*_shapes_x_streams*.txt.  Small launches (at most one 1024-block tile per CU) are the same under both. */
+ *                                  streams run side by side on each CU: 5.45-5.6 us per slice with 4 streams (BC7; ASTC 5.4), ETC1 17.7 -> 12.1,
+ *                                  ETC2 22.1 -> 15.0, RGBA32 14.9 -> 13.1; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
+ * Figures: profiles/r05_ab_bc7_two_launches_in_flight.txt, r05_ab_wave_priorities_with_launches_in_flight.txt, r05_ab_etc_shared_shapes_x_streams.txt.  Small launches (at most one 1024-block tile per CU) are the same under both. */
 typedef enum bu_launch_policy { BU_LAUNCH_EXCLUSIVE = 0, BU_LAUNCH_SHARED = 1 } bu_launch_policy;
 bu_status bu_context_set_launch_policy(bu_context* ctx, bu_launch_policy policy);
 bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* out_policy);
