@@ -1147,6 +1147,14 @@ def run_atlas4096(env):
         extra["coherent_atlas"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / coh_s / 1e9, 1), "us_per_launch": round(coh_s * 1e6, 3),
                                    "mblocks_s": round(N_BLOCKS / coh_s / 1e6, 1), "verified": coh_ok,
                                    "note": "A-coh: UASTC mode chosen per 8x8-block tile"}
+        try:
+            sramp(4, True, inp=coh_ptrs, outp=out_ptrs, nb=len(coh))
+            coh4 = srow(256, 4, True, inp=coh_ptrs, outp=out_ptrs, nb=len(coh))
+            torch.cuda.synchronize()
+            extra["coherent_atlas"]["in_flight_4_shared"] = {"us_per_atlas": round(coh4 * 1e6, 3), "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / coh4 / 1e9 / HBM_PEAK_GBS, 4),
+                                                             "verified": bool(torch.equal(outs[0], g_bc7[coh_idx0]))}
+        except Exception as e:
+            extra["coherent_atlas"]["in_flight_error"] = repr(e)
         del coh
         # end-to-end row: host buffer -> host buffer through bu_uastc_transcode (H2D + kernel + D2H, PCIe-bound)
         host_in = golden["uastc"][idx0]
