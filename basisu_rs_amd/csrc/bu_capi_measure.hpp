@@ -158,13 +158,12 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
 // with lead = tail = 0 the whole run from an idle chip to an idle chip.
 // host_ms = steady clock from "every start event seen complete" to "every end event seen complete".
 // n_streams == 1, tail == 0 is bu_time_uastc_launches_window on a context stream.
-bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
-                                                size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches, int tail,
-                                                int n_streams, uint64_t* d_status, float* out_event_ms, float* out_host_ms, float* out_fill_drain_ms,
-                                                int* out_late)
+}  // extern "C"
+template <class LAUNCH>  // bu_status launch(int i, hipStream_t s): enqueue launch number i (lead, timed and tail launches are numbered through) on s
+static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int tail, int n_streams, float* out_event_ms, float* out_host_ms,
+                                   float* out_fill_drain_ms, int* out_late, LAUNCH launch)
 {
-    if (!ctx || !d_in || !d_out || n_buffers == 0 || launches <= 0 || lead < 0 || tail < 0 || !out_event_ms || !out_host_ms || n_streams < 1 || n_streams > 8)
-        return BU_ERR_ARGUMENT;
+    if (!ctx || launches <= 0 || lead < 0 || tail < 0 || !out_event_ms || !out_host_ms || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
     BU_HIP(ctx, hipSetDevice(ctx->device));
     {
         const bu_status sst = bu_ctx_streams(ctx, n_streams);
@@ -187,10 +186,7 @@ bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target targe
             BU_HIP(ctx, hipEventRecord(ctx->ev_start[si], s));
             used[si] = true;
         }
-        const size_t k = (first_buffer + (size_t)i) % n_buffers;
-        // (target BU_TIME_COPY_CEILING: the uint4 -> uint4 copy kernel instead of a transcode -- the HBM ceiling of the same pipeline)
-        bu_status st = (int)target == BU_TIME_COPY_CEILING ? bu_copy_ceiling_device(ctx, d_in[k], n_blocks, d_out[k], s)
-                                                             : bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, s);
+        bu_status st = launch(i, s);
         if (st) return st;
         if (i == last_timed[si]) BU_HIP(ctx, hipEventRecord(ctx->ev_end[si], s));
     }
@@ -233,6 +229,36 @@ bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target targe
     *out_event_ms = last_end - last_start;
     if (out_fill_drain_ms) *out_fill_drain_ms = last_end - first_start;
     return BU_OK;
+}
+
+extern "C" {
+
+bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
+                                                size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches, int tail,
+                                                int n_streams, uint64_t* d_status, float* out_event_ms, float* out_host_ms, float* out_fill_drain_ms,
+                                                int* out_late)
+{
+    if (!d_in || !d_out || n_buffers == 0) return BU_ERR_ARGUMENT;
+    return bu_streams_window(ctx, lead, launches, tail, n_streams, out_event_ms, out_host_ms, out_fill_drain_ms, out_late, [&](int i, hipStream_t s) {
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
+        // (target BU_TIME_COPY_CEILING: the uint4 -> uint4 copy kernel instead of a transcode -- the HBM ceiling of the same pipeline)
+        return (int)target == BU_TIME_COPY_CEILING ? bu_copy_ceiling_device(ctx, d_in[k], n_blocks, d_out[k], s)
+                                                   : bu_uastc_transcode_device(ctx, target, d_in[k], n_blocks, d_out[k], blocks_per_row, 0, d_status, s);
+    });
+}
+
+// the same window over the ETC1S codebook-lookup kernels: launch i decodes index array d_idx[(first_buffer + i) % n_buffers] (nbx x nby blocks each)
+// against one pair of codebooks into d_out[...]; rgba = 0: bu_etc1s_transcode_etc1_device, 1: bu_etc1s_decode_rgba_device (no alpha slice)
+bu_status bu_time_etc1s_launches_streams_window(bu_context* ctx, int rgba, const uint32_t* const* d_idx, void* const* d_out, size_t n_buffers, size_t first_buffer,
+                                                size_t nbx, size_t nby, const uint32_t* d_endpoints, uint32_t n_endpoints, const void* d_selectors,
+                                                uint32_t n_selectors, int lead, int launches, int tail, int n_streams, float* out_event_ms, float* out_host_ms)
+{
+    if (!d_idx || !d_out || n_buffers == 0) return BU_ERR_ARGUMENT;
+    return bu_streams_window(ctx, lead, launches, tail, n_streams, out_event_ms, out_host_ms, nullptr, nullptr, [&](int i, hipStream_t s) {
+        const size_t k = (first_buffer + (size_t)i) % n_buffers;
+        return rgba ? bu_etc1s_decode_rgba_device(ctx, d_idx[k], nullptr, nbx, nby, d_endpoints, n_endpoints, d_selectors, n_selectors, d_out[k], nullptr, s)
+                    : bu_etc1s_transcode_etc1_device(ctx, d_idx[k], nbx * nby, d_endpoints, n_endpoints, d_selectors, n_selectors, d_out[k], nullptr, s);
+    });
 }
 
 // The reference's own micro-benchmark shape (benches/benchmark.rs:66-98: 32 blocks x 1000 calls per target): `reps` passes over

@@ -1234,6 +1234,28 @@ def run_atlas4096(env):
                 ts = e0.elapsed_time(e1) / 1e3 / reps
                 extra[name] = {"gb_s": round(bpb * nbl / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3), "mblocks_s": round(nbl / ts / 1e6, 1),
                                "bytes_per_block": bpb, "blocks": nbl, "parity": ETC1S_UNPINNED}
+            # the same 2^18-block launches (launch-bound one at a time: a 4-6 us dispatch for 0.5-3 us of memory traffic) with four in flight on the context's
+            # streams: independent slices of a mip chain or an array
+            try:
+                VP32 = ctypes.c_void_p * 32
+                pi32 = VP32(*[t.data_ptr() for t in d_idx])
+                for name, rgba_, outl, bpb in (("etc1s_to_etc1", 0, d_o8, 12), ("etc1s_to_rgba32", 1, d_o64, 68)):
+                    po32 = VP32(*[t.data_ptr() for t in outl])
+
+                    def ewin(lead_, n_, tail_):
+                        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+                        check(env, lib.bu_time_etc1s_launches_streams_window(ctx.handle, rgba_, pi32, po32, 32, 0, 512, 512, ctypes.c_void_p(pe_), 4096, ctypes.c_void_p(ps_), 8192,
+                                                                             lead_, n_, tail_, 4, ctypes.byref(ev), ctypes.byref(host)), "bu_time_etc1s_launches_streams_window")
+                        return max(ev.value, host.value) / 1e3 / n_
+
+                    t0_ = time.perf_counter()
+                    while args.prewarm_ms > 0 and (time.perf_counter() - t0_) * 1e3 < args.prewarm_ms:
+                        ewin(0, 256, 0)
+                    t4_ = ewin(64, 256, 4)
+                    extra[name]["in_flight_4"] = {"us_per_launch": round(t4_ * 1e6, 3), "gb_s": round(bpb * nbl / t4_ / 1e9, 1), "mblocks_s": round(nbl / t4_ / 1e6, 1),
+                                                  "frac_of_hbm_peak": round(bpb * nbl / t4_ / 1e9 / HBM_PEAK_GBS, 4)}
+            except Exception as e:
+                extra["etc1s_in_flight_error"] = repr(e)
             del d_idx, d_o8, d_o64
             # the same kernels on a large slice (2^22 blocks, 2048 x 2048 blocks): the codebooks are staged in LDS from 2^19 blocks up
             nbl2 = 1 << 22

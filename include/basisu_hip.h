@@ -389,6 +389,12 @@ bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target targe
                                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,
                                                 int lead, int launches, int tail, int n_streams, uint64_t* d_status,
                                                 float* out_event_ms, float* out_host_ms, float* out_fill_drain_ms, int* out_late);
+/* the same window over the ETC1S codebook-lookup kernels (parity unpinned): launch i decodes index array d_idx[(first_buffer + i) % n_buffers]
+ * (nbx x nby blocks) against one pair of device codebooks into d_out[...]; rgba = 0: ETC1 blocks, 1: the RGBA8 image (no alpha slice) */
+bu_status bu_time_etc1s_launches_streams_window(bu_context* ctx, int rgba, const uint32_t* const* d_idx, void* const* d_out, size_t n_buffers,
+                                                size_t first_buffer, size_t nbx, size_t nby, const uint32_t* d_endpoints, uint32_t n_endpoints,
+                                                const void* d_selectors, uint32_t n_selectors, int lead, int launches, int tail, int n_streams,
+                                                float* out_event_ms, float* out_host_ms);
 /* The reference's micro-benchmark shape (benches/benchmark.rs:66-98): `reps` passes over `n_blocks` blocks, one per-block API
  * call per block (RGBA32: bu_unpack_uastc_block_to_rgba), host steady clock around the loop; nanoseconds per call. */
 bu_status bu_time_block_api(bu_context* ctx, bu_target target, const uint8_t* blocks, size_t n_blocks, int reps, uint8_t* out,
