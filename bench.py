@@ -287,7 +287,7 @@ def self_launch(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     if dry:
-        print(json.dumps({"self_launch": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"],
+        print(json.dumps({"self_launch": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"], "GPU_MAX_HW_QUEUES": env.get("GPU_MAX_HW_QUEUES"),
                           "parent_initialised_cuda": bool(torch.cuda.is_initialized())}))
         raise SystemExit(0)
     r = subprocess.run(cmd, env=env)

@@ -172,6 +172,7 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
 
     env = dict(os.environ, BENCH_SELF_LAUNCH_DRYRUN="1")
     env.pop("WORLD_SIZE", None)
+    env.pop("GPU_MAX_HW_QUEUES", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "3", "--config", "array512"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -182,6 +183,9 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     assert cmd[-8:] == ["--gpus", "8", "--steps", "7", "--warmup", "3", "--config", "array512"] and cmd[-9].endswith("bench.py")
     assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") not in (None, "0")
     assert d["parent_initialised_cuda"] is False  # the parent only counted devices: nothing that a child could not re-do
+    # the ranks inherit one hardware queue per stream from the launcher's environment (set before torch is imported: the HIP runtime
+    # reads it when it initialises; four launches in flight need four queues of their own)
+    assert d["GPU_MAX_HW_QUEUES"] == "8"
 
 
 def test_bench_live_traffic_falls_back_without_a_gpu():
