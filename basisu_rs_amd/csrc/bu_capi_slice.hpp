@@ -176,7 +176,7 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
     if (target == BU_TARGET_RGBA32 && blocks_per_row == 0) return BU_ERR_ARGUMENT;
     // the kernels store pixel rows 4*by+1..3 at the full image pitch: a ragged last block row would land past 64*n_blocks bytes
     if (target == BU_TARGET_RGBA32 && n_blocks % blocks_per_row != 0) return BU_ERR_ARGUMENT;
-    return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream));
+    return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream), 0, -1);
 }
 
 bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
@@ -216,7 +216,7 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
         runs.push_back(Run{in, out, n_blocks[i], base});
     }
     if (runs.empty()) return BU_OK;
-    if (runs.size() == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s);
+    if (runs.size() == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s, 0, -1);
     // several runs at unrelated addresses: ONE launch per BU_MULTI_RUNS runs, the run table in the kernel arguments (kernel layout
     // MULTI).  Launching the runs one by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices
     // of 65 536 blocks: 290 us on one stream, 230-260 us on 2-8, profiles/r03_small_slices_streams_vs_one_launch.txt).
@@ -236,7 +236,7 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
             n_tiles += t;
         }
         if (k <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
-            bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s);
+            bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s, 0, -1);
             if (st) return st;
             r0 += 1;
             continue;

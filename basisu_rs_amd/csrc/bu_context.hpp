@@ -244,9 +244,12 @@ void bu_launch_sorted_rgba(const BuPiece& p, unsigned cu_count, int policy, unsi
     else bu_go<BU_TGT_RGBA, BuShape<512, 2, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
 }
 
-// grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups
+// grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups.
+// policy = BU_POLICY_* of this launch, or -1 for the context's (bu_context_set_launch_policy): only the device-pointer slice entry
+// points pass -1 -- the host-pointer and whole-file entry points issue their launches one after another on one stream, for which the
+// exclusive shapes are the right ones whatever the context says.
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
-                          uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0)
+                          uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0, int policy = BU_POLICY_EXCLUSIVE)
 {
     if (n_blocks == 0) return BU_OK;
     const unsigned grid = bu_grid_for(n_blocks, ctx->cu_count);
@@ -258,7 +261,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         size_t piece = (size_t)1 << 26;
         if (target == BU_TARGET_RGBA32) piece = bpr <= piece ? (piece / bpr) * bpr : bpr;
         const size_t obytes = bu_target_block_bytes(target);
-        const int policy = ctx->launch_policy.load(std::memory_order_relaxed);
+        if (policy < 0) policy = ctx->launch_policy.load(std::memory_order_relaxed);
         constexpr size_t RW = BU_RECT_W;
         BuPiece p;
         p.status = st;

@@ -79,7 +79,9 @@ size_t bu_target_block_bytes(bu_target target);
 
 /* ---- launch policy -------------------------------------------------------------------------------
  * How much of the chip ONE large launch of the slice-level transcode takes (a property of the context, read by
- * bu_uastc_transcode_device / _batch_device and everything built on them at the moment they enqueue; results never depend on it).
+ * bu_uastc_transcode_device / _batch_device -- the entry points that take the caller's stream -- at the moment they enqueue; the
+ * host-pointer and whole-file entry points issue their launches one after another and always use the exclusive shapes; results never
+ * depend on it).
  * The reference's slice loop (uastc.rs:112-165, basis.rs:246-257) runs slices one after another; on the GPU a launch over one
  * 4096 x 4096 slice spends its first ~3.4 us waiting for HBM with the ALUs idle and the rest computing with HBM idle, and launches
  * queued on ONE stream never overlap (the queue drains between two dispatches).  A caller with several independent slices gets
