@@ -1454,10 +1454,12 @@ def run_atlas4096(env):
             line["roofline"]["period_ns_by_rocprofv3"] = tr3["period_avg_ns"]
             line["roofline"]["frac_by_rocprofv3_period"] = round(BYTES_PER_BLOCK * N_BLOCKS / tr3["end_to_end_period_avg_ns"] / HBM_PEAK_GBS, 4)
             line["roofline"]["rocprofv3_note"] = ("the trace pass is the evidence for the OVERLAP (dispatch spans of several periods, dispatches starting before their predecessor ends, one "
-                                                  "hardware queue per stream); its period is NOT the unprofiled one and cannot be: under rocprofv3 --kernel-trace an empty kernel completes "
-                                                  "once per 6.3-6.6 us and a 5 us whole-chip kernel once per 7.8-8.1 us whatever the number of streams (plain: 1.5 / 4.85 us; "
-                                                  "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt) -- the profiler's own cost per dispatch exceeds the period being measured.  The "
-                                                  "HIP events and the host clock of this unprofiled run agree (timed_region.event_ms / host_ms); --steps 512 repeats it on a 3 ms window")
+                                                  "hardware queue per stream).  Its period is that of a PROFILED pipeline, which runs slower: rocprofv3 --kernel-trace adds host-side work to "
+                                                  "every dispatch (an empty kernel completes once per 6.3-6.6 us under it, a 5 us whole-chip kernel once per 7.8-8.1 us, plain 1.5 / 4.85 us: "
+                                                  "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt), so the enqueue rate sets the pace.  Within one profiled run the profiler's "
+                                                  "completion period equals that run's HIP-event period (7.41 against 7.418 us: profiles/r05_v4_rocprofv3_headline_trace_summary.txt; config 5 with "
+                                                  "2^23-block launches, where the profiler's cost does not matter: 172.8 against 175.3 us per array) -- the clocks agree, the profiler perturbs.  "
+                                                  "This unprofiled run: HIP events and the host clock agree (timed_region.event_ms / host_ms); --steps 512 repeats it on a 3 ms window")
     if env.live_traffic[0] is not None:
         line["roofline"]["traffic"] = env.live_traffic[0]
         line["roofline"]["traffic_source"] = env.live_traffic[1]

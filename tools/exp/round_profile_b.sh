@@ -8,7 +8,14 @@ mkdir -p $O
 rm -rf $O/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --headline-only --steps 512 --warmup 64 > $O/bench_profiled.json 2> $O/bench_profiled.err
 find $O/prof -name "*kernel_stats*.csv" | head -1 | while read f; do cp "$f" $O/rocprofv3_kernel_stats.csv; done
+# what the same trace says about the pipeline: span of a dispatch, completion period UNDER THE PROFILER (its own cost per dispatch is 6-8 us:
+# profiles/r05_rocprofv3_dispatch_floor_*), dispatches running, hardware queues
+find $O/prof -name "*kernel_trace.csv" | head -1 | while read f; do python3 tools/exp/trace_periods.py "$f" "sorted_kernel<1, 256" 1 > $O/rocprofv3_headline_trace_summary.txt; done
 rm -rf $O/prof
+# BASELINE config 5 with four launches in flight: at 2^23 blocks per launch the profiler's cost is small beside the period, its clock and the events agree
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof5 -- python3 bench.py --config array512 --steps 200 --warmup 3 > $O/bench_array512_profiled.json 2> $O/bench_array512_profiled.err
+find $O/prof5 -name "*kernel_trace.csv" | head -1 | while read f; do python3 tools/exp/trace_periods.py "$f" sorted_kernel 4 > $O/rocprofv3_array512_four_launches_in_flight.txt; done
+rm -rf $O/prof5
 head -5 $O/rocprofv3_kernel_stats.csv | cut -c1-200
 timeout 1500 bash tools/gpu_pmc.sh > $O/gpu_pmc.log 2>&1
 cp gpurun_out/pmc/kernel_stats.csv $O/rocprofv3_kernel_stats_all_kernels.csv
