@@ -1453,6 +1453,10 @@ def run_atlas4096(env):
             line["roofline"]["kernel_span_ns"] = tr3["kernel_avg_ns"]
             line["roofline"]["period_ns_by_rocprofv3"] = tr3["period_avg_ns"]
             line["roofline"]["frac_by_rocprofv3_period"] = round(BYTES_PER_BLOCK * N_BLOCKS / tr3["end_to_end_period_avg_ns"] / HBM_PEAK_GBS, 4)
+            if tr3.get("hardware_queues_used", args.in_flight) < args.in_flight:
+                line["roofline"]["warning"] = ("the trace pass saw %d hardware queue(s) for %d streams: streams that share a queue run their launches one after another -- "
+                                               "GPU_MAX_HW_QUEUES was %r when HIP initialised (INTEGRATION.md section 4e)" % (
+                                                   tr3["hardware_queues_used"], args.in_flight, os.environ.get("GPU_MAX_HW_QUEUES")))
             line["roofline"]["rocprofv3_note"] = ("the trace pass is the evidence for the OVERLAP (dispatch spans of several periods, dispatches starting before their predecessor ends, one "
                                                   "hardware queue per stream).  Its period is that of a PROFILED pipeline, which runs slower: rocprofv3 --kernel-trace adds host-side work to "
                                                   "every dispatch (an empty kernel completes once per 6.3-6.6 us under it, a 5 us whole-chip kernel once per 7.8-8.1 us, plain 1.5 / 4.85 us: "
