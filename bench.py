@@ -312,6 +312,9 @@ def main():
     ap.add_argument("--policy", choices=("shared", "exclusive"), default=None,
                     help="launch policy of the context (bu_context_set_launch_policy): shared = a launch keeps at most half of every CU so that launches "
                          "of different streams run side by side (default when --in-flight > 1), exclusive = a launch fills the chip by itself")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (lead launches, exactly K timed launches, tail) is run this many times back to back and the MEDIAN window is "
+                         "reported; every window is listed in config.timed_region.windows_us_per_step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the verified, timed headline launches (no context rows, no CPU leg): the command profiled with rocprofv3, "
@@ -860,19 +863,30 @@ def run_atlas4096(env):
     # the K steps.  (A synchronize() directly in front of K = 20 launches put ~35 us of pipeline refill into a 200 us
     # window: round-2 driver run 11.47 us per launch against 9.77 us in the long pre-warm loop of the same process.)
     busy_barrier(env, warm_async, 400)  # ~4 ms of work
-    lead = max(256, 2 * args.steps)
-    ev_ms, host_ms, late = run_window(lead, args.steps)
+    # The timed region is run `--repeats` times back to back (default 5: lead launches, EXACTLY K timed launches, tail launches each) and the MEDIAN
+    # window is the one reported -- every window's figure is in config.timed_region.windows_us_per_step.  One window of K = 20 launches lasts 0.12 ms: a
+    # single clock transition or a stall of 30 us inside it moves the per-step figure by a quarter (seen once in ten runs: 7.2 where the others read
+    # 5.6-6.0, with the strict bracket of the same run at 6.6), and a median of five does not care.  EVERY window sits behind `lead` = max(2048, 2K)
+    # untimed launches (12 ms of the same work): the few tens of microseconds the chip idles between two windows cost it more than a millisecond of
+    # slower launches (windows behind only 64 lead launches read 5.9-8.9 us per step where the first one read 5.8).
+    lead = max(2048, 2 * args.steps)
+    wins = []
+    for r_ in range(max(1, args.repeats)):
+        ev_ms_, host_ms_, late_ = run_window(lead, args.steps)
+        wins.append((max(host_ms_, ev_ms_), ev_ms_, host_ms_, late_))
     torch.cuda.synchronize()
-    # this rank's K steps: never less than what the GPU's own events say (a host that was still enqueueing when event 0
-    # fired starts its bracket late); the MAX over ranks below is the job's time
-    dt = max(host_ms, ev_ms) / 1e3
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    t = torch.tensor([dt, ev_ms / 1e3], dtype=torch.float64, device=dev)
+    # per window: this rank's K steps are never less than what the GPU's own events say; the MAX over ranks is the job's time for that window
+    t = torch.tensor([w[0] / 1e3 for w in wins] + [w[1] / 1e3 for w in wins], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max, ev_max = float(t[0]), float(t[1])
+    R_ = len(wins)
+    dts, evs = [float(x) for x in t[:R_]], [float(x) for x in t[R_:]]
+    m_ = sorted(range(R_), key=lambda i: dts[i])[R_ // 2]  # the median window (of the job, i.e. of the slowest rank per window)
+    dt_max, ev_max = dts[m_], evs[m_]
+    ev_ms, host_ms, late = wins[m_][1], wins[m_][2], wins[m_][3]
     ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
 
     total_blocks = world * args.steps * N_BLOCKS
@@ -1418,6 +1432,7 @@ def run_atlas4096(env):
                    "prewarm": {"launches": prewarm_launches, "ms": args.prewarm_ms,
                                "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"},
                    "timed_region": {"lead_launches": lead, "host_ms": round(host_ms, 6), "event_ms": round(ev_ms, 6), "host_started_late": bool(late),
+                                    "repeats": len(wins), "window_reported": "median", "windows_us_per_step": [round(x / args.steps * 1e6, 3) for x in dts],
                                     "tail_launches": args.in_flight if args.in_flight > 1 else 0,
                                     "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, a start "
                                             "event per stream behind its last lead launch, K timed launches, an end event per stream behind its last timed launch, one untimed "
