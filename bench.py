@@ -1479,8 +1479,8 @@ def run_atlas4096(env):
                                                   "hardware queue per stream).  Its period is that of a PROFILED pipeline, which runs slower: rocprofv3 --kernel-trace adds host-side work to "
                                                   "every dispatch (an empty kernel completes once per 6.3-6.6 us under it, a 5 us whole-chip kernel once per 7.8-8.1 us, plain 1.5 / 4.85 us: "
                                                   "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt), so the enqueue rate sets the pace.  Within one profiled run the profiler's "
-                                                  "completion period equals that run's HIP-event period (7.41 against 7.418 us: profiles/r05_v4_rocprofv3_headline_trace_summary.txt; config 5 with "
-                                                  "2^23-block launches, where the profiler's cost does not matter: 172.8 against 175.3 us per array) -- the clocks agree, the profiler perturbs.  "
+                                                  "completion period equals that run's HIP-event period (7.69 against 7.74 us: profiles/r05_v5_rocprofv3_headline_trace_summary.txt; config 5 with "
+                                                  "2^23-block launches, where the profiler's cost does not matter: 174.6 against 175.1 us per array) -- the clocks agree, the profiler perturbs.  "
                                                   "This unprofiled run: HIP events and the host clock agree (timed_region.event_ms / host_ms); --steps 512 repeats it on a 3 ms window")
     if env.live_traffic[0] is not None:
         line["roofline"]["traffic"] = env.live_traffic[0]
