@@ -178,17 +178,41 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
     for (int i = 1; i < n_streams; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
     bool used[8] = {false, false, false, false, false, false, false, false};
     int last_timed[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // the number of each stream's last timed launch
+    int first_timed[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (int i = lead + launches - 1; i >= lead; i--) first_timed[i % n_streams] = i;
     for (int i = lead; i < lead + launches; i++) last_timed[i % n_streams] = i;
-    for (int i = 0; i < lead + launches + tail; i++) {
+    for (int i = 0; i < n_streams; i++) used[i] = first_timed[i] >= 0;
+    const auto enqueue = [&](int i) -> bu_status {  // launch number i with the events that belong in front of and behind it
         const int si = i % n_streams;
         hipStream_t s = ctx->extra_streams[si];
-        if (i >= lead && i < lead + launches && !used[si]) {
-            BU_HIP(ctx, hipEventRecord(ctx->ev_start[si], s));
-            used[si] = true;
-        }
-        bu_status st = launch(i, s);
+        if (i == first_timed[si]) BU_HIP(ctx, hipEventRecord(ctx->ev_start[si], s));
+        const bu_status st = launch(i, s);
         if (st) return st;
         if (i == last_timed[si]) BU_HIP(ctx, hipEventRecord(ctx->ev_end[si], s));
+        return BU_OK;
+    };
+    const int total = lead + launches + tail;
+    if (ctx->time_enqueue_threads.load(std::memory_order_relaxed) && n_streams > 1) {
+        // one host thread per stream (bu_time_set_enqueue_threads): the order inside every stream is the one below, the order between
+        // streams is whatever the threads make it -- the way a caller with one thread per stream drives the context
+        bu_status sts[8] = {BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK};
+        std::vector<std::thread> th;
+        for (int si = 0; si < n_streams; si++)
+            th.emplace_back([&, si] {
+                if (hipSetDevice(ctx->device) != hipSuccess) {
+                    sts[si] = BU_ERR_HIP;
+                    return;
+                }
+                for (int i = si; i < total && sts[si] == BU_OK; i += n_streams) sts[si] = enqueue(i);
+            });
+        for (auto& t : th) t.join();
+        for (int si = 0; si < n_streams; si++)
+            if (sts[si]) return sts[si];
+    } else {
+        for (int i = 0; i < total; i++) {
+            const bu_status st = enqueue(i);
+            if (st) return st;
+        }
     }
     // host bracket: from every start event seen complete to every end event seen complete
     std::chrono::steady_clock::time_point t0, t1, t;
@@ -232,6 +256,16 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
 }
 
 extern "C" {
+
+// on != 0: the streams windows below enqueue from one host thread per stream instead of from the calling thread alone.  The GPU side
+// is the same; what changes is how much host time one enqueue may take before the host, not the chip, sets the pace -- under
+// rocprofv3 --kernel-trace an enqueue costs 6-8 us of host time (profiles/r05_rocprofv3_dispatch_floor_*), more than the period.
+bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on)
+{
+    if (!ctx) return BU_ERR_ARGUMENT;
+    ctx->time_enqueue_threads.store(on ? 1 : 0, std::memory_order_relaxed);
+    return BU_OK;
+}
 
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out, size_t n_buffers,
                                                 size_t first_buffer, size_t n_blocks, size_t blocks_per_row, int lead, int launches, int tail,

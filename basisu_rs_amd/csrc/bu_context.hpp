@@ -26,11 +26,13 @@ struct bu_context {
     hipEvent_t ev_end[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::atomic<int> launch_policy{0};  // BU_POLICY_*: how much of a CU one large launch of the mode-sorted kernel takes (bu_context_set_launch_policy)
+    std::atomic<int> time_enqueue_threads{0};  // bu_time_set_enqueue_threads: the streams windows enqueue from one host thread per stream
     std::atomic<bool> block_api_on_device{false};  // per-block API: host build of the block code (default) or a 1-block launch
     size_t etc1s_lds_limit = 0;  // what the device reports a workgroup may use, less a margin (bu_context_create)
     std::atomic<size_t> etc1s_lds_state[2] = {{0}, {0}};  // bu_etc1s_staged_kernel<false / true>: 0 not asked, 1 refused, else dynamic LDS bytes granted
     std::mutex stream_lock;  // creation of extra_streams (bu_ctx_streams)
     std::mutex lock;  // host-pointer entry points share the staging buffers
+    std::mutex err_lock;  // `err` is written by whichever thread fails (device-pointer entry points run without `lock`)
     char err[256] = {0};
 };
 
@@ -38,7 +40,10 @@ namespace {
 
 bu_status bu_fail(bu_context* ctx, hipError_t e, const char* what)
 {
-    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->err_lock);
+        snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+    }
     return BU_ERR_HIP;
 }
 #define BU_HIP(ctx, call)                                       \

@@ -107,6 +107,7 @@ def pmc_child():
 
     ctx = Context(0)
     ctx.set_launch_policy(os.environ.get("BENCH_PMC_POLICY", "shared") == "shared")
+    _lib.load().bu_time_set_enqueue_threads(ctx.handle, int(os.environ.get("BENCH_PMC_ENQ_THREADS", "0")))
     g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
     dev = torch.device("cuda", 0)
     gu = torch.from_numpy(g["uastc"]).to(dev)
@@ -158,7 +159,7 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
     then WRITE_SIZE: separate passes, nothing but --kernel-trace beside --pmc, the program directly after `--`) over
     `bench.py --pmc-child`, run before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB; gfx950 reports half of
     a wide coalesced read stream (MI355X_MICROARCH.md, HBM section): bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.
-    A third child pass (--kernel-trace only, no counters, 64 rounds over the 24 atlases, `in_flight` launches in flight) gives what rocprofv3 says about the same
+    A third child pass (--kernel-trace only, no counters, 400 rounds over the 24 atlases, `in_flight` launches in flight) gives what rocprofv3 says about the same
     launches unperturbed by counters: the per-kernel average duration, the launch-to-launch period of the back-to-back launches and
     how many launches started before their predecessor had ended.
     Returns (bytes, note, trace) or (None, reason, trace); trace is a dict or None."""
@@ -182,14 +183,16 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
         try:
             out = os.path.join(work, "trace")
             cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
-            rc, err = _run_child(cmd, dict(env, BENCH_PMC_ROUNDS="64"), timeout_s)
+            # (one enqueue thread per stream in this pass: under the profiler one enqueue costs 6-8 us of host time, more than the period, and a
+            #  single thread would set the pace -- 7.5-8.1 us per completion against 6.3-6.4 with a thread per stream, profiles/r05_enqueue_threads_*)
+            rc, err = _run_child(cmd, dict(env, BENCH_PMC_ROUNDS="400", BENCH_PMC_ENQ_THREADS="1" if in_flight > 1 else "0"), timeout_s)
             rows = []
             for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if is_bc7(row["Kernel_Name"]):
                         rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row.get("Queue_Id", "")))
             rows.sort()
-            rows = rows[len(rows) // 4:]  # the first launches start from idle clocks
+            rows = rows[len(rows) // 2:]  # the clocks take 25-40 ms of load to settle (9 600 launches: ~60 ms)
             if rc == 0 and len(rows) >= 64:
                 dur = [e - s_ for s_, e, _ in rows]
                 per = [rows[i + 1][0] - rows[i][0] for i in range(len(rows) - 1)]
@@ -198,15 +201,31 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
                 eper = [ends[i + 1] - ends[i] for i in range(len(ends) - 1)]
                 eper = [x for x in eper if x < 10 * (sum(dur) / len(dur))]
                 wall = max(e for _, e, _ in rows) - rows[0][0]
+                # steady stretches: runs of >= 64 consecutive completions without a pause (gap < 3 x median) -- the host threads of a profiled run stall
+                # now and then for tens of microseconds, which is no property of the pipeline
+                gaps = [ends[i + 1] - ends[i] for i in range(len(ends) - 1)]
+                med = sorted(gaps)[len(gaps) // 2]
+                runs, cur = [], []
+                for x in gaps + [10 ** 12]:
+                    if x < 3 * med:
+                        cur.append(x)
+                    else:
+                        if len(cur) >= 64:
+                            runs.append(cur)
+                        cur = []
+                steady_n = sum(len(r) for r in runs)
+                steady_ns = sum(sum(r) for r in runs) / steady_n if steady_n else None
                 trace = {"launches": len(rows), "launches_in_flight_requested": in_flight, "launch_policy": policy,
                          "kernel_avg_ns": round(sum(dur) / len(dur), 1), "kernel_min_ns": min(dur),
                          "period_avg_ns": round(sum(per) / max(1, len(per)), 1), "end_to_end_period_avg_ns": round(sum(eper) / max(1, len(eper)), 1),
                          "starts_before_previous_end": sum(1 for i in range(len(rows) - 1) if rows[i + 1][0] < rows[i][1]),
                          "avg_kernels_running": round(sum(dur) / max(1, wall), 2), "hardware_queues_used": len(set(q for _, _, q in rows)),
-                         "source": "child rocprofv3 --kernel-trace pass (no counters) over `bench.py --pmc-child`: 64 rounds x 24 cold atlases enqueued up front by "
-                                   "bu_time_uastc_launches_streams_window on %d context stream(s), the last three quarters counted; kernel_avg = span of one dispatch "
+                         "end_to_end_period_median_ns": float(np.median(eper)) if eper else None, "enqueue_threads": in_flight if in_flight > 1 else 1,
+                         "steady_period_ns": round(steady_ns, 1) if steady_ns else None, "steady_completions": steady_n,
+                         "source": "child rocprofv3 --kernel-trace pass (no counters) over `bench.py --pmc-child`: 400 rounds x 24 cold atlases enqueued up front by "
+                                   "bu_time_uastc_launches_streams_window on %d context stream(s), one enqueue thread per stream, the last half counted; kernel_avg = span of one dispatch "
                                    "(with several launches in flight a span is about that many periods); period = start-to-start of consecutive launches "
-                                   "(end_to_end: end-to-end); avg_kernels_running = sum of spans / wall time" % in_flight}
+                                   "(end_to_end: end-to-end; steady_period: end-to-end over the stretches of >= 64 completions without a host-side pause, i.e. no gap above 3 x the median); avg_kernels_running = sum of spans / wall time" % in_flight}
         except Exception as e:  # the trace pass is a cross-check: without it the counter passes still run
             trace = {"error": "%s: %s" % (type(e).__name__, e)}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -309,6 +328,10 @@ def main():
                     help="launches in flight: step i is issued on context stream i %% IN_FLIGHT (1..8).  One launch over a 4096^2 atlas waits ~3.4 us for "
                          "HBM with the ALUs idle and then computes with HBM idle, and launches on ONE stream never overlap; independent atlases on several "
                          "streams do.  1 = one launch at a time (the round 1-4 headline; always reported under extra.one_launch_at_a_time)")
+    ap.add_argument("--enqueue-threads", type=int, choices=(0, 1), default=0,
+                    help="1: the native timed loop enqueues from one host thread per stream (bu_time_set_enqueue_threads) instead of from one thread. "
+                         "The unprofiled period is the same either way (the host is far ahead of the chip); under rocprofv3 --kernel-trace one enqueue "
+                         "costs 6-8 us of host time, more than the period, and one thread then paces the run")
     ap.add_argument("--policy", choices=("shared", "exclusive"), default=None,
                     help="launch policy of the context (bu_context_set_launch_policy): shared = a launch keeps at most half of every CU so that launches "
                          "of different streams run side by side (default when --in-flight > 1), exclusive = a launch fills the chip by itself")
@@ -616,6 +639,7 @@ def run_array512(env):
     # roofline; four launches of 2^23 blocks in flight 167 us = 0.80).  P = 1 (ragged splits, --in-flight 1): one launch over the range.
     P = args.in_flight if (args.in_flight > 1 and (hi - lo) % args.in_flight == 0) else 1
     ctx.set_launch_policy(P > 1 and args.policy == "shared")
+    lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
     npiece = nb // P
     PtrArr = ctypes.c_void_p * (nrot * P)
     in_ptrs = PtrArr(*[t.data_ptr() + q * npiece * 16 for t in ins for q in range(P)])
@@ -797,6 +821,11 @@ def run_atlas4096(env):
             raise RuntimeError("bu_time_uastc_launches_streams_window: " + lib.bu_status_string(st).decode())
         rot[0] += lead + launches + tail
         fill_drain[0] = fd.value
+        if args.enqueue_threads and nfl > 1:
+            # one enqueue thread per stream: the streams are not fed in step, so "latest start event to latest end event" no longer brackets exactly
+            # `launches` completions (under rocprofv3 one stream runs hundreds of launches ahead of another).  The strict bracket -- earliest start to
+            # latest end, every timed launch inside from first to last instruction -- holds whatever the order: the figure of this mode, K + S - 1 periods
+            return fd.value, fd.value, late.value
         return ev.value, host.value, late.value
 
     def srow(launches, in_flight, shared, target=_lib.BC7, inp=in_ptrs, outp=out_ptrs, nb=nbuf, lead=64):
@@ -832,6 +861,7 @@ def run_atlas4096(env):
     # ---- correctness gate before any timing: full-size, self-verifying, through the headline's own path (policy, streams) ----
     policy_now = [args.policy == "shared"]  # the context's launch policy outside srow()
     ctx.set_launch_policy(policy_now[0])
+    lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
     ctx.status_word_reset(status)
     torch.cuda.synchronize()  # (the context's streams do not wait for torch's)
     run_window(0, nbuf)       # one launch per atlas, round-robin over the streams
@@ -1469,8 +1499,8 @@ def run_atlas4096(env):
             # two clocks, both reported: `frac` above = bytes / (event time of the K timed launches / K); the child trace pass of this run gives
             # the span of one dispatch and the start-to-start period of the same launches under the profiler
             line["roofline"]["kernel_span_ns"] = tr3["kernel_avg_ns"]
-            line["roofline"]["period_ns_by_rocprofv3"] = tr3["period_avg_ns"]
-            line["roofline"]["frac_by_rocprofv3_period"] = round(BYTES_PER_BLOCK * N_BLOCKS / tr3["end_to_end_period_avg_ns"] / HBM_PEAK_GBS, 4)
+            line["roofline"]["period_ns_by_rocprofv3"] = tr3.get("steady_period_ns") or tr3["period_avg_ns"]
+            line["roofline"]["frac_by_rocprofv3_period"] = round(BYTES_PER_BLOCK * N_BLOCKS / (tr3.get("steady_period_ns") or tr3["end_to_end_period_avg_ns"]) / HBM_PEAK_GBS, 4)
             if tr3.get("hardware_queues_used", args.in_flight) < args.in_flight:
                 line["roofline"]["warning"] = ("the trace pass saw %d hardware queue(s) for %d streams: streams that share a queue run their launches one after another -- "
                                                "GPU_MAX_HW_QUEUES was %r when HIP initialised (INTEGRATION.md section 4e)" % (
@@ -1478,7 +1508,9 @@ def run_atlas4096(env):
             line["roofline"]["rocprofv3_note"] = ("the trace pass is the evidence for the OVERLAP (dispatch spans of several periods, dispatches starting before their predecessor ends, one "
                                                   "hardware queue per stream).  Its period is that of a PROFILED pipeline, which runs slower: rocprofv3 --kernel-trace adds host-side work to "
                                                   "every dispatch (an empty kernel completes once per 6.3-6.6 us under it, a 5 us whole-chip kernel once per 7.8-8.1 us, plain 1.5 / 4.85 us: "
-                                                  "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt), so the enqueue rate sets the pace.  Within one profiled run the profiler's "
+                                                  "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt), so ONE enqueueing thread sets the pace at 7.5-8.1 us per completion; the trace pass "
+                                                  "therefore enqueues from one host thread per stream (bu_time_set_enqueue_threads) and reads 6.3-6.4 us per completion over its steady stretches "
+                                                  "(steady_period_ns; frac_by_rocprofv3_period is computed from it) -- still a profiled pipeline, 10-13 % slower than the unprofiled one.  Fed by one thread, the profiler's "
                                                   "completion period equals that run's HIP-event period (7.69 against 7.74 us: profiles/r05_v5_rocprofv3_headline_trace_summary.txt; config 5 with "
                                                   "2^23-block launches, where the profiler's cost does not matter: 174.6 against 175.1 us per array) -- the clocks agree, the profiler perturbs.  "
                                                   "This unprofiled run: HIP events and the host clock agree (timed_region.event_ms / host_ms); --steps 512 repeats it on a 3 ms window")

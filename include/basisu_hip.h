@@ -386,6 +386,10 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
  * launch to last instruction of the last one (launches + n_streams - 1 periods in a full pipeline; with lead = tail = 0 the whole run
  * from an idle chip to an idle chip).  *out_host_ms = host steady clock from "every start event seen complete" to "every end event seen complete"; *out_late
  * (optional) = 1 if the first start event had already completed when the host finished enqueueing. */
+/* on != 0: the two streams windows below enqueue from one host thread per stream (the order inside a stream unchanged, between streams
+ * free) instead of from the calling thread alone -- how a caller with a thread per stream drives the context, and what keeps the host
+ * from setting the pace when one enqueue costs more host time than a period (under rocprofv3 --kernel-trace: 6-8 us). */
+bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on);
 #define BU_TIME_COPY_CEILING 100 /* as `target` of the call below: the uint4 -> uint4 copy kernel (bu_copy_ceiling_device) in place of a transcode */
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,

@@ -149,6 +149,42 @@ def test_streams_window_runs_every_launch_on_every_stream(golden, shared, stream
     ctx.close()
 
 
+def test_streams_window_with_an_enqueue_thread_per_stream(golden):
+    """bu_time_set_enqueue_threads: the same window fed by one host thread per stream -- every launch still runs (all rotated outputs hold the
+    known answers), the strict bracket (earliest start event to latest end event: valid whatever the order between streams) is in range"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    ctx.set_launch_policy(True)
+    lib = ctx._lib
+    assert lib.bu_time_set_enqueue_threads(None, 1) == _lib.ERR_ARGUMENT
+    assert lib.bu_time_set_enqueue_threads(ctx.handle, 1) == 0
+    n, nbuf, streams = 1 << 20, 12, 4
+    vp = ctypes.c_void_p
+    idxs = [synth.gold_indices(n, seed=1900 + k) for k in range(nbuf)]
+    ins = [torch.from_numpy(golden["uastc"][i]).cuda() for i in idxs]
+    outs = [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    A = vp * nbuf
+    ev, host, fd = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+    lead, launches, tail = 6, 41, 4
+    st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 5, n, 1024,
+                                                   lead, launches, tail, streams, vp(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(fd), None)
+    assert st == 0, lib.bu_status_string(st)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(golden["bc7"]).cuda()
+    for k in range(nbuf):
+        assert torch.equal(outs[k], want[torch.from_numpy(idxs[k]).cuda()]), k
+    ctx.status_word_check(int(status.item()))
+    assert 3.0 < fd.value * 1e3 / launches < 60.0, fd.value
+    assert lib.bu_time_set_enqueue_threads(ctx.handle, 0) == 0
+    ctx.close()
+
+
 def _batch_args(ins, outs, sizes):
     n_s = len(sizes)
     VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s

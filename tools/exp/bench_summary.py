@@ -5,7 +5,7 @@ for f in sys.argv[1:]:
     print("==", f)
     print("value %.0f Mblocks/s  ms_per_step %.6f  frac %.4f  drain-incl %.4f  first-start-to-last-end/K %s ns" % (
         d["value"], d["ms_per_step"], r["frac"], r.get("frac_by_strict_bracket", 0), r.get("strict_bracket_ns_per_step")))
-    print("  span %s  period(rocprof) %s  frac(rocprof period) %s  traffic %s  host/event ms %s/%s late %s" % (
+    print("  span %s  period(rocprof, steady) %s  frac(rocprof period) %s  traffic %s  host/event ms %s/%s late %s" % (
         r.get("kernel_span_ns"), r.get("period_ns_by_rocprofv3"), r.get("frac_by_rocprofv3_period"), r.get("traffic"),
         d["config"]["timed_region"]["host_ms"], d["config"]["timed_region"]["event_ms"], d["config"]["timed_region"]["host_started_late"]))
     t = r.get("rocprofv3_this_run") or {}
