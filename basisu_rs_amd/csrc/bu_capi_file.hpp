@@ -198,7 +198,7 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
     const size_t per_img = p.alpha_pairs ? 2 : 1;
     std::vector<Job> jobs(n_img * per_img);
     const bool may_split = st_tables == BU_OK && lz.split_ok() && !getenv("BU_ETC1S_ONE_THREAD");
-    size_t tok_bytes = 0, n_split = 0;
+    size_t tok_bytes = 0;
     for (size_t k = 0; k < n_img; k++)
         for (size_t a = 0; a < per_img; a++) {
             const bu_slice_desc& s = p.slices[p.first_slice[k] + a];
@@ -210,7 +210,6 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             j.idx = h_idx + (a ? ain_off[k] : in_off[k]);
             if (may_split && j.nbx * j.nby >= BU_ETC1S_STREAM_MIN_BLOCKS) {
                 j.split = true;
-                n_split++;
                 tok_bytes += (j.nbx * j.nby * 6 + 127) & ~(size_t)63;
             }
         }
@@ -226,7 +225,6 @@ static bu_status bu_read_etc1s_streamed(bu_context* ctx, bu_read_target target, 
             if (!j.split) continue;
             if (!t) {  // (no memory for the tokens: the ordinary loop)
                 j.split = false;
-                n_split--;
                 continue;
             }
             const size_t nblk = j.nbx * j.nby;

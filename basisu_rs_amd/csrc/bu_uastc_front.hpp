@@ -308,7 +308,6 @@ BU_DEV uint32_t bu_perm(uint32_t a, uint32_t b, uint32_t sel)
 BU_DEV uint32_t bu_cvt_pk_i16(int32_t lo, int32_t hi)
 {
 #if defined(BU_GCN)
-    typedef short bu_s2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(lo, hi));
 #else
     const int32_t a = lo < -32768 ? -32768 : (lo > 32767 ? 32767 : lo), b = hi < -32768 ? -32768 : (hi > 32767 ? 32767 : hi);
