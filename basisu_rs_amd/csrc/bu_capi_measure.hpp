@@ -197,15 +197,25 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
         // streams is whatever the threads make it -- the way a caller with one thread per stream drives the context
         bu_status sts[8] = {BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK};
         std::vector<std::thread> th;
-        for (int si = 0; si < n_streams; si++)
-            th.emplace_back([&, si] {
-                if (hipSetDevice(ctx->device) != hipSuccess) {
-                    sts[si] = BU_ERR_HIP;
-                    return;
-                }
-                for (int i = si; i < total && sts[si] == BU_OK; i += n_streams) sts[si] = enqueue(i);
-            });
+        bool spawned = true;
+        for (int si = 0; si < n_streams && spawned; si++) {
+            try {
+                th.emplace_back([&, si] {
+                    if (hipSetDevice(ctx->device) != hipSuccess) {
+                        sts[si] = BU_ERR_HIP;
+                        return;
+                    }
+                    for (int i = si; i < total && sts[si] == BU_OK; i += n_streams) sts[si] = enqueue(i);
+                });
+            } catch (const std::exception&) {  // (no thread to be had: what is already enqueued is drained by `drain`)
+                spawned = false;
+            }
+        }
         for (auto& t : th) t.join();
+        if (!spawned) {
+            snprintf(ctx->err, sizeof(ctx->err), "bu_streams_window: could not start an enqueue thread");
+            return BU_ERR_HIP;
+        }
         for (int si = 0; si < n_streams; si++)
             if (sts[si]) return sts[si];
     } else {

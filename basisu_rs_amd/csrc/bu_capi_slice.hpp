@@ -320,8 +320,13 @@ bu_status bu_context_synchronize(bu_context* ctx)
     if (!ctx) return BU_ERR_ARGUMENT;
     BU_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->stream) BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (hipStream_t es : ctx->extra_streams)
-        if (es) BU_HIP(ctx, hipStreamSynchronize(es));
+    hipStream_t es[8];
+    {  // (another thread may be creating a stream through bu_context_stream)
+        std::lock_guard<std::mutex> g(ctx->stream_lock);
+        for (int i = 0; i < 8; i++) es[i] = ctx->extra_streams[i];
+    }
+    for (hipStream_t e : es)
+        if (e) BU_HIP(ctx, hipStreamSynchronize(e));
     return BU_OK;
 }
 
