@@ -243,7 +243,9 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
     t1 = t0;
     float first_start = 0, last_start = 0, last_end = 0;
     bool any = false;
+    ctx->win_streams = n_streams;
     for (int i = 0; i < n_streams; i++) {
+        ctx->win_start_ms[i] = ctx->win_end_ms[i] = -1.0f;
         if (!used[i]) continue;
         bu_status st = bu_spin_event(ctx, ctx->ev_end[i], &t);
         if (st) return st;
@@ -251,6 +253,8 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
         float ms_s = 0, ms_e = 0;
         BU_HIP(ctx, hipEventElapsedTime(&ms_s, ctx->ev0, ctx->ev_start[i]));
         BU_HIP(ctx, hipEventElapsedTime(&ms_e, ctx->ev0, ctx->ev_end[i]));
+        ctx->win_start_ms[i] = ms_s;
+        ctx->win_end_ms[i] = ms_e;
         if (!any || ms_s < first_start) first_start = ms_s;
         if (!any || ms_s > last_start) last_start = ms_s;
         if (!any || ms_e > last_end) last_end = ms_e;
@@ -270,6 +274,21 @@ extern "C" {
 // on != 0: the streams windows below enqueue from one host thread per stream instead of from the calling thread alone.  The GPU side
 // is the same; what changes is how much host time one enqueue may take before the host, not the chip, sets the pace -- under
 // rocprofv3 --kernel-trace an enqueue costs 6-8 us of host time (profiles/r05_rocprofv3_dispatch_floor_*), more than the period.
+// the per-stream events of the LAST streams window of this context, in ms from the head of that call: out_start_ms[i] = stream i's start
+// event (behind its last lead launch), out_end_ms[i] = its end event (behind its last timed launch), -1 for a stream without timed
+// launches; both arrays hold 8 floats.  Streams that run in step start and end within a few periods of each other; streams that share a
+// hardware queue with something else fall behind, and "latest start to latest end" then no longer brackets `launches` completions.
+bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, float* out_end_ms, int* out_n_streams)
+{
+    if (!ctx || !out_start_ms || !out_end_ms || !out_n_streams) return BU_ERR_ARGUMENT;
+    for (int i = 0; i < 8; i++) {
+        out_start_ms[i] = i < ctx->win_streams ? ctx->win_start_ms[i] : -1.0f;
+        out_end_ms[i] = i < ctx->win_streams ? ctx->win_end_ms[i] : -1.0f;
+    }
+    *out_n_streams = ctx->win_streams;
+    return BU_OK;
+}
+
 bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on)
 {
     if (!ctx) return BU_ERR_ARGUMENT;

@@ -22,7 +22,7 @@ waits ~3.4 us for HBM with the ALUs idle and then computes with HBM idle; indepe
 streams use both at once.  `value` = K x 2^20 blocks / the time in which the K timed launches COMPLETE in a
 full pipeline (lead launches in front, one tail launch per stream behind); beside it the
 line carries the strict bracket around the same K steps and the one-launch-at-a-time figure of rounds 1-4.
-GPU_MAX_HW_QUEUES=8 is set before HIP initialises (a stream needs a hardware queue of its own to overlap).
+GPU_MAX_HW_QUEUES=8 (16 beside an RCCL communicator) is set before HIP initialises (a stream needs a hardware queue of its own to overlap).
 Every rank owns its own atlases (weak scaling: in the texture-array reading of the config each rank
 holds 16 slices of 1024x1024 px); the transcode needs no data-path collective.  The all-gather that
 reassembles the array is timed separately and reported under "allgather" -- never folded into `value`.
@@ -352,7 +352,10 @@ def main():
     # GPU_MAX_HW_QUEUES (default 4) of them per priority level, two of which torch's NULL stream and the context's internal stream already
     # hold: with the default, 4 launches "in flight" run as 2 (profiles/r05_hip_hw_queue_knobs_vs_streams.txt).  The runtime reads the
     # variable when it initialises, so it is set here, before torch is imported and before any child is started; a value the caller set wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # A process that also holds an RCCL communicator (N > 1) has more streams than eight queues: with 8, two of the context's four streams then
+    # share a queue, run at half the others' pace and fall thousands of launches behind (profiles/r05_dist_branch_hw_queues.txt) -- 16 there.
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if multi else "8")
     if args.pmc_child:
         pmc_child()
         return
@@ -636,7 +639,7 @@ def run_array512(env):
     ctx.status_word_reset(status)
     # A rank issues its range of slices as P equal pieces on P context streams under the shared launch policy (--in-flight, default 4): launches
     # queued on one stream never overlap and even a 2^25-block launch leaves a seventh of the HBM rate unused (one launch 189 us = 0.71 of the
-    # roofline; four launches of 2^23 blocks in flight 167 us = 0.80).  P = 1 (ragged splits, --in-flight 1): one launch over the range.
+    # roofline; four launches of 2^23 blocks in flight 172-177 us = 0.76-0.78).  P = 1 (ragged splits, --in-flight 1): one launch over the range.
     P = args.in_flight if (args.in_flight > 1 and (hi - lo) % args.in_flight == 0) else 1
     ctx.set_launch_policy(P > 1 and args.policy == "shared")
     lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
@@ -645,15 +648,24 @@ def run_array512(env):
     in_ptrs = PtrArr(*[t.data_ptr() + q * npiece * 16 for t in ins for q in range(P)])
     out_ptrs = PtrArr(*[f.ptr + rank * shard_bytes + q * npiece * 16 for f in fulls for q in range(P)])
     rot = [0]  # in steps; step r uses buffer entries r*P .. r*P + P - 1
+    PtrArr1 = ctypes.c_void_p * nrot
+    in_ptrs1 = PtrArr1(*[t.data_ptr() for t in ins])  # the range as ONE launch (the fallback when the streams are out of step)
+    out_ptrs1 = PtrArr1(*[f.ptr + rank * shard_bytes for f in fulls])
+    last_streams = [None]
 
-    def window(lead_steps, steps):
-        """`steps` passes over this rank's range (P launches each), behind `lead_steps` untimed ones; (event ms, host ms) of the timed part"""
+    def window(lead_steps, steps, pieces=None):
+        """`steps` passes over this rank's range (`pieces` launches each, default P), behind `lead_steps` untimed ones; (event ms, host ms) of the timed part"""
+        q = P if pieces is None else pieces
+        ip, op = (in_ptrs, out_ptrs) if q == P else (in_ptrs1, out_ptrs1)
         ev, host = ctypes.c_float(0), ctypes.c_float(0)
-        tail = P if (P > 1 and lead_steps > 0) else 0
-        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, env._lib.BC7, in_ptrs, out_ptrs, nrot * P, (rot[0] % nrot) * P, npiece, 256, lead_steps * P, steps * P,
-                                                             tail, P, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None),
+        tail = q if (q > 1 and lead_steps > 0) else 0
+        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, env._lib.BC7, ip, op, nrot * q, (rot[0] % nrot) * q, nb // q, 256, lead_steps * q, steps * q,
+                                                             tail, q, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None),
               "bu_time_uastc_launches_streams_window")
         rot[0] = (rot[0] + lead_steps + steps + (1 if tail else 0)) % nrot
+        a_, b_, n_ = (ctypes.c_float * 8)(), (ctypes.c_float * 8)(), ctypes.c_int(0)
+        if lib.bu_time_last_window_streams(ctx.handle, a_, b_, ctypes.byref(n_)) == 0:
+            last_streams[0] = {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
         return ev.value, host.value
 
     def run(launches):
@@ -689,9 +701,28 @@ def run_array512(env):
     busy_barrier(env, warm_async, max(2, 12 // world))  # ~3 ms of work
     # timed region as in run_atlas4096: lead untimed steps, K timed steps, (P > 1: one tail launch per stream), no host sync in between;
     # the window runs from the last lead launch's completion to the last timed launch's completion
-    lead = 16
+    # (lead: 128 steps = 22 ms of the same work in front of the window.  The barrier above ends in a synchronize(): the chip idles for a moment, and
+    #  after an idle moment the 2^23..2^25-block launches run 10-25 % slower for tens of milliseconds -- with 16 lead steps the one-rank run of this
+    #  branch read 208-213 us per step where the same launches without torch.distributed read 175: profiles/r05_dist_branch_hw_queues.txt)
+    lead = int(os.environ.get("BENCH_ARRAY_LEAD", "128"))
     ev_ms, host_ms = window(lead, args.steps)
     torch.cuda.synchronize()
+    # the streams have to be in step for the window to hold `steps` completions of every stream (run_atlas4096 has the story): start events more than
+    # 8 launch periods apart mean two streams share a hardware queue -- then the range is timed again as ONE launch per step on one stream
+    timed_streams = last_streams[0]
+    spread_us = (max(timed_streams["start_us"]) - min(timed_streams["start_us"])) if (timed_streams and P > 1) else 0.0
+    oos = torch.tensor([1.0 if spread_us > 8 * ev_ms * 1e3 / (args.steps * P) else 0.0], dtype=torch.float64, device=dev)
+    if env.use_dist:
+        dist.all_reduce(oos, op=dist.ReduceOp.MAX)
+    out_of_step = bool(oos.item() > 0)
+    P_timed = P
+    if out_of_step:
+        ctx.set_launch_policy(False)
+        window(0, 2, pieces=1)
+        ev_ms, host_ms = window(4, args.steps, pieces=1)
+        torch.cuda.synchronize()
+        ctx.set_launch_policy(P > 1 and args.policy == "shared")
+        P_timed = 1
     dt = max(host_ms, ev_ms) / 1e3
     if env.use_dist:
         dist.barrier()
@@ -718,7 +749,11 @@ def run_array512(env):
         "config": {"workload": "UASTC->BC7, texture array of 512 slices x 65 536 blocks (512 MiB in, 512 MiB out) per step; rank r owns "
                                "slices [r*512/N, (r+1)*512/N) and issues its contiguous range as %d launch(es) of %d blocks on %d context stream(s) (%s launch "
                                "policy); A-gold blocks; %d rotated input shards / full output buffers per rank" % (P, npiece, P, "shared" if (P > 1 and args.policy == "shared") else "exclusive", nrot),
-                   "launches_in_flight": P,
+                   "launches_in_flight": P_timed,
+                   "timed_region": {"streams": timed_streams, "start_event_spread_us": round(spread_us, 1), "streams_in_step": not out_of_step,
+                                    "note": None if not out_of_step else (
+                                        "the %d streams were NOT in step (two share a hardware queue: GPU_MAX_HW_QUEUES=%s, more streams in this process than queues); "
+                                        "the figures are those of ONE launch per step over the rank's range on one stream" % (P, os.environ.get("GPU_MAX_HW_QUEUES")))},
                    "blocks_per_step": total, "slices_per_gpu": hi - lo, "gb_s_in": round(value * 16 / 1e3, 1),
                    "prewarm": {"launches": prewarm_launches, "ms": 4 * args.prewarm_ms,
                                "note": "untimed launches ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}},
@@ -807,6 +842,13 @@ def run_atlas4096(env):
         return ev.value / 1e3 / launches
 
     fill_drain = [0.0]  # out_fill_drain_ms of the last run_window call
+
+    def window_streams():
+        """per-stream start / end event of the last streams window, us from the head of that call (bu_time_last_window_streams)"""
+        a_, b_, n_ = (ctypes.c_float * 8)(), (ctypes.c_float * 8)(), ctypes.c_int(0)
+        if lib.bu_time_last_window_streams(ctx.handle, a_, b_, ctypes.byref(n_)) != 0:
+            return None
+        return {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
 
     def run_window(lead, launches, in_flight=None, tail=None):
         """the timed region: step i on context stream i % in_flight; `lead` untimed launches, start event per stream, `launches` timed ones, end event
@@ -903,7 +945,7 @@ def run_atlas4096(env):
     wins = []
     for r_ in range(max(1, args.repeats)):
         ev_ms_, host_ms_, late_ = run_window(lead, args.steps)
-        wins.append((max(host_ms_, ev_ms_), ev_ms_, host_ms_, late_))
+        wins.append((max(host_ms_, ev_ms_), ev_ms_, host_ms_, late_, window_streams()))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -923,20 +965,39 @@ def run_atlas4096(env):
     value = total_blocks / dt_max / 1e6
     period_s = ev_max / args.steps  # launch-to-launch period of the timed region (slowest rank), HIP events
     achieved = BYTES_PER_BLOCK * N_BLOCKS / period_s / 1e9
+    # Are the streams in step?  The window counts K completions only if every stream is at about the same launch when it opens: the start events of a
+    # pipeline in step lie in_flight - 1 periods apart.  Streams that share a hardware queue (more streams in the process than GPU_MAX_HW_QUEUES, e.g.
+    # beside an RCCL communicator) run at half the others' pace and end up milliseconds behind -- the window then holds only the laggards' launches and
+    # reads too short (profiles/r05_dist_branch_hw_queues.txt).  Beyond 8 periods of spread the figure is not used: the one-launch-at-a-time
+    # measurement below (one stream, no assumption about anybody's pace) becomes the headline, with a warning.
+    sk_ = wins[m_][4]
+    start_spread_us = (max(sk_["start_us"]) - min(x for x in sk_["start_us"] if x >= 0)) if (sk_ and args.in_flight > 1) else 0.0
+    out_of_step = torch.tensor([1.0 if start_spread_us > 8 * period_s * 1e6 else 0.0], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(out_of_step, op=dist.ReduceOp.MAX)
+    out_of_step = bool(out_of_step.item() > 0)
 
     # the strict bracket: the same K steps with NOTHING behind them, from the first instruction of the first timed launch to the last instruction
     # of the last one (the pipeline's fill is credited to nobody and its drain -- the last launches running with fewer and fewer partners -- is inside)
     stricts = []
     for _ in range(max(1, args.repeats)):  # (median of the same number of passes as the headline: one 0.12 ms window is at the mercy of a single stall)
         run_window(lead, args.steps, tail=0)
-        stricts.append(fill_drain[0] / 1e3 / args.steps)
-    strict_s = sorted(stricts)[len(stricts) // 2]
+        stricts.append((fill_drain[0] / 1e3 / args.steps, window_streams()))
+    strict_s, strict_streams = sorted(stricts, key=lambda x: x[0])[len(stricts) // 2]
     # ---- the round 1-4 headline, kept as a row: ONE launch at a time (exclusive policy, one stream), same window method ----
     policy_now[0] = False
     ctx.set_launch_policy(False)
     run_window(0, 256, in_flight=1)
     one_ev, one_host, _ = run_window(lead, args.steps, in_flight=1)
     one_s = max(one_ev, one_host) / 1e3 / args.steps
+    if out_of_step:
+        o_ = torch.tensor([one_s], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(o_, op=dist.ReduceOp.MAX)
+        dt_max = ev_max = float(o_.item()) * args.steps
+        value = total_blocks / dt_max / 1e6
+        period_s = ev_max / args.steps
+        achieved = BYTES_PER_BLOCK * N_BLOCKS / period_s / 1e9
     # per-launch distribution: one event between every two launches of another K steps
     each = (ctypes.c_float * args.steps)()
     st = lib.bu_time_uastc_launches_each(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, args.steps,
@@ -1466,6 +1527,8 @@ def run_atlas4096(env):
                                "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"},
                    "timed_region": {"lead_launches": lead, "host_ms": round(host_ms, 6), "event_ms": round(ev_ms, 6), "host_started_late": bool(late),
                                     "repeats": len(wins), "window_reported": "median", "windows_us_per_step": [round(x / args.steps * 1e6, 3) for x in dts],
+                                    "streams_of_median_window": wins[m_][4], "streams_of_strict_bracket": strict_streams,
+                                    "start_event_spread_us": round(start_spread_us, 1), "streams_in_step": not out_of_step,
                                     "tail_launches": args.in_flight if args.in_flight > 1 else 0,
                                     "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, a start "
                                             "event per stream behind its last lead launch, K timed launches, an end event per stream behind its last timed launch, one untimed "
@@ -1488,6 +1551,13 @@ def run_atlas4096(env):
                              "launched behind them, first instruction of the first timed launch to last instruction of the last one, / K -- a window that holds "
                              "K + in_flight - 1 periods of a full pipeline and its drain (at --steps 512 the two figures meet)"},
     }
+    if out_of_step:
+        line["roofline"]["streams_out_of_step"] = (
+            "the %d streams of the timed region were NOT in step (start events %.0f us apart, period %.1f us): two of them share a hardware queue "
+            "(GPU_MAX_HW_QUEUES=%s; more streams in this process than queues).  The window over the pipelined launches is not reported; value, ms_per_step "
+            "and this roofline are the ONE-LAUNCH-AT-A-TIME measurement (extra.one_launch_at_a_time), which assumes nothing about the streams' pace"
+            % (args.in_flight, start_spread_us, ev_ms / args.steps * 1e3, os.environ.get("GPU_MAX_HW_QUEUES")))
+        line["roofline"]["launches_in_flight"] = 1
     tr = pmc_traffic()
     if tr:
         line["roofline"]["traffic"] = tr[0]

@@ -100,7 +100,8 @@ bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* 
  * DIFFERENT hardware queues, and the HIP runtime multiplexes all streams of a process over GPU_MAX_HW_QUEUES (default 4) queues per
  * priority level -- two streams that share one run their kernels strictly one after the other.  A process that wants four launches in
  * flight should start with GPU_MAX_HW_QUEUES=8 in its environment (set before the first HIP call; bench.py does): with the default a
- * process's NULL stream and the context's internal stream already hold two of the four queues. */
+ * process's NULL stream and the context's internal stream already hold two of the four queues.  A process
+ * that holds an RCCL communicator as well needs more (16): the communicator's streams take queues too. */
 bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream);
 /* waits until everything enqueued on the context's own streams (bu_context_stream) and on its internal stream has completed: the
  * host-side join for a caller without a HIP binding of its own (examples/slices_in_flight.c) */
@@ -390,6 +391,11 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
  * free) instead of from the calling thread alone -- how a caller with a thread per stream drives the context, and what keeps the host
  * from setting the pace when one enqueue costs more host time than a period (under rocprofv3 --kernel-trace: 6-8 us). */
 bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on);
+/* the per-stream events of the context's LAST streams window, ms from the head of that call: out_start_ms[i] / out_end_ms[i] (8 floats each)
+ * = stream i's start event (behind its last lead launch) / end event (behind its last timed launch), -1 for a stream without timed launches.
+ * Streams running in step start and end within a few periods of each other; a stream that shares a hardware queue falls behind, and the
+ * window "latest start to latest end" then no longer brackets `launches` completions -- callers check the spread. */
+bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, float* out_end_ms, int* out_n_streams);
 #define BU_TIME_COPY_CEILING 100 /* as `target` of the call below: the uint4 -> uint4 copy kernel (bu_copy_ceiling_device) in place of a transcode */
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,

@@ -184,8 +184,9 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") not in (None, "0")
     assert d["parent_initialised_cuda"] is False  # the parent only counted devices: nothing that a child could not re-do
     # the ranks inherit one hardware queue per stream from the launcher's environment (set before torch is imported: the HIP runtime
-    # reads it when it initialises; four launches in flight need four queues of their own)
-    assert d["GPU_MAX_HW_QUEUES"] == "8"
+    # reads it when it initialises; four launches in flight need four queues of their own, and a rank's RCCL communicator brings streams of
+    # its own: 16 in the multi-rank branch, profiles/r05_dist_branch_hw_queues.txt)
+    assert d["GPU_MAX_HW_QUEUES"] == "16"
 
 
 def test_bench_live_traffic_falls_back_without_a_gpu():
