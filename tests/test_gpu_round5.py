@@ -3,6 +3,8 @@ launches in flight on different streams) must give the exclusive policy's bytes 
 on ragged sizes and through the oracle on random blocks; the multi-stream timing window of bench.py must really run every launch on
 every stream.  Everything goes through the C ABI; bit-exact.  Run on the GPU box: pytest -m gpu."""
 import ctypes
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +12,7 @@ import pytest
 from basisu_rs_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TB = {"astc": (_lib.ASTC, 16), "bc7": (_lib.BC7, 16), "rgba": (_lib.RGBA32, 64), "etc1": (_lib.ETC1, 8), "etc2": (_lib.ETC2, 16)}
 
 
@@ -317,3 +320,43 @@ def test_context_streams_and_synchronize(golden):
     for k in range(8):
         assert (host[k] == golden["astc"][idx[k]]).all(), k
     ctx.close()
+
+
+@pytest.mark.parametrize("queues", [None, "8"])
+def test_bench_dist_branch_checks_that_its_streams_are_in_step(queues):
+    """bench.py, N > 1 branch with one rank (an RCCL communicator alive): the line carries every stream's start / end event of the median window, the
+    default environment (16 hardware queues) keeps the four streams in step, and whenever they are NOT in step -- a forced GPU_MAX_HW_QUEUES=8 puts two
+    of them on one queue beside the communicator on this runtime -- the headline is the one-launch-at-a-time measurement and says so, never the
+    pipelined window (profiles/r05_dist_branch_hw_queues.txt)"""
+    import json
+    import socket
+    import subprocess
+
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_PORT=str(port))
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    if queues:
+        env["GPU_MAX_HW_QUEUES"] = queues
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--headline-only", "--no-cpu", "--steps", "20", "--warmup", "5"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    t, roof = line["config"]["timed_region"], line["roofline"]
+    assert line["config"]["hip_runtime_env"]["GPU_MAX_HW_QUEUES"] == (queues or "16")
+    st = t["streams_of_median_window"]
+    assert len(st["start_us"]) == 4 and all(b > a >= 0 for a, b in zip(st["start_us"], st["end_us"]))
+    period_us = t["event_ms"] * 1e3 / line["steps"]
+    if t["streams_in_step"]:
+        assert t["start_event_spread_us"] <= 16 * period_us + 1e-6
+        assert roof["launches_in_flight"] == 4 and "streams_out_of_step" not in roof
+        assert 4.5 < line["ms_per_step"] * 1e3 < 9.0, line["ms_per_step"]
+    else:
+        assert roof["launches_in_flight"] == 1 and "hardware queue" in roof["streams_out_of_step"]
+        one = line["extra"]["one_launch_at_a_time"]["us_per_launch"] if "extra" in line and "one_launch_at_a_time" in line.get("extra", {}) else None
+        assert 7.0 < line["ms_per_step"] * 1e3 < 14.0, line["ms_per_step"]
+        assert one is None or abs(one - line["ms_per_step"] * 1e3) < 0.5
+    if queues is None:
+        assert t["streams_in_step"], t
