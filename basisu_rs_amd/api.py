@@ -135,6 +135,12 @@ class Context:
         self._check(self._lib.bu_context_stream(self._h, int(index), ctypes.byref(p)))
         return p.value
 
+    def probe_streams(self, n_streams=4):
+        """the largest number of the context's streams 0..n_streams-1 sharing one hardware queue in this process (1: each has its own)"""
+        k = ctypes.c_int(0)
+        self._check(self._lib.bu_context_probe_streams(self._h, int(n_streams), ctypes.byref(k)))
+        return k.value
+
     def block_api_on_device(self, enable):
         """Per-block API: False (default) = the library's own block code on the calling thread, True = a one-block kernel launch."""
         self._check(self._lib.bu_block_api_on_device(self._h, 1 if enable else 0))

@@ -330,6 +330,48 @@ bu_status bu_context_synchronize(bu_context* ctx)
     return BU_OK;
 }
 
+// Do the context's streams 0..n_streams-1 really run side by side?  One sleeping wave (200 us) is launched on every one of them behind a common
+// event; streams on different hardware queues sleep together (the whole probe takes one sleep), streams that share a queue sleep one after
+// the other.  *out_max_sharing = round(time of the probe / one sleep) = the largest number of the probed streams on one queue: 1 = every
+// stream has a queue of its own.  (The HIP runtime has no call that says which queue a stream is on; GPU_MAX_HW_QUEUES decides, see
+// bu_ctx_streams.)  Waits for the probe; ~0.3 ms.
+bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_sharing)
+{
+    if (!ctx || !out_max_sharing || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        const bu_status st = bu_ctx_streams(ctx, n_streams);
+        if (st) return st;
+    }
+    std::lock_guard<std::mutex> g(ctx->lock);  // (ev0 / ev_end are the context's)
+    for (int i = 0; i < n_streams; i++)
+        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreate(&ctx->ev_end[i]));
+    constexpr unsigned long long TICKS = 20000;  // 200 us of the 100 MHz clock
+    BuDrain drain(ctx);
+    float best = 0;
+    for (int pass = 0; pass < 2; pass++) {  // (the first pass pays for loading the kernel)
+        BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->extra_streams[0]));
+        for (int i = 1; i < n_streams; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
+        for (int i = 0; i < n_streams; i++) {
+            hipLaunchKernelGGL(bu_sleep_kernel, dim3(1), dim3(64), 0, ctx->extra_streams[i], TICKS);
+            BU_HIP(ctx, hipGetLastError());
+            BU_HIP(ctx, hipEventRecord(ctx->ev_end[i], ctx->extra_streams[i]));
+        }
+        float worst = 0;
+        for (int i = 0; i < n_streams; i++) {
+            BU_HIP(ctx, hipEventSynchronize(ctx->ev_end[i]));
+            float ms = 0;
+            BU_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_end[i]));
+            if (ms > worst) worst = ms;
+        }
+        best = worst;
+    }
+    drain.armed = false;
+    const int k = (int)(best / 0.2f + 0.5f);
+    *out_max_sharing = k < 1 ? 1 : (k > n_streams ? n_streams : k);
+    return BU_OK;
+}
+
 // ---- per-block API (lib.rs:29-53) -----------------------------------------------------------------------------------------------
 // One 16-byte block is not worth a kernel launch (upload + 1-block launch + download: tens of microseconds; the reference's own
 // benchmark calls these 32 000 times, benches/benchmark.rs:66-98).  They run the product's OWN block code -- the mode-templated

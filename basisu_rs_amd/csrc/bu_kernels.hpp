@@ -598,6 +598,14 @@ __global__ __launch_bounds__(256) void bu_crc16_pieces_kernel(const uint4* __res
     if (threadIdx.x == 0) partial[blockIdx.x] = (uint16_t)(red[0] ^ red[1] ^ red[2] ^ red[3]);
 }
 
+// one wave that does nothing for `ticks` ticks of the constant 100 MHz clock (bu_context_probe_streams: kernels of different streams that
+// sit on different hardware queues sleep side by side, kernels of streams that share a queue one after the other)
+__global__ __launch_bounds__(64) void bu_sleep_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // uint4 -> uint4 copy (measurement only): the practical ceiling any 16 B in / 16 B out kernel is compared with.  The shape is the
 // fastest of tools/exp/copy_shapes.hip at 2^20 blocks (profiles/r02_copy_shapes_32MiB.txt): 512 threads, four 16-byte elements per
 // thread issued back to back (all four loads in flight before the first store), nontemporal both ways, one pass per thread --

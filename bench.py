@@ -643,6 +643,7 @@ def run_array512(env):
     P = args.in_flight if (args.in_flight > 1 and (hi - lo) % args.in_flight == 0) else 1
     ctx.set_launch_policy(P > 1 and args.policy == "shared")
     lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
+    queue_sharing = ctx.probe_streams(P) if P > 1 else 1  # (the communicator of the N > 1 branch exists by now)
     npiece = nb // P
     PtrArr = ctypes.c_void_p * (nrot * P)
     in_ptrs = PtrArr(*[t.data_ptr() + q * npiece * 16 for t in ins for q in range(P)])
@@ -711,7 +712,7 @@ def run_array512(env):
     # 16 launch periods apart mean two streams share a hardware queue -- then the range is timed again as ONE launch per step on one stream
     timed_streams = last_streams[0]
     spread_us = (max(timed_streams["start_us"]) - min(timed_streams["start_us"])) if (timed_streams and P > 1) else 0.0
-    oos = torch.tensor([1.0 if spread_us > 16 * ev_ms * 1e3 / (args.steps * P) else 0.0], dtype=torch.float64, device=dev)
+    oos = torch.tensor([1.0 if (spread_us > 16 * ev_ms * 1e3 / (args.steps * P) or queue_sharing > 1) else 0.0], dtype=torch.float64, device=dev)
     if env.use_dist:
         dist.all_reduce(oos, op=dist.ReduceOp.MAX)
     out_of_step = bool(oos.item() > 0)
@@ -751,6 +752,7 @@ def run_array512(env):
                                "policy); A-gold blocks; %d rotated input shards / full output buffers per rank" % (P, npiece, P, "shared" if (P > 1 and args.policy == "shared") else "exclusive", nrot),
                    "launches_in_flight": P_timed,
                    "timed_region": {"streams": timed_streams, "start_event_spread_us": round(spread_us, 1), "streams_in_step": not out_of_step,
+                                    "streams_on_one_hardware_queue_max": queue_sharing,
                                     "note": None if not out_of_step else (
                                         "the %d streams were NOT in step (two share a hardware queue: GPU_MAX_HW_QUEUES=%s, more streams in this process than queues); "
                                         "the figures are those of ONE launch per step over the rank's range on one stream" % (P, os.environ.get("GPU_MAX_HW_QUEUES")))},
@@ -904,6 +906,8 @@ def run_atlas4096(env):
     policy_now = [args.policy == "shared"]  # the context's launch policy outside srow()
     ctx.set_launch_policy(policy_now[0])
     lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
+    # does every stream of the timed region have a hardware queue of its own in this process (the communicator of the N > 1 branch exists by now)?
+    queue_sharing = ctx.probe_streams(args.in_flight) if args.in_flight > 1 else 1
     ctx.status_word_reset(status)
     torch.cuda.synchronize()  # (the context's streams do not wait for torch's)
     run_window(0, nbuf)       # one launch per atlas, round-robin over the streams
@@ -972,7 +976,7 @@ def run_atlas4096(env):
     # measurement below (one stream, no assumption about anybody's pace) becomes the headline, with a warning.
     sk_ = wins[m_][4]
     start_spread_us = (max(sk_["start_us"]) - min(x for x in sk_["start_us"] if x >= 0)) if (sk_ and args.in_flight > 1) else 0.0
-    out_of_step = torch.tensor([1.0 if start_spread_us > 16 * period_s * 1e6 else 0.0], dtype=torch.float64, device=dev)
+    out_of_step = torch.tensor([1.0 if (start_spread_us > 16 * period_s * 1e6 or queue_sharing > 1) else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(out_of_step, op=dist.ReduceOp.MAX)
     out_of_step = bool(out_of_step.item() > 0) and not args.enqueue_threads  # (with --enqueue-threads the figure is the strict bracket already)
@@ -1521,7 +1525,8 @@ def run_atlas4096(env):
                                    nbuf, ("%d launches in flight on %d streams (step i on context stream i %% %d), %s launch policy" % (
                                        args.in_flight, args.in_flight, args.in_flight, args.policy)) if args.in_flight > 1 else "one launch at a time on one stream, %s launch policy" % args.policy),
                    "launches_in_flight": args.in_flight, "launch_policy": args.policy,
-                   "hip_runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                   "hip_runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_on_one_hardware_queue_max": queue_sharing,
+                                       "note": "bu_context_probe_streams over the streams of the timed region: 1 = every stream has its own hardware queue"},
                    "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1),
                    "prewarm": {"launches": prewarm_launches, "ms": args.prewarm_ms,
                                "note": "untimed launches of the same kernel ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"},
@@ -1553,10 +1558,10 @@ def run_atlas4096(env):
     }
     if out_of_step:
         line["roofline"]["streams_out_of_step"] = (
-            "the %d streams of the timed region were NOT in step (start events %.0f us apart, period %.1f us): two of them share a hardware queue "
-            "(GPU_MAX_HW_QUEUES=%s; more streams in this process than queues).  The window over the pipelined launches is not reported; value, ms_per_step "
+            "the %d streams of the timed region were NOT in step (start events %.0f us apart, period %.1f us; bu_context_probe_streams found up to %d of them on "
+            "one hardware queue): streams share a hardware queue (GPU_MAX_HW_QUEUES=%s; more streams in this process than queues).  The window over the pipelined launches is not reported; value, ms_per_step "
             "and this roofline are the ONE-LAUNCH-AT-A-TIME measurement (extra.one_launch_at_a_time), which assumes nothing about the streams' pace"
-            % (args.in_flight, start_spread_us, ev_ms / args.steps * 1e3, os.environ.get("GPU_MAX_HW_QUEUES")))
+            % (args.in_flight, start_spread_us, ev_ms / args.steps * 1e3, queue_sharing, os.environ.get("GPU_MAX_HW_QUEUES")))
         line["roofline"]["launches_in_flight"] = 1
     tr = pmc_traffic()
     if tr:

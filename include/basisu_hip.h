@@ -106,6 +106,12 @@ bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream);
 /* waits until everything enqueued on the context's own streams (bu_context_stream) and on its internal stream has completed: the
  * host-side join for a caller without a HIP binding of its own (examples/slices_in_flight.c) */
 bu_status bu_context_synchronize(bu_context* ctx);
+/* Do the context's streams 0..n_streams-1 (1..8) really run side by side in THIS process?  A 200 us sleeping wave is launched on each of them
+ * behind a common event: streams on different hardware queues sleep together, streams sharing a queue one after the other.
+ * *out_max_sharing = the largest number of the probed streams found on one queue -- 1: every stream has its own; 2 and more: raise
+ * GPU_MAX_HW_QUEUES (above) before the process first touches HIP.  Blocks for about 0.3 ms; call it once after setting a process up
+ * (other libraries' streams -- an RCCL communicator's -- take queues too, so probe after they exist). */
+bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_sharing);
 
 /* ---- UASTC slice level, host pointers ------------------------------------------------------- */
 

@@ -101,6 +101,8 @@ extern "C" {
     // the context's own streams (hipStream_t), index 0..7, on different hardware queues: for several launches in flight
     pub fn bu_context_stream(ctx: *mut bu_context, index: c_int, out_stream: *mut *mut c_void) -> c_int;
     pub fn bu_context_synchronize(ctx: *mut bu_context) -> c_int;
+    // the largest number of the context's streams 0..n_streams-1 that share one hardware queue in this process (1 = none do)
+    pub fn bu_context_probe_streams(ctx: *mut bu_context, n_streams: c_int, out_max_sharing: *mut c_int) -> c_int;
     // slice level, host pointers (uastc.rs:89-146)
     pub fn bu_uastc_transcode(ctx: *mut bu_context, target: c_int, input: *const u8, in_bytes: usize, out: *mut u8, out_bytes: usize,
                               first_bad_block: *mut u64) -> c_int;

@@ -360,3 +360,30 @@ def test_bench_dist_branch_checks_that_its_streams_are_in_step(queues):
         assert one is None or abs(one - line["ms_per_step"] * 1e3) < 0.5
     if queues is None:
         assert t["streams_in_step"], t
+        assert line["config"]["hip_runtime_env"]["streams_on_one_hardware_queue_max"] == 1
+    assert t["streams_in_step"] or line["config"]["hip_runtime_env"]["streams_on_one_hardware_queue_max"] >= 1
+
+
+def test_probe_streams_sees_queue_sharing():
+    """bu_context_probe_streams: a child process started with GPU_MAX_HW_QUEUES=8 finds every one of the context's four streams on its own hardware
+    queue (1); with GPU_MAX_HW_QUEUES=2 four streams cannot have two queues to themselves (>= 2); argument checks"""
+    import subprocess
+
+    child = ("import sys; sys.path.insert(0, %r); import torch; torch.zeros(1, device='cuda'); from basisu_rs_amd import Context; c = Context(0); "
+             "print('SHARING', c.probe_streams(4), c.probe_streams(1)); c.close()" % ROOT)
+    got = {}
+    for q in ("8", "2"):
+        env = dict(os.environ, GPU_MAX_HW_QUEUES=q)
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[q] = [int(x) for x in r.stdout.split("SHARING")[1].split()[:2]]
+    assert got["8"] == [1, 1], got
+    assert got["2"][0] >= 2 and got["2"][1] == 1, got
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    k = ctypes.c_int(0)
+    assert ctx._lib.bu_context_probe_streams(ctx.handle, 0, ctypes.byref(k)) == _lib.ERR_ARGUMENT
+    assert ctx._lib.bu_context_probe_streams(ctx.handle, 9, ctypes.byref(k)) == _lib.ERR_ARGUMENT
+    assert ctx._lib.bu_context_probe_streams(ctx.handle, 4, None) == _lib.ERR_ARGUMENT
+    ctx.close()
