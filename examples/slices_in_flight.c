@@ -81,6 +81,13 @@ int main(int argc, char** argv)
         st = bu_context_stream(ctx, t, &streams[t]);
         if (st) return fail(ctx, "bu_context_stream", st);
     }
+    {   /* are the four streams on four hardware queues?  (results never depend on it; the overlap does) */
+        int sharing = 0;
+        st = bu_context_probe_streams(ctx, STREAMS, &sharing);
+        if (st) return fail(ctx, "bu_context_probe_streams", st);
+        if (sharing > 1)
+            fprintf(stderr, "note: up to %d of the %d streams share a hardware queue and will not overlap: start with GPU_MAX_HW_QUEUES=8 (or more)\n", sharing, STREAMS);
+    }
     st = bu_device_alloc(ctx, (size_t)flen, &d_in);
     if (!st) st = bu_device_alloc(ctx, out_slice_bytes * (size_t)n_slices, &d_out);
     if (!st) st = bu_device_alloc(ctx, sizeof(uint64_t), &d_status);
