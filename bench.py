@@ -975,6 +975,14 @@ def run_atlas4096(env):
     # reads too short (profiles/r05_dist_branch_hw_queues.txt: spreads of 2 500-5 700 us; streams in step: 15-35 us).  Beyond 16 periods of spread the figure is not used: the one-launch-at-a-time
     # measurement below (one stream, no assumption about anybody's pace) becomes the headline, with a warning.
     sk_ = wins[m_][4]
+    # a third reading of the same window, stream by stream: stream s completed its K_s timed launches between ITS start and end event, i.e. at a rate
+    # of K_s / (end_s - start_s); the streams were active side by side, so the rates add up
+    by_rates_us = None
+    if sk_ and args.in_flight > 1:
+        ks_ = [len(range(lead + j, lead + args.steps, args.in_flight)) for j in range(args.in_flight)]  # timed launches of the stream of launch lead + j
+        ks_ = {(lead + j) % args.in_flight: ks_[j] for j in range(args.in_flight)}
+        rate_ = sum(ks_[s_] / (sk_["end_us"][s_] - sk_["start_us"][s_]) for s_ in range(args.in_flight) if sk_["start_us"][s_] >= 0 and sk_["end_us"][s_] > sk_["start_us"][s_])
+        by_rates_us = round(1.0 / rate_, 3) if rate_ > 0 else None
     start_spread_us = (max(sk_["start_us"]) - min(x for x in sk_["start_us"] if x >= 0)) if (sk_ and args.in_flight > 1) else 0.0
     out_of_step = torch.tensor([1.0 if (start_spread_us > 16 * period_s * 1e6 or queue_sharing > 1) else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
@@ -1534,6 +1542,7 @@ def run_atlas4096(env):
                                     "repeats": len(wins), "window_reported": "median", "windows_us_per_step": [round(x / args.steps * 1e6, 3) for x in dts],
                                     "streams_of_median_window": wins[m_][4], "streams_of_strict_bracket": strict_streams,
                                     "start_event_spread_us": round(start_spread_us, 1), "streams_in_step": not out_of_step,
+                                    "us_per_step_by_stream_rates": by_rates_us,
                                     "tail_launches": args.in_flight if args.in_flight > 1 else 0,
                                     "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, a start "
                                             "event per stream behind its last lead launch, K timed launches, an end event per stream behind its last timed launch, one untimed "
@@ -1541,7 +1550,9 @@ def run_atlas4096(env):
                                             "start event (every lead launch has completed) to the LAST end event (every timed launch has completed) on the device clock; "
                                             "host clock from every start event seen complete to every end event seen complete; value uses max(host, event).  The pipeline "
                                             "is full at both instants (what the first timed launches got done beside the last lead launches, the tail launches get done "
-                                            "beside the last timed ones).  --steps 512 gives the same figure with the ends weighing 25 times less"}},
+                                            "beside the last timed ones).  us_per_step_by_stream_rates: the same window read stream by stream -- 1 / sum over the streams of "
+                                            "(its timed launches / (its end event - its start event)); streams_in_step: the start events lie within 16 periods and no two "
+                                            "streams share a hardware queue (bu_context_probe_streams).  --steps 512 gives the same figure with the ends weighing 25 times less"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                      "kernel": "bu_uastc_sorted_kernel<BC7> (%s-policy shape)" % args.policy,
