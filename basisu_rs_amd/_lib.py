@@ -20,7 +20,7 @@ SYMBOLS = [
     "bu_uastc_transcode", "bu_uastc_decode_to_rgba",
     "bu_unpack_uastc_block_to_rgba", "bu_transcode_uastc_block_to_astc", "bu_transcode_uastc_block_to_bc7",
     "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2", "bu_block_api_on_device", "bu_context_set_launch_policy", "bu_context_get_launch_policy", "bu_context_stream", "bu_context_synchronize", "bu_context_probe_streams",
-    "bu_uastc_transcode_device", "bu_uastc_transcode_batch_device", "bu_status_word_reset", "bu_status_word_decode", "bu_host_alloc", "bu_host_free",
+    "bu_uastc_transcode_device", "bu_uastc_transcode_batch_device", "bu_uastc_transcode_batch_in_flight", "bu_status_word_reset", "bu_status_word_decode", "bu_host_alloc", "bu_host_free",
     "bu_etc1s_selector_from_rows", "bu_etc1s_transcode_etc1_device", "bu_etc1s_decode_rgba_device",
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
     "bu_basis_read_header", "bu_basis_read_slice_descs", "bu_basis_crc16", "bu_read_query", "bu_read_to", "bu_basislz_decode",
@@ -155,6 +155,8 @@ def load():
     lib.bu_time_uastc_launches.restype = c.c_int
     lib.bu_uastc_transcode_batch_device.argtypes = [vp, c.c_int, sz, c.POINTER(vp), c.POINTER(sz), c.POINTER(vp), sz, c.POINTER(c.c_uint64), vp, vp]
     lib.bu_uastc_transcode_batch_device.restype = c.c_int
+    lib.bu_uastc_transcode_batch_in_flight.argtypes = [vp, c.c_int, sz, c.POINTER(vp), c.POINTER(sz), c.POINTER(vp), sz, c.POINTER(c.c_uint64), vp, c.c_int]
+    lib.bu_uastc_transcode_batch_in_flight.restype = c.c_int
     lib.bu_time_uastc_launches_window.argtypes = [vp, c.c_int, c.POINTER(vp), c.POINTER(vp), sz, sz, sz, sz, c.c_int, c.c_int, vp, vp,
                                                   c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_int)]
     lib.bu_time_uastc_launches_window.restype = c.c_int

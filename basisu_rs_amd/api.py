@@ -192,6 +192,20 @@ class Context:
                                                  int(block_index_base), _ptr(d_status), _stream_ptr(stream))
         self._check(st)
 
+    def transcode_batch_in_flight(self, fmt, d_ins, n_blocks, d_outs, blocks_per_row=0, index_base=None, d_status=None, n_streams=4):
+        """bu_uastc_transcode_batch_in_flight: independent slices as a pipeline of launches on the context's own streams; only enqueues --
+        synchronize() waits.  d_ins / d_outs: device tensors or raw pointers, n_blocks: blocks per slice"""
+        n = len(d_ins)
+        VP, SZ = ctypes.c_void_p * n, ctypes.c_size_t * n
+        ib = (ctypes.c_uint64 * n)(*[int(x) for x in index_base]) if index_base is not None else None
+        st = self._lib.bu_uastc_transcode_batch_in_flight(self._h, int(fmt), n, VP(*[_ptr(x) for x in d_ins]), SZ(*[int(x) for x in n_blocks]),
+                                                          VP(*[_ptr(x) for x in d_outs]), int(blocks_per_row), ib, _ptr(d_status), int(n_streams))
+        self._check(st)
+
+    def synchronize(self):
+        """bu_context_synchronize: everything enqueued on the context's own streams has completed"""
+        self._check(self._lib.bu_context_synchronize(self._h))
+
     def status_word_reset(self, d_status, stream=None):
         self._check(self._lib.bu_status_word_reset(self._h, _ptr(d_status), _stream_ptr(stream)))
 

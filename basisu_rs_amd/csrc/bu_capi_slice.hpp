@@ -179,9 +179,19 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
     return bu_launch_uastc(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, d_status, static_cast<hipStream_t>(stream), 0, -1);
 }
 
-bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
-                                          const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
-                                          const uint64_t* index_base, uint64_t* d_status, void* stream)
+}  // extern "C"
+namespace {
+// a run = slices that are contiguous in input, output and block numbering
+struct BuRun {
+    const uint8_t* in;
+    uint8_t* out;
+    size_t n;
+    uint64_t base;
+};
+
+// argument check of the batch entry points, then the slices merged into runs
+bu_status bu_batch_runs(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in, const size_t* n_blocks, void* const* d_out,
+                        size_t blocks_per_row, const uint64_t* index_base, std::vector<BuRun>& runs)
 {
     if (!ctx || (n_slices && (!d_in || !n_blocks || !d_out))) return BU_ERR_ARGUMENT;
     const size_t bb = bu_target_block_bytes(target);
@@ -190,15 +200,6 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
         if (n_blocks[i] && (!d_in[i] || !d_out[i])) return BU_ERR_ARGUMENT;
         if (target == BU_TARGET_RGBA32 && n_blocks[i] % blocks_per_row != 0) return BU_ERR_ARGUMENT;
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // runs of slices that are contiguous in input, output and block numbering become one launch each
-    struct Run {
-        const uint8_t* in;
-        uint8_t* out;
-        size_t n;
-        uint64_t base;
-    };
-    std::vector<Run> runs;
     uint64_t next_base = 0;
     for (size_t i = 0; i < n_slices; i++) {
         const uint64_t base = index_base ? index_base[i] : next_base;
@@ -207,28 +208,34 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
         const uint8_t* in = static_cast<const uint8_t*>(d_in[i]);
         uint8_t* out = static_cast<uint8_t*>(d_out[i]);
         if (!runs.empty()) {
-            Run& r = runs.back();
+            BuRun& r = runs.back();
             if (r.in + r.n * 16 == in && r.out + r.n * bb == out && r.base + r.n == base) {
                 r.n += n_blocks[i];
                 continue;
             }
         }
-        runs.push_back(Run{in, out, n_blocks[i], base});
+        runs.push_back(BuRun{in, out, n_blocks[i], base});
     }
-    if (runs.empty()) return BU_OK;
-    if (runs.size() == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s, 0, -1);
-    // several runs at unrelated addresses: ONE launch per BU_MULTI_RUNS runs, the run table in the kernel arguments (kernel layout
-    // MULTI).  Launching the runs one by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices
+    return BU_OK;
+}
+
+// runs[0 .. n_runs) on ONE stream: one run is the plain launch; several runs at unrelated addresses are ONE launch per BU_MULTI_RUNS runs,
+// the run table in the kernel arguments (kernel layout MULTI).  policy: BU_POLICY_* of the plain launches, -1 = the context's.
+bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, size_t n_runs, size_t blocks_per_row, uint64_t* d_status, hipStream_t s, int policy)
+{
+    if (n_runs == 0) return BU_OK;
+    if (n_runs == 1) return bu_launch_uastc(ctx, target, runs[0].in, runs[0].n, runs[0].out, blocks_per_row, runs[0].base, d_status, s, 0, policy);
+    // Launching the runs one by one is bound by the ~4 us of host time per launch whatever the number of streams (64 slices
     // of 65 536 blocks: 290 us on one stream, 230-260 us on 2-8, profiles/r03_small_slices_streams_vs_one_launch.txt).
     // (a run too long for the table's 32-bit fields -- 2^32 blocks or more -- never enters it: it goes out as the plain launch
     // below, which cuts it into pieces of 2^26 blocks, exactly as it would on its own)
     BU_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long* stw = reinterpret_cast<unsigned long long*>(d_status);
-    for (size_t r0 = 0; r0 < runs.size();) {
+    for (size_t r0 = 0; r0 < n_runs;) {
         BuRunTable tb;
         size_t k = 0, n_tiles = 0;
-        for (; r0 + k < runs.size() && k < BU_MULTI_RUNS; k++) {
-            const Run& r = runs[r0 + k];
+        for (; r0 + k < n_runs && k < BU_MULTI_RUNS; k++) {
+            const BuRun& r = runs[r0 + k];
             const size_t t = (r.n + 1023) / 1024;
             if (n_tiles + t >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
             tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, 0u};
@@ -236,7 +243,7 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
             n_tiles += t;
         }
         if (k <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
-            bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s, 0, -1);
+            bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s, 0, policy);
             if (st) return st;
             r0 += 1;
             continue;
@@ -270,6 +277,99 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return bu_fail(ctx, e, "multi-run launch");
         r0 += k;
+    }
+    return BU_OK;
+}
+}  // namespace
+extern "C" {
+
+bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
+                                          const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
+                                          const uint64_t* index_base, uint64_t* d_status, void* stream)
+{
+    std::vector<BuRun> runs;
+    const bu_status st = bu_batch_runs(ctx, target, n_slices, d_in, n_blocks, d_out, blocks_per_row, index_base, runs);
+    if (st) return st;
+    return bu_launch_runs(ctx, target, runs.data(), runs.size(), blocks_per_row, d_status, static_cast<hipStream_t>(stream), -1);
+}
+
+// The same loop at the rate of a PIPELINE of launches (include/basisu_hip.h): the runs are grouped into launches of about one 4096^2 atlas
+// or more, a batch that makes fewer launches than streams has its largest runs cut into equal pieces, and launch j goes to context stream
+// j % n_streams under the shared launch policy.  Only enqueues; bu_context_synchronize (or the streams) waits.
+bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
+                                             const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
+                                             const uint64_t* index_base, uint64_t* d_status, int n_streams)
+{
+    if (n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
+    std::vector<BuRun> runs;
+    bu_status st = bu_batch_runs(ctx, target, n_slices, d_in, n_blocks, d_out, blocks_per_row, index_base, runs);
+    if (st) return st;
+    if (runs.empty()) return BU_OK;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    st = bu_ctx_streams(ctx, n_streams);
+    if (st) return st;
+    const size_t bb = bu_target_block_bytes(target);
+    // 1. groups of consecutive runs, closed at about 2^20 blocks (one launch per group: below that a launch is bound by the host's ~4 us)
+    constexpr size_t GROUP_BLOCKS = (size_t)1 << 20;
+    struct Group {
+        size_t first, count, blocks;
+    };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < runs.size();) {
+        Group g{i, 0, 0};
+        while (i < runs.size() && g.count < (size_t)BU_MULTI_RUNS && (g.count == 0 || g.blocks + runs[i].n <= GROUP_BLOCKS)) {
+            g.blocks += runs[i].n;
+            g.count++;
+            i++;
+            if (g.blocks >= GROUP_BLOCKS) break;
+        }
+        groups.push_back(g);
+    }
+    // 2. fewer launches than streams: the largest single-run groups are cut into equal pieces on tile boundaries (rectangular tiles: 16
+    //    block rows; RGBA32: whole block rows) as long as a piece keeps at least 2^20 blocks
+    std::vector<BuRun> extra;  // the pieces (groups index into `runs` or, with first >= runs.size(), into `extra`)
+    if (groups.size() < (size_t)n_streams) {
+        size_t align = 1024;
+        if (blocks_per_row) {
+            size_t a = blocks_per_row * 16, b = 1024;  // lcm(16 rows, 1024 blocks)
+            while (b) {
+                const size_t t = a % b;
+                a = b;
+                b = t;
+            }
+            align = blocks_per_row * 16 / a * 1024;
+        }
+        std::vector<Group> cut;
+        size_t spare = (size_t)n_streams - groups.size();  // additional launches wanted
+        for (const Group& g : groups) {
+            size_t pieces = 1;
+            if (g.count == 1 && spare > 0) {
+                const size_t want = 1 + (spare + groups.size() - 1) / groups.size();
+                pieces = want;
+                while (pieces > 1 && ((g.blocks / pieces) / align) * align < GROUP_BLOCKS) pieces--;
+            }
+            if (pieces <= 1) {
+                cut.push_back(g);
+                continue;
+            }
+            const BuRun r = runs[g.first];
+            size_t per = ((r.n + pieces - 1) / pieces + align - 1) / align * align;
+            for (size_t done = 0; done < r.n; done += per) {
+                const size_t n = r.n - done < per ? r.n - done : per;
+                extra.push_back(BuRun{r.in + done * 16, r.out + done * bb, n, r.base + done});
+                cut.push_back(Group{runs.size() + extra.size() - 1, 1, n});
+            }
+            spare -= pieces - 1 < spare ? pieces - 1 : spare;
+        }
+        groups.swap(cut);
+    }
+    // 3. launch j on stream j % n_streams, shared policy (a single launch gets the exclusive shape: nothing runs beside it)
+    const int policy = groups.size() > 1 && n_streams > 1 ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE;
+    for (size_t j = 0; j < groups.size(); j++) {
+        const Group& g = groups[j];
+        const BuRun* first = g.first >= runs.size() ? &extra[g.first - runs.size()] : &runs[g.first];
+        st = bu_launch_runs(ctx, target, first, g.count, blocks_per_row, d_status, ctx->extra_streams[j % (size_t)n_streams], policy);
+        if (st) return st;
     }
     return BU_OK;
 }

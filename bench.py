@@ -1115,6 +1115,32 @@ def run_atlas4096(env):
                                                              "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
                                                              "note": "one call of bu_uastc_transcode_batch_device per eight 2^20-block slices in separate allocations = ONE launch over 2^23 blocks, "
                                                                      "calls back to back on one stream, exclusive policy; every rotated output compared afterwards"}
+            # the same loop as ONE call of the pipelined entry point: bu_uastc_transcode_batch_in_flight issues the slices round-robin on the context's
+            # four streams under the shared policy and returns; bu_context_synchronize waits.  512 slices per call (the 64 atlases eight times over),
+            # host clock around call + wait -- the pipeline's fill and drain and the final wake-up are inside
+            nsl = 8 * nbuf
+            VPs, SZs = ctypes.c_void_p * nsl, ctypes.c_size_t * nsl
+            fl_in, fl_out, fl_n = VPs(*[in_ptrs[j % nbuf] for j in range(nsl)]), VPs(*[out_ptrs[j % nbuf] for j in range(nsl)]), SZs(*([N_BLOCKS] * nsl))
+            for o_ in outs:
+                o_.zero_()
+            torch.cuda.synchronize()
+
+            def in_flight_call():
+                t0_ = time.perf_counter()
+                assert lib.bu_uastc_transcode_batch_in_flight(ctx.handle, _lib.BC7, nsl, fl_in, fl_n, fl_out, NBX, None, None, 4) == 0
+                ctx.synchronize()
+                return time.perf_counter() - t0_
+
+            for _ in range(6):
+                in_flight_call()
+            fl_s = sorted(in_flight_call() for _ in range(5))[2] / nsl
+            extra["batch_in_flight_512_atlases_one_call"] = {
+                "us_per_atlas": round(fl_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / fl_s / 1e6, 1),
+                "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / fl_s / 1e9 / HBM_PEAK_GBS, 4),
+                "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
+                "note": "ONE call of bu_uastc_transcode_batch_in_flight over 512 slices of 2^20 blocks in separate allocations (the 64 atlases eight times over) on four "
+                        "context streams + bu_context_synchronize, host clock around both (median of five calls): the headline's pipeline as an entry point, its fill, "
+                        "drain and the final wake-up included"}
         except Exception as e:  # secondary rows must never break the headline line
             extra["launches_in_flight_matrix_error"] = repr(e)
         # a loop over 64 independent slices of 65 536 blocks (256 x 256 blocks: a 1024 x 1024 px mip), the shape of the per-slice
@@ -1243,6 +1269,35 @@ def run_atlas4096(env):
                                                              "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / b4_s / 1e9 / HBM_PEAK_GBS, 4), "verified": big4_ok,
                                                              "note": "the 512-slice array as four launches of 128 slices (2^23 blocks) each on four context streams, shared launch policy; 8 lead + 40 "
                                                                      "timed passes over the array, window from the last lead launch's completion to the last timed launch's"}
+                # ... and as ONE call of the pipelined entry point over the 512 slices (one allocation: they merge into one run, which the call cuts
+                # into four pieces on tile boundaries): call + bu_context_synchronize by the host clock, back to back on the two rotated pairs
+                VPa, SZa = ctypes.c_void_p * 512, ctypes.c_size_t * 512
+                a_n = SZa(*([65536] * 512))
+                a_io = [(VPa(*[t_i.data_ptr() + k * 65536 * 16 for k in range(512)]), VPa(*[t_o.data_ptr() + k * 65536 * 16 for k in range(512)])) for t_i, t_o in zip(big_in, big_out)]
+                for t_ in big_out:
+                    t_.zero_()
+                torch.cuda.synchronize()
+
+                def array_calls(k0, n_calls):
+                    t0_ = time.perf_counter()
+                    for k in range(k0, k0 + n_calls):
+                        check(env, lib.bu_uastc_transcode_batch_in_flight(ctx.handle, _lib.BC7, 512, a_io[k % 2][0], a_n, a_io[k % 2][1], 256, None, ctypes.c_void_p(status.data_ptr()), 4),
+                              "bu_uastc_transcode_batch_in_flight")
+                    ctx.synchronize()
+                    return (time.perf_counter() - t0_) / n_calls
+
+                array_calls(0, 2)
+                a512_call_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0]))
+                array_calls(0, 64)  # clocks
+                call_s = sorted(array_calls(16 * r_, 16) for r_ in range(5))[2]
+                one_s_ = sorted(array_calls(r_, 1) for r_ in range(5))[2]
+                extra["array512_one_call_in_flight"] = {"blocks": nbig, "us_per_array": round(call_s * 1e6, 2), "mblocks_s": round(nbig / call_s / 1e6, 1),
+                                                        "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / call_s / 1e9 / HBM_PEAK_GBS, 4),
+                                                        "verified": a512_call_ok, "us_per_array_one_call_then_wait": round(one_s_ * 1e6, 2),
+                                                        "note": "the 512-slice array through ONE call of bu_uastc_transcode_batch_in_flight per array (512 slice pointers into one "
+                                                                "allocation; the call cuts the run into four launches of 2^23 blocks on four context streams): 16 calls back to back, "
+                                                                "then bu_context_synchronize, host clock around all of it / 16 (median of five).  us_per_array_one_call_then_wait: a "
+                                                                "single call and the wait, starting on an idle chip and ending with a wake-up"}
             finally:
                 ctx.set_launch_policy(policy_now[0])
             a512 = pmc_array512()

@@ -175,6 +175,19 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
 bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
                                           const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
                                           const uint64_t* index_base, uint64_t* d_status, void* stream);
+/* The same loop over independent slices at the rate of a PIPELINE of launches -- what bench.py's headline measures, as one call.
+ * Launches queued on one stream never overlap, and a launch over a slice waits for HBM with the ALUs idle and then computes with HBM idle;
+ * launches on several streams fill each other's gaps (UASTC -> BC7 over 4096 x 4096 slices: 8.4 us per slice one at a time, 5.6-6.0 us in a
+ * pipeline).  The call merges the slices into runs as above, groups small runs into launches of about 2^20 blocks (one launch per group, the run
+ * table in its kernel arguments), cuts the largest runs of a batch that would make fewer launches than streams into equal pieces (a 512-slice
+ * texture array in one allocation becomes n_streams launches: 0.76-0.78 of the HBM roofline against 0.70 as one launch), and issues launch j on
+ * the context's own stream j % n_streams (1..8; bu_context_stream) under the shared launch policy, whatever the context's policy is.
+ * It only ENQUEUES: bu_context_synchronize(ctx), or synchronising those streams, waits for the results, and nothing the caller enqueued on
+ * other streams is waited for -- inputs and the status word must be ready before the call (bu_status_word_reset + a synchronise).  The streams
+ * need a hardware queue each (bu_context_probe_streams).  Results, status reporting and argument rules are those of the call above. */
+bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
+                                             const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
+                                             const uint64_t* index_base, uint64_t* d_status, int n_streams);
 
 /* value a status word must hold before the launches that report into it (all ones) */
 #define BU_STATUS_WORD_CLEAR 0xFFFFFFFFFFFFFFFFull

@@ -121,6 +121,11 @@ extern "C" {
     pub fn bu_uastc_transcode_batch_device(ctx: *mut bu_context, target: c_int, n_slices: usize, d_in: *const *const c_void, n_blocks: *const usize,
                                            d_out: *const *mut c_void, blocks_per_row: usize, index_base: *const u64, d_status: *mut u64,
                                            stream: *mut c_void) -> c_int;
+    // the same loop as a pipeline of launches on the context's own streams 0..n_streams-1 (shared launch policy); only enqueues:
+    // bu_context_synchronize waits
+    pub fn bu_uastc_transcode_batch_in_flight(ctx: *mut bu_context, target: c_int, n_slices: usize, d_in: *const *const c_void, n_blocks: *const usize,
+                                              d_out: *const *mut c_void, blocks_per_row: usize, index_base: *const u64, d_status: *mut u64,
+                                              n_streams: c_int) -> c_int;
     pub fn bu_status_word_reset(ctx: *mut bu_context, d_status: *mut u64, stream: *mut c_void) -> c_int;
     pub fn bu_status_word_decode(word: u64, first_bad_block: *mut u64) -> c_int;
     pub fn bu_host_alloc(ctx: *mut bu_context, bytes: usize, out_ptr: *mut *mut c_void) -> c_int;

@@ -46,7 +46,7 @@ def test_shared_policy_known_answers_both_layouts_and_first_error(golden, target
         ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr)
         torch.cuda.synchronize()
         got = _unrgba(d_out.cpu().numpy(), rows, bpr) if target == "rgba" else d_out.cpu().numpy()
-        assert (got == golden[target][idx]).all(), (target, bpr, rows)
+        assert (got == golden[target][idx]).all(), (target, bpr)
         bad_hi, bad_lo = n - 2, (n * 3) // 8 + 5
         blocks[bad_hi, 0] = 69  # the one invalid 7-bit mode code (uastc.rs:560-577)
         blocks[bad_lo, 0] = 69
@@ -57,7 +57,7 @@ def test_shared_policy_known_answers_both_layouts_and_first_error(golden, target
         torch.cuda.synchronize()
         with pytest.raises(BasisuError) as e:
             ctx.status_word_check(int(st.item()))
-        assert e.value.status == _lib.ERR_INVALID_MODE and e.value.first_bad_block == bad_lo, (target, bpr, rows)
+        assert e.value.status == _lib.ERR_INVALID_MODE and e.value.first_bad_block == bad_lo, (target, bpr)
         got = _unrgba(d_out.cpu().numpy(), rows, bpr) if target == "rgba" else d_out.cpu().numpy()
         assert not got[bad_lo].any() and not got[bad_hi].any()  # a failing block's result is zeros under either policy
     ctx.close()
@@ -386,4 +386,93 @@ def test_probe_streams_sees_queue_sharing():
     assert ctx._lib.bu_context_probe_streams(ctx.handle, 0, ctypes.byref(k)) == _lib.ERR_ARGUMENT
     assert ctx._lib.bu_context_probe_streams(ctx.handle, 9, ctypes.byref(k)) == _lib.ERR_ARGUMENT
     assert ctx._lib.bu_context_probe_streams(ctx.handle, 4, None) == _lib.ERR_ARGUMENT
+    ctx.close()
+
+
+@pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2", "rgba"])
+def test_batch_in_flight_mixed_slices(golden, target):
+    """bu_uastc_transcode_batch_in_flight: large slices in separate allocations (one launch each), a crowd of small ones (grouped into table
+    launches of about 2^20 blocks) and a ragged one, round-robin over the context's four streams under the shared policy.  Same bytes as the
+    known answers after bu_context_synchronize; two failing blocks in different launches report the lower batch-wide index."""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    t, bb = TB[target]
+    bpr = 512
+    sizes = [1 << 20, bpr * 601, 1 << 20] + [65536] * 40 + [bpr * 1024 + bpr * 3, 4096, bpr * 2048]
+    idx = [synth.gold_indices(n, seed=2500 + k) for k, n in enumerate(sizes)]
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    want = torch.from_numpy(golden[target]).cuda()
+    ins = [gu[torch.from_numpy(i).cuda()].contiguous() for i in idx]
+    outs = [torch.zeros((n, bb), dtype=torch.uint8, device="cuda") for n in sizes]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()  # inputs, zeroed outputs and the status word are ready before the call: it waits for nobody
+    ctx.transcode_batch_in_flight(t, ins, sizes, outs, blocks_per_row=bpr, d_status=status, n_streams=4)
+    ctx.synchronize()
+    ctx.status_word_check(int(status.item()))
+    for k, n in enumerate(sizes):
+        got = outs[k]
+        if target == "rgba":
+            got = got.view(n // bpr, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64)
+        assert torch.equal(got, want[torch.from_numpy(idx[k]).cuda()]), (target, k)
+    ins[2][999, 0] = 69      # in a large slice
+    ins[20][5, 0] = 69       # in a grouped small one, further on in the batch
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    ctx.transcode_batch_in_flight(t, ins, sizes, outs, blocks_per_row=bpr, d_status=status, n_streams=3)
+    ctx.synchronize()
+    with pytest.raises(BasisuError) as e:
+        ctx.status_word_check(int(status.item()))
+    assert e.value.first_bad_block == sum(sizes[:2]) + 999
+    # argument checks: stream count, RGBA32 without a pitch
+    lib = ctx._lib
+    n_s, pi, pn, po = _batch_args(ins, outs, sizes)
+    assert lib.bu_uastc_transcode_batch_in_flight(ctx.handle, t, n_s, pi, pn, po, bpr, None, None, 0) == _lib.ERR_ARGUMENT
+    assert lib.bu_uastc_transcode_batch_in_flight(ctx.handle, t, n_s, pi, pn, po, bpr, None, None, 9) == _lib.ERR_ARGUMENT
+    assert lib.bu_uastc_transcode_batch_in_flight(ctx.handle, _lib.RGBA32, n_s, pi, pn, po, 0, None, None, 4) == _lib.ERR_ARGUMENT
+    assert lib.bu_uastc_transcode_batch_in_flight(ctx.handle, t, 0, None, None, None, bpr, None, None, 4) == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("target,bpr", [("bc7", 1024), ("bc7", 0), ("rgba", 1024), ("etc1", 192), ("rgba", 192)])
+def test_batch_in_flight_cuts_one_contiguous_array_into_pieces(golden, target, bpr):
+    """a texture array in ONE allocation (contiguous slices merge into one run) makes fewer launches than streams: the run is cut into equal
+    pieces on tile / block-row boundaries, one per stream, block indices numbered through.  Same bytes as one plain launch's known answers,
+    for a pitch that allows rectangular tiles (1024), for none, and for one that is no multiple of 64 (192: pieces end on whole block rows)."""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    t, bb = TB[target]
+    n_slices, per = (8, 192 * 4096) if bpr == 192 else (8, 1 << 20)
+    n = n_slices * per
+    idx = synth.gold_indices(n, seed=3100)
+    gu = torch.from_numpy(golden["uastc"]).cuda()
+    want = torch.from_numpy(golden[target]).cuda()
+    whole_in = gu[torch.from_numpy(idx).cuda()].contiguous()
+    whole_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+    ins = [whole_in[k * per:(k + 1) * per] for k in range(n_slices)]
+    outs = [whole_out[k * per:(k + 1) * per] for k in range(n_slices)]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    ctx.transcode_batch_in_flight(t, ins, [per] * n_slices, outs, blocks_per_row=bpr, d_status=status, n_streams=4)
+    ctx.synchronize()
+    ctx.status_word_check(int(status.item()))
+    got = whole_out
+    if target == "rgba":
+        got = got.view(n // bpr, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64)
+    assert torch.equal(got, want[torch.from_numpy(idx).cuda()]), (target, bpr)
+    whole_in[n - 5, 0] = 69  # in the last piece: the index is the array's
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    ctx.transcode_batch_in_flight(t, ins, [per] * n_slices, outs, blocks_per_row=bpr, d_status=status, n_streams=4)
+    ctx.synchronize()
+    with pytest.raises(BasisuError) as e:
+        ctx.status_word_check(int(status.item()))
+    assert e.value.first_bad_block == n - 5
     ctx.close()

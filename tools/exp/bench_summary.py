@@ -11,7 +11,7 @@ for f in sys.argv[1:]:
     t = r.get("rocprofv3_this_run") or {}
     print("  trace:", {k: v for k, v in t.items() if k != "source"})
     for k in ("one_launch_at_a_time", "launches_in_flight_matrix", "atlases_2_one_launch", "uastc_to_astc", "uastc_to_etc1", "uastc_to_etc2", "uastc_to_rgba32",
-              "array512_one_launch", "copy_ceiling", "coherent_atlas"):
+              "array512_one_launch", "array512_four_launches_in_flight", "array512_one_call_in_flight", "batch_8_atlases_separate_allocations", "batch_in_flight_512_atlases_one_call", "copy_ceiling", "coherent_atlas"):
         v = e.get(k)
         if isinstance(v, dict):
             v = {a: b for a, b in v.items() if a not in ("note", "per_launch")}
