@@ -59,7 +59,15 @@ def run(L, h, pol, ns, first, lead, launches):
     ev, host, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
     st = L.bu_time_uastc_launches_streams_window(h, t, ip, op, NBUF, first, N, a.bpr, lead, launches, (ns if a.tail < 0 else a.tail) if lead else 0, ns, None, ctypes.byref(ev), ctypes.byref(host), None, ctypes.byref(late))
     assert st == 0, st
-    return max(ev.value, host.value) / launches * 1e3, ev.value / launches * 1e3, late.value
+    # the window holds `launches` completions only if the streams ran in step: start events within a few periods of each other
+    oos = False
+    if hasattr(L, "bu_time_last_window_streams") and ns > 1:
+        a_, b_, n_ = (ctypes.c_float * 8)(), (ctypes.c_float * 8)(), ctypes.c_int(0)
+        L.bu_time_last_window_streams.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+        if L.bu_time_last_window_streams(h, a_, b_, ctypes.byref(n_)) == 0:
+            st_ = [a_[i] for i in range(n_.value) if a_[i] >= 0]
+            oos = bool(st_) and (max(st_) - min(st_)) * 1e3 > 16 * (ev.value / launches * 1e3)
+    return max(ev.value, host.value) / launches * 1e3, ev.value / launches * 1e3, (late.value, oos)
 def check():
     torch.cuda.synchronize()
     bad = 0
@@ -85,5 +93,5 @@ for r in range(a.rounds):
             while a.prewarm_ms and (_t.perf_counter() - t0) * 1e3 < a.prewarm_ms: run(L, h, p, ns, first, 0, 256)
             us, ev, late = run(L, h, p, ns, first, a.lead, a.launches)
             first = (first + a.lead + a.launches) % NBUF
-            res.append("S%d %.2f (ev %.2f%s)%s" % (ns, us, ev, " LATE" if late else "", "" if bad[(name, ns)] == 0 else " WRONG:%d" % bad[(name, ns)]))
+            res.append("S%d %.2f (ev %.2f%s%s)%s" % (ns, us, ev, " LATE" if late[0] else "", " OUT-OF-STEP: not a period" if late[1] else "", "" if bad[(name, ns)] == 0 else " WRONG:%d" % bad[(name, ns)]))
         print("%-22s %s" % (name, "  ".join(res)), flush=True)
