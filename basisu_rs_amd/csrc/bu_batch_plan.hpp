@@ -1,0 +1,105 @@
+// Host-side planning of the batch entry points (bu_capi_slice.hpp): slices -> runs -> launches.  No HIP in here: the test-only host
+// build (tests/host_emul) compiles it as it is and tests/test_batch_plan.py checks its invariants without a GPU.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+// a run = slices that are contiguous in input, output and block numbering
+struct BuRun {
+    const uint8_t* in;
+    uint8_t* out;
+    size_t n;
+    uint64_t base;
+};
+
+// one launch of the pipelined batch call: `count` consecutive runs from `first` -- an index into the run list or, from runs.size() on,
+// into the list of pieces cut out of large runs
+struct BuLaunchGroup {
+    size_t first, count, blocks;
+};
+
+// slices merged into runs: slice i = n_blocks[i] blocks at d_in[i] -> d_out[i], numbered from index_base[i] (NULL: back to back from 0);
+// empty slices vanish, a slice that continues its predecessor in input, output (block_bytes per block) and numbering extends its run
+inline void bu_merge_runs(size_t n_slices, const void* const* d_in, const size_t* n_blocks, void* const* d_out, size_t block_bytes,
+                          const uint64_t* index_base, std::vector<BuRun>& runs)
+{
+    uint64_t next_base = 0;
+    for (size_t i = 0; i < n_slices; i++) {
+        const uint64_t base = index_base ? index_base[i] : next_base;
+        next_base = base + n_blocks[i];
+        if (n_blocks[i] == 0) continue;
+        const uint8_t* in = static_cast<const uint8_t*>(d_in[i]);
+        uint8_t* out = static_cast<uint8_t*>(d_out[i]);
+        if (!runs.empty()) {
+            BuRun& r = runs.back();
+            if (r.in + r.n * 16 == in && r.out + r.n * block_bytes == out && r.base + r.n == base) {
+                r.n += n_blocks[i];
+                continue;
+            }
+        }
+        runs.push_back(BuRun{in, out, n_blocks[i], base});
+    }
+}
+
+// The launches of bu_uastc_transcode_batch_in_flight.
+// 1. Consecutive runs are grouped into launches of about 2^20 blocks (below that a launch is bound by the host's ~4 us): a group is closed
+//    when it holds 2^20 blocks or `max_runs` runs, a run of 2^20 blocks or more is a group of its own.
+// 2. A batch that makes fewer launches than streams has its largest single-run groups cut into equal pieces, as long as a piece keeps at
+//    least 2^20 blocks.  Pieces end on tile boundaries: 1024 blocks, and with a pitch 16 block rows of it (the rectangular tiles of the
+//    kernels; RGBA32 needs whole block rows) -- lcm(16 * blocks_per_row, 1024).
+// Every block of every run is in exactly one launch, in order; pieces carry their share of the run's block numbering.
+inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, size_t blocks_per_row, size_t block_bytes, size_t max_runs,
+                              std::vector<BuLaunchGroup>& groups, std::vector<BuRun>& pieces)
+{
+    constexpr size_t GROUP_BLOCKS = (size_t)1 << 20;
+    groups.clear();
+    pieces.clear();
+    for (size_t i = 0; i < runs.size();) {
+        BuLaunchGroup g{i, 0, 0};
+        while (i < runs.size() && g.count < max_runs && (g.count == 0 || g.blocks + runs[i].n <= GROUP_BLOCKS)) {
+            g.blocks += runs[i].n;
+            g.count++;
+            i++;
+            if (g.blocks >= GROUP_BLOCKS) break;
+        }
+        groups.push_back(g);
+    }
+    if (groups.empty() || groups.size() >= (size_t)n_streams) return;
+    size_t align = 1024;
+    if (blocks_per_row) {
+        size_t a = blocks_per_row * 16, b = 1024;  // gcd
+        while (b) {
+            const size_t t = a % b;
+            a = b;
+            b = t;
+        }
+        align = blocks_per_row * 16 / a * 1024;
+    }
+    std::vector<BuLaunchGroup> cut;
+    size_t spare = (size_t)n_streams - groups.size();  // additional launches wanted
+    const size_t n_groups = groups.size();
+    for (const BuLaunchGroup& g : groups) {
+        size_t n_pieces = 1;
+        if (g.count == 1 && spare > 0) {
+            n_pieces = 1 + (spare + n_groups - 1) / n_groups;
+            while (n_pieces > 1 && ((g.blocks / n_pieces) / align) * align < GROUP_BLOCKS) n_pieces--;
+        }
+        if (n_pieces <= 1) {
+            cut.push_back(g);
+            continue;
+        }
+        const BuRun r = runs[g.first];
+        const size_t per = ((r.n + n_pieces - 1) / n_pieces + align - 1) / align * align;
+        size_t made = 0;
+        for (size_t done = 0; done < r.n; done += per) {
+            const size_t n = r.n - done < per ? r.n - done : per;
+            pieces.push_back(BuRun{r.in + done * 16, r.out + done * block_bytes, n, r.base + done});
+            cut.push_back(BuLaunchGroup{runs.size() + pieces.size() - 1, 1, n});
+            made++;
+        }
+        spare -= made - 1 < spare ? made - 1 : spare;
+    }
+    groups.swap(cut);
+}

@@ -181,14 +181,6 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
 
 }  // extern "C"
 namespace {
-// a run = slices that are contiguous in input, output and block numbering
-struct BuRun {
-    const uint8_t* in;
-    uint8_t* out;
-    size_t n;
-    uint64_t base;
-};
-
 // argument check of the batch entry points, then the slices merged into runs
 bu_status bu_batch_runs(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in, const size_t* n_blocks, void* const* d_out,
                         size_t blocks_per_row, const uint64_t* index_base, std::vector<BuRun>& runs)
@@ -200,22 +192,7 @@ bu_status bu_batch_runs(bu_context* ctx, bu_target target, size_t n_slices, cons
         if (n_blocks[i] && (!d_in[i] || !d_out[i])) return BU_ERR_ARGUMENT;
         if (target == BU_TARGET_RGBA32 && n_blocks[i] % blocks_per_row != 0) return BU_ERR_ARGUMENT;
     }
-    uint64_t next_base = 0;
-    for (size_t i = 0; i < n_slices; i++) {
-        const uint64_t base = index_base ? index_base[i] : next_base;
-        next_base = base + n_blocks[i];
-        if (n_blocks[i] == 0) continue;
-        const uint8_t* in = static_cast<const uint8_t*>(d_in[i]);
-        uint8_t* out = static_cast<uint8_t*>(d_out[i]);
-        if (!runs.empty()) {
-            BuRun& r = runs.back();
-            if (r.in + r.n * 16 == in && r.out + r.n * bb == out && r.base + r.n == base) {
-                r.n += n_blocks[i];
-                continue;
-            }
-        }
-        runs.push_back(BuRun{in, out, n_blocks[i], base});
-    }
+    bu_merge_runs(n_slices, d_in, n_blocks, d_out, bb, index_base, runs);
     return BU_OK;
 }
 
@@ -308,65 +285,14 @@ bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, 
     BU_HIP(ctx, hipSetDevice(ctx->device));
     st = bu_ctx_streams(ctx, n_streams);
     if (st) return st;
-    const size_t bb = bu_target_block_bytes(target);
-    // 1. groups of consecutive runs, closed at about 2^20 blocks (one launch per group: below that a launch is bound by the host's ~4 us)
-    constexpr size_t GROUP_BLOCKS = (size_t)1 << 20;
-    struct Group {
-        size_t first, count, blocks;
-    };
-    std::vector<Group> groups;
-    for (size_t i = 0; i < runs.size();) {
-        Group g{i, 0, 0};
-        while (i < runs.size() && g.count < (size_t)BU_MULTI_RUNS && (g.count == 0 || g.blocks + runs[i].n <= GROUP_BLOCKS)) {
-            g.blocks += runs[i].n;
-            g.count++;
-            i++;
-            if (g.blocks >= GROUP_BLOCKS) break;
-        }
-        groups.push_back(g);
-    }
-    // 2. fewer launches than streams: the largest single-run groups are cut into equal pieces on tile boundaries (rectangular tiles: 16
-    //    block rows; RGBA32: whole block rows) as long as a piece keeps at least 2^20 blocks
-    std::vector<BuRun> extra;  // the pieces (groups index into `runs` or, with first >= runs.size(), into `extra`)
-    if (groups.size() < (size_t)n_streams) {
-        size_t align = 1024;
-        if (blocks_per_row) {
-            size_t a = blocks_per_row * 16, b = 1024;  // lcm(16 rows, 1024 blocks)
-            while (b) {
-                const size_t t = a % b;
-                a = b;
-                b = t;
-            }
-            align = blocks_per_row * 16 / a * 1024;
-        }
-        std::vector<Group> cut;
-        size_t spare = (size_t)n_streams - groups.size();  // additional launches wanted
-        for (const Group& g : groups) {
-            size_t pieces = 1;
-            if (g.count == 1 && spare > 0) {
-                const size_t want = 1 + (spare + groups.size() - 1) / groups.size();
-                pieces = want;
-                while (pieces > 1 && ((g.blocks / pieces) / align) * align < GROUP_BLOCKS) pieces--;
-            }
-            if (pieces <= 1) {
-                cut.push_back(g);
-                continue;
-            }
-            const BuRun r = runs[g.first];
-            size_t per = ((r.n + pieces - 1) / pieces + align - 1) / align * align;
-            for (size_t done = 0; done < r.n; done += per) {
-                const size_t n = r.n - done < per ? r.n - done : per;
-                extra.push_back(BuRun{r.in + done * 16, r.out + done * bb, n, r.base + done});
-                cut.push_back(Group{runs.size() + extra.size() - 1, 1, n});
-            }
-            spare -= pieces - 1 < spare ? pieces - 1 : spare;
-        }
-        groups.swap(cut);
-    }
+    // launches of about 2^20 blocks or more; a batch with fewer launches than streams has its largest runs cut (bu_batch_plan.hpp)
+    std::vector<BuRun> extra;
+    std::vector<BuLaunchGroup> groups;
+    bu_plan_in_flight(runs, n_streams, blocks_per_row, bu_target_block_bytes(target), (size_t)BU_MULTI_RUNS, groups, extra);
     // 3. launch j on stream j % n_streams, shared policy (a single launch gets the exclusive shape: nothing runs beside it)
     const int policy = groups.size() > 1 && n_streams > 1 ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE;
     for (size_t j = 0; j < groups.size(); j++) {
-        const Group& g = groups[j];
+        const BuLaunchGroup& g = groups[j];
         const BuRun* first = g.first >= runs.size() ? &extra[g.first - runs.size()] : &runs[g.first];
         st = bu_launch_runs(ctx, target, first, g.count, blocks_per_row, d_status, ctx->extra_streams[j % (size_t)n_streams], policy);
         if (st) return st;

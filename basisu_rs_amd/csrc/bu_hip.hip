@@ -26,6 +26,7 @@
 
 #include "../../include/basisu_hip.h"
 #include "bu_basis.hpp"
+#include "bu_batch_plan.hpp"   // slices -> runs -> launches of the batch entry points (host only)
 #include "bu_uastc_dispatch.hpp"
 
 #include "bu_kernels.hpp"        // device code
