@@ -192,6 +192,7 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
         return BU_OK;
     };
     const int total = lead + launches + tail;
+    const auto enq0 = std::chrono::steady_clock::now();
     if (ctx->time_enqueue_threads.load(std::memory_order_relaxed) && n_streams > 1) {
         // one host thread per stream (bu_time_set_enqueue_threads): the order inside every stream is the one below, the order between
         // streams is whatever the threads make it -- the way a caller with one thread per stream drives the context
@@ -224,6 +225,8 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
             if (st) return st;
         }
     }
+    ctx->win_enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - enq0).count();
+    ctx->win_enqueued = total;
     // host bracket: from every start event seen complete to every end event seen complete
     std::chrono::steady_clock::time_point t0, t1, t;
     bool first_query = true;
@@ -286,6 +289,16 @@ bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, floa
         out_end_ms[i] = i < ctx->win_streams ? ctx->win_end_ms[i] : -1.0f;
     }
     *out_n_streams = ctx->win_streams;
+    return BU_OK;
+}
+
+// host time the context's LAST streams window spent enqueueing (launches and events, before it started to wait) and how many launches that
+// was: *out_ms / *out_launches is what one enqueue costs this host -- above the pipeline's period the host, not the chip, sets the pace
+bu_status bu_time_last_window_enqueue(bu_context* ctx, float* out_ms, int* out_launches)
+{
+    if (!ctx || !out_ms || !out_launches) return BU_ERR_ARGUMENT;
+    *out_ms = ctx->win_enqueue_ms;
+    *out_launches = ctx->win_enqueued;
     return BU_OK;
 }
 

@@ -28,6 +28,8 @@ struct bu_context {
     std::atomic<int> launch_policy{0};  // BU_POLICY_*: how much of a CU one large launch of the mode-sorted kernel takes (bu_context_set_launch_policy)
     float win_start_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, win_end_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last streams window: per-stream event times (bu_time_last_window_streams)
     int win_streams = 0;
+    float win_enqueue_ms = 0;  // host time the last streams window spent enqueueing its win_enqueued launches (and their events)
+    int win_enqueued = 0;
     std::atomic<int> time_enqueue_threads{0};  // bu_time_set_enqueue_threads: the streams windows enqueue from one host thread per stream
     std::atomic<bool> block_api_on_device{false};  // per-block API: host build of the block code (default) or a 1-block launch
     size_t etc1s_lds_limit = 0;  // what the device reports a workgroup may use, less a margin (bu_context_create)

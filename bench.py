@@ -850,7 +850,11 @@ def run_atlas4096(env):
         a_, b_, n_ = (ctypes.c_float * 8)(), (ctypes.c_float * 8)(), ctypes.c_int(0)
         if lib.bu_time_last_window_streams(ctx.handle, a_, b_, ctypes.byref(n_)) != 0:
             return None
-        return {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
+        out_ = {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
+        ms_, k_ = ctypes.c_float(0), ctypes.c_int(0)
+        if lib.bu_time_last_window_enqueue(ctx.handle, ctypes.byref(ms_), ctypes.byref(k_)) == 0 and k_.value:
+            out_["host_enqueue_us_per_launch"] = round(ms_.value * 1e3 / k_.value, 3)  # (above the period the host would set the pace)
+        return out_
 
     def run_window(lead, launches, in_flight=None, tail=None):
         """the timed region: step i on context stream i % in_flight; `lead` untimed launches, start event per stream, `launches` timed ones, end event
