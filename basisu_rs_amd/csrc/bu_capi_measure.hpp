@@ -170,8 +170,10 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
         if (sst) return sst;
     }
     for (int i = 0; i < n_streams; i++) {
-        if (!ctx->ev_start[i]) BU_HIP(ctx, hipEventCreate(&ctx->ev_start[i]));
-        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreate(&ctx->ev_end[i]));
+        // timing-only events: no system-scope fence when they complete (hipEventDisableSystemFence) -- a default event writes the caches back and
+        // invalidates them, under the launches that are running beside it on the other streams; the streams are synchronised before the call returns
+        if (!ctx->ev_start[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_start[i], hipEventDisableSystemFence));
+        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_end[i], hipEventDisableSystemFence));
     }
     BuDrain drain(ctx);
     BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->extra_streams[0]));  // the reference point of every time below

@@ -371,7 +371,7 @@ bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_
     }
     std::lock_guard<std::mutex> g(ctx->lock);  // (ev0 / ev_end are the context's)
     for (int i = 0; i < n_streams; i++)
-        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreate(&ctx->ev_end[i]));
+        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_end[i], hipEventDisableSystemFence));  // (timing only, as in bu_streams_window)
     constexpr unsigned long long TICKS = 20000;  // 200 us of the 100 MHz clock
     BuDrain drain(ctx);
     float best = 0;
