@@ -1656,8 +1656,8 @@ def run_atlas4096(env):
                                                   "profiles/r05_rocprofv3_dispatch_floor_empty_and_5us_kernels.txt), so ONE enqueueing thread sets the pace at 7.5-8.1 us per completion; the trace pass "
                                                   "therefore enqueues from one host thread per stream (bu_time_set_enqueue_threads) and reads 6.3-6.4 us per completion over its steady stretches "
                                                   "(steady_period_ns; frac_by_rocprofv3_period is computed from it) -- still a profiled pipeline, 10-13 % slower than the unprofiled one.  Fed by one thread, the profiler's "
-                                                  "completion period equals that run's HIP-event period (7.83 against 8.00 us: profiles/r05_v8_rocprofv3_headline_trace_summary.txt; config 5 with "
-                                                  "2^23-block launches, where the profiler's cost does not matter: 175.6 against 174.6 us per array) -- the clocks agree, the profiler perturbs.  "
+                                                  "completion period equals that run's HIP-event period (9.97 against 10.14 us: profiles/r05_v10_rocprofv3_headline_trace_summary.txt; config 5 with "
+                                                  "2^23-block launches, where the profiler's cost does not matter: 175.7 against 174.8 us per array) -- the clocks agree, the profiler perturbs.  "
                                                   "This unprofiled run: HIP events and the host clock agree (timed_region.event_ms / host_ms); --steps 512 repeats it on a 3 ms window")
     if env.live_traffic[0] is not None:
         line["roofline"]["traffic"] = env.live_traffic[0]
