@@ -295,7 +295,8 @@ bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, floa
 }
 
 // host time the context's LAST streams window spent enqueueing (launches and events, before it started to wait) and how many launches that
-// was: *out_ms / *out_launches is what one enqueue costs this host -- above the pipeline's period the host, not the chip, sets the pace
+// was: *out_ms / *out_launches is an upper bound of what one enqueue costs this host (waits for space in a full hardware queue are inside) -- at
+// or above the pipeline's period the host, not the chip, may be setting the pace
 bu_status bu_time_last_window_enqueue(bu_context* ctx, float* out_ms, int* out_launches)
 {
     if (!ctx || !out_ms || !out_launches) return BU_ERR_ARGUMENT;

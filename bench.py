@@ -853,7 +853,7 @@ def run_atlas4096(env):
         out_ = {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
         ms_, k_ = ctypes.c_float(0), ctypes.c_int(0)
         if lib.bu_time_last_window_enqueue(ctx.handle, ctypes.byref(ms_), ctypes.byref(k_)) == 0 and k_.value:
-            out_["host_enqueue_us_per_launch"] = round(ms_.value * 1e3 / k_.value, 3)  # (above the period the host would set the pace)
+            out_["host_enqueue_us_per_launch"] = round(ms_.value * 1e3 / k_.value, 3)  # (an upper bound: waits for queue space are inside; at the period or above, the host may be setting the pace)
         return out_
 
     def run_window(lead, launches, in_flight=None, tail=None):

@@ -416,7 +416,8 @@ bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on);
  * window "latest start to latest end" then no longer brackets `launches` completions -- callers check the spread. */
 bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, float* out_end_ms, int* out_n_streams);
 /* host time the context's LAST streams window spent enqueueing (launches and events, before it began to wait) and the number of launches:
- * *out_ms / *out_launches = what one enqueue costs this host; above the pipeline's period the host sets the pace, not the chip */
+ * *out_ms / *out_launches = an UPPER bound of what one enqueue costs this host (waits for space in a full hardware queue are inside); at or
+ * above the pipeline's period the host, not the chip, may be setting the pace */
 bu_status bu_time_last_window_enqueue(bu_context* ctx, float* out_ms, int* out_launches);
 #define BU_TIME_COPY_CEILING 100 /* as `target` of the call below: the uint4 -> uint4 copy kernel (bu_copy_ceiling_device) in place of a transcode */
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
