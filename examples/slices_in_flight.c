@@ -2,7 +2,10 @@
  * (src/basis.rs:246-257: one transcode per slice, one after another) with the slices resident on the GPU and FOUR of them in
  * flight -- each slice is one launch, slice i goes to the context's stream i % 4, under the shared launch policy.
  *
- *   slices_in_flight <astc|bc7|etc1|etc2> <in.uastc> <n_slices> <out.bin>
+ *   slices_in_flight <astc|bc7|etc1|etc2> <in.uastc> <n_slices> <out.bin> [batch]
+ *
+ * With `batch` as a fifth argument the loop is ONE call of bu_uastc_transcode_batch_in_flight (the library merges, groups and cuts the slices and issues
+ * the launches on its four streams itself); without it the program issues one launch per slice on the streams it got from bu_context_stream.
  *
  * in.uastc holds n_slices equal slices of raw UASTC blocks (16 bytes each) back to back; out.bin receives the transcoded
  * slices back to back.  Exit code: 0 = done, 2 = usage / file errors, otherwise 10 + bu_status.  No HIP header is needed:
@@ -39,8 +42,8 @@ int main(int argc, char** argv)
     bu_status st;
     FILE* fp;
 
-    if (argc != 5) {
-        fprintf(stderr, "usage: %s <astc|bc7|etc1|etc2> <in.uastc> <n_slices> <out.bin>\n", argv[0]);
+    if (argc != 5 && !(argc == 6 && !strcmp(argv[5], "batch"))) {
+        fprintf(stderr, "usage: %s <astc|bc7|etc1|etc2> <in.uastc> <n_slices> <out.bin> [batch]\n", argv[0]);
         return 2;
     }
     for (t = 0; t < 4; t++)
@@ -98,10 +101,27 @@ int main(int argc, char** argv)
     st = bu_status_word_reset(ctx, (uint64_t*)d_status, streams[0]);
     if (!st) st = bu_context_synchronize(ctx); /* the other streams must see the reset */
     if (st) return fail(ctx, "bu_status_word_reset", st);
-    for (i = 0; i < (size_t)n_slices; i++) {
-        st = bu_uastc_transcode_device(ctx, target, (const uint8_t*)d_in + i * slice_bytes, n_blocks, (uint8_t*)d_out + i * out_slice_bytes, 0,
-                                       (uint64_t)i * n_blocks, (uint64_t*)d_status, streams[i % STREAMS]);
-        if (st) return fail(ctx, "bu_uastc_transcode_device", st);
+    if (argc == 6) { /* the whole loop in one call: slice table in, launches on the context's streams out */
+        const void** ins = (const void**)malloc(sizeof(void*) * (size_t)n_slices);
+        void** outs = (void**)malloc(sizeof(void*) * (size_t)n_slices);
+        size_t* counts = (size_t*)malloc(sizeof(size_t) * (size_t)n_slices);
+        if (!ins || !outs || !counts) return fail(ctx, "malloc", BU_ERR_ARGUMENT);
+        for (i = 0; i < (size_t)n_slices; i++) {
+            ins[i] = (const uint8_t*)d_in + i * slice_bytes;
+            outs[i] = (uint8_t*)d_out + i * out_slice_bytes;
+            counts[i] = n_blocks;
+        }
+        st = bu_uastc_transcode_batch_in_flight(ctx, target, (size_t)n_slices, ins, counts, outs, 0, NULL, (uint64_t*)d_status, STREAMS);
+        free(ins);
+        free(outs);
+        free(counts);
+        if (st) return fail(ctx, "bu_uastc_transcode_batch_in_flight", st);
+    } else {
+        for (i = 0; i < (size_t)n_slices; i++) {
+            st = bu_uastc_transcode_device(ctx, target, (const uint8_t*)d_in + i * slice_bytes, n_blocks, (uint8_t*)d_out + i * out_slice_bytes, 0,
+                                           (uint64_t)i * n_blocks, (uint64_t*)d_status, streams[i % STREAMS]);
+            if (st) return fail(ctx, "bu_uastc_transcode_device", st);
+        }
     }
     st = bu_context_synchronize(ctx);
     if (st) return fail(ctx, "bu_context_synchronize", st);

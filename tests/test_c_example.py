@@ -110,10 +110,12 @@ def test_slices_in_flight_compiles_as_c99_and_fails_loudly_without_a_device(tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["batch"]])
 @pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2"])
-def test_slices_in_flight_output_equals_the_known_answers(tmp_path, golden, target):
+def test_slices_in_flight_output_equals_the_known_answers(tmp_path, golden, target, mode):
     """ten slices of 300 000 blocks (large launches: the shared policy's shapes), four in flight on the context's streams, joined by
-    bu_context_synchronize; then a failing block in slice 7: the array-wide index and the reference's message"""
+    bu_context_synchronize -- issued by the program slice by slice, and (`batch`) by ONE call of bu_uastc_transcode_batch_in_flight, which
+    merges the contiguous slices and cuts the run into pieces; then a failing block in slice 7: the array-wide index and the reference's message"""
     _build2()
     n_slices, n = 10, 300000
     idx = synth.gold_indices(n_slices * n, seed=22)
@@ -121,12 +123,12 @@ def test_slices_in_flight_output_equals_the_known_answers(tmp_path, golden, targ
     inp, outp = tmp_path / "a.uastc", tmp_path / "o.bin"
     inp.write_bytes(blocks.tobytes())
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
-    r = subprocess.run([EXE2, target, str(inp), str(n_slices), str(outp)], capture_output=True, text=True, env=env)
+    r = subprocess.run([EXE2, target, str(inp), str(n_slices), str(outp)] + mode, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert outp.read_bytes() == golden[target][idx].tobytes()
     blocks[7 * n + 1234, 0] = 69  # the one invalid 7-bit mode code (uastc.rs:560-577)
     blocks[9 * n + 5, 0] = 69
     inp.write_bytes(blocks.tobytes())
-    r = subprocess.run([EXE2, target, str(inp), str(n_slices), str(outp)], capture_output=True, text=True, env=env)
+    r = subprocess.run([EXE2, target, str(inp), str(n_slices), str(outp)] + mode, capture_output=True, text=True, env=env)
     assert r.returncode == 10 + 1, r.stdout + r.stderr  # BU_ERR_INVALID_MODE
     assert "block %d of the array (slice 7)" % (7 * n + 1234) in r.stderr
