@@ -53,6 +53,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ETC1S_UNPINNED = "unpinned: the reference holds no ETC1S / BasisLZ vectors (tests/corpus_tests.rs:54-73 are #[ignore]d, the corpus absent); checked against the oracle's reading of the source"
 
 
+IN_STEP_PERIODS = 16  # start events of a window's streams further apart than this many launch periods: the streams are not in step
+
+
+def streams_out_of_step(streams, period_us, in_flight, queue_sharing=1):
+    """(out_of_step, start-event spread in us) of a pipelined window.  `streams` = {"start_us": [...], "end_us": [...]} per stream (-1: a stream
+    without timed launches), from bu_time_last_window_streams.  A window "latest start event -> latest end event" holds its K completions only
+    while the streams run in step: their start events then lie in_flight - 1 periods apart, give or take a burst.  Streams that share a hardware
+    queue (`queue_sharing` > 1, bu_context_probe_streams) run at a fraction of the others' pace and end up thousands of microseconds behind."""
+    if not streams or in_flight <= 1:
+        return False, 0.0
+    st = [x for x in streams["start_us"] if x >= 0]
+    spread = (max(st) - min(st)) if st else 0.0
+    return bool(spread > IN_STEP_PERIODS * period_us or queue_sharing > 1), spread
+
+
 def pmc_traffic():
     """HBM bytes per launch of the BC7 kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE with the
     gfx950 x2 correction + WRITE_SIZE; tools/gpu_pmc.sh), or None when no summary is committed"""
@@ -711,8 +726,8 @@ def run_array512(env):
     # the streams have to be in step for the window to hold `steps` completions of every stream (run_atlas4096 has the story): start events more than
     # 16 launch periods apart mean two streams share a hardware queue -- then the range is timed again as ONE launch per step on one stream
     timed_streams = last_streams[0]
-    spread_us = (max(timed_streams["start_us"]) - min(timed_streams["start_us"])) if (timed_streams and P > 1) else 0.0
-    oos = torch.tensor([1.0 if (spread_us > 16 * ev_ms * 1e3 / (args.steps * P) or queue_sharing > 1) else 0.0], dtype=torch.float64, device=dev)
+    oos_, spread_us = streams_out_of_step(timed_streams, ev_ms * 1e3 / (args.steps * P), P, queue_sharing)
+    oos = torch.tensor([1.0 if oos_ else 0.0], dtype=torch.float64, device=dev)
     if env.use_dist:
         dist.all_reduce(oos, op=dist.ReduceOp.MAX)
     out_of_step = bool(oos.item() > 0)
@@ -987,8 +1002,8 @@ def run_atlas4096(env):
         ks_ = {(lead + j) % args.in_flight: ks_[j] for j in range(args.in_flight)}
         rate_ = sum(ks_[s_] / (sk_["end_us"][s_] - sk_["start_us"][s_]) for s_ in range(args.in_flight) if sk_["start_us"][s_] >= 0 and sk_["end_us"][s_] > sk_["start_us"][s_])
         by_rates_us = round(1.0 / rate_, 3) if rate_ > 0 else None
-    start_spread_us = (max(sk_["start_us"]) - min(x for x in sk_["start_us"] if x >= 0)) if (sk_ and args.in_flight > 1) else 0.0
-    out_of_step = torch.tensor([1.0 if (start_spread_us > 16 * period_s * 1e6 or queue_sharing > 1) else 0.0], dtype=torch.float64, device=dev)
+    oos_, start_spread_us = streams_out_of_step(sk_, period_s * 1e6, args.in_flight, queue_sharing)
+    out_of_step = torch.tensor([1.0 if oos_ else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(out_of_step, op=dist.ReduceOp.MAX)
     out_of_step = bool(out_of_step.item() > 0) and not args.enqueue_threads  # (with --enqueue-threads the figure is the strict bracket already)

@@ -204,3 +204,26 @@ def test_bench_live_traffic_falls_back_without_a_gpu():
         assert bench.live_traffic() in ((None, "this run is itself being profiled", None), (None, "rocprofv3 not on PATH", None))
     finally:
         del os.environ["ROCPROF_TEST_MARKER"]
+
+
+def test_bench_in_step_rule_on_recorded_windows():
+    """bench.streams_out_of_step on per-stream start / end events as the GPU runs recorded them (profiles/r05_dist_branch_hw_queues.txt): a
+    pipeline in step, the same bench beside an RCCL communicator with 8 hardware queues (two streams 5.7 ms behind), config 5's four
+    2^23-block launches, a probe that found two streams on one queue, a stream without timed launches, one launch in flight"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    plain = {"start_us": [11501.1, 11518.8, 11529.5, 11534.5], "end_us": [11615.2, 11630.3, 11641.3, 11650.9]}
+    dist8 = {"start_us": [10411.3, 10418.6, 16101.9, 16116.7], "end_us": [10508.2, 10514.4, 16216.7, 16231.5]}
+    a512 = {"start_us": [2744.9, 2775.6, 2829.7, 2860.7], "end_us": [6214.3, 6270.5, 6299.9, 6350.5]}
+    oos, spread = bench.streams_out_of_step(plain, 5.82, 4)
+    assert not oos and abs(spread - 33.4) < 0.01
+    oos, spread = bench.streams_out_of_step(dist8, 5.74, 4)
+    assert oos and spread > 5000
+    oos, spread = bench.streams_out_of_step(a512, 174.5 / 4, 4)
+    assert not oos and abs(spread - 115.8) < 0.01
+    assert bench.streams_out_of_step(plain, 5.82, 4, queue_sharing=2)[0]          # the probe overrides a small spread
+    assert bench.streams_out_of_step({"start_us": [100.0, -1.0, 120.0, 110.0], "end_us": [200.0, -1.0, 220.0, 210.0]}, 5.8, 4) == (False, 20.0)
+    assert bench.streams_out_of_step(dist8, 5.74, 1) == (False, 0.0)             # one launch at a time: nothing to be in step with
+    assert bench.streams_out_of_step(None, 5.8, 4) == (False, 0.0)
+    assert bench.IN_STEP_PERIODS == 16
