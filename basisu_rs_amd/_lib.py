@@ -19,7 +19,7 @@ SYMBOLS = [
     "bu_context_create", "bu_context_destroy", "bu_status_string", "bu_last_error", "bu_target_block_bytes",
     "bu_uastc_transcode", "bu_uastc_decode_to_rgba",
     "bu_unpack_uastc_block_to_rgba", "bu_transcode_uastc_block_to_astc", "bu_transcode_uastc_block_to_bc7",
-    "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2", "bu_block_api_on_device", "bu_context_set_launch_policy", "bu_context_get_launch_policy", "bu_context_stream", "bu_context_synchronize", "bu_context_probe_streams",
+    "bu_transcode_uastc_block_to_etc1", "bu_transcode_uastc_block_to_etc2", "bu_block_api_on_device", "bu_context_set_launch_policy", "bu_context_get_launch_policy", "bu_context_stream", "bu_context_synchronize", "bu_context_probe_streams", "bu_context_query_in_flight", "bu_uastc_transcode_device_sync",
     "bu_uastc_transcode_device", "bu_uastc_transcode_batch_device", "bu_uastc_transcode_batch_in_flight", "bu_status_word_reset", "bu_status_word_decode", "bu_host_alloc", "bu_host_free",
     "bu_etc1s_selector_from_rows", "bu_etc1s_transcode_etc1_device", "bu_etc1s_decode_rgba_device",
     "bu_etc1s_transcode_etc1", "bu_etc1s_decode_rgba",
@@ -112,6 +112,10 @@ def load():
     lib.bu_context_synchronize.restype = c.c_int
     lib.bu_context_probe_streams.argtypes = [vp, c.c_int, c.POINTER(c.c_int)]
     lib.bu_context_probe_streams.restype = c.c_int
+    lib.bu_context_query_in_flight.argtypes = [vp, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    lib.bu_context_query_in_flight.restype = c.c_int
+    lib.bu_uastc_transcode_device_sync.argtypes = [vp, c.c_int, vp, sz, vp, sz, c.c_uint64, u64p]
+    lib.bu_uastc_transcode_device_sync.restype = c.c_int
     lib.bu_block_api_on_device.argtypes = [vp, c.c_int]
     lib.bu_block_api_on_device.restype = c.c_int
     lib.bu_uastc_transcode_device.argtypes = [vp, c.c_int, vp, sz, vp, sz, c.c_uint64, vp, vp]

@@ -125,21 +125,33 @@ class Context:
         return out[: n * 64]
 
     def set_launch_policy(self, shared):
-        """False (default) = BU_LAUNCH_EXCLUSIVE: a large launch fills the chip by itself; True = BU_LAUNCH_SHARED: it keeps at most half
-        of every CU so that launches queued on different streams run side by side (include/basisu_hip.h)."""
-        self._check(self._lib.bu_context_set_launch_policy(self._h, 1 if shared else 0))
+        """bu_context_set_launch_policy.  "auto" / None (the default of a new context) = BU_LAUNCH_AUTO: decided per call -- shared when the launch goes
+        to one of the context's own streams and another of them has work in flight, exclusive otherwise; False = BU_LAUNCH_EXCLUSIVE: a large launch
+        fills the chip by itself; True = BU_LAUNCH_SHARED: it keeps at most half of every CU so that launches queued on different streams run side by
+        side (include/basisu_hip.h)."""
+        code = 2 if shared is None or shared == "auto" else (1 if shared else 0)
+        self._check(self._lib.bu_context_set_launch_policy(self._h, code))
 
     def stream(self, index):
-        """the context's own stream `index` (0..7) as a raw hipStream_t value; streams 0..3 sit on different hardware queues"""
+        """the context's own stream `index` (0..7) as a raw hipStream_t value.  The library checks when it creates them (in groups of four) that each
+        has a hardware queue of its own and re-creates the group with CU masks if the runtime's queue pool (GPU_MAX_HW_QUEUES) is too small;
+        query_in_flight() tells what the context got"""
         p = ctypes.c_void_p(0)
         self._check(self._lib.bu_context_stream(self._h, int(index), ctypes.byref(p)))
         return p.value
 
     def probe_streams(self, n_streams=4):
-        """the largest number of the context's streams 0..n_streams-1 sharing one hardware queue in this process (1: each has its own)"""
+        """the largest number of the context's streams 0..n_streams-1 sharing one hardware queue in this process, measured now (1: each has its own)"""
         k = ctypes.c_int(0)
         self._check(self._lib.bu_context_probe_streams(self._h, int(n_streams), ctypes.byref(k)))
         return k.value
+
+    def query_in_flight(self, n_streams=4):
+        """bu_context_query_in_flight: (effective_streams, "pool" | "cu_mask") -- how many launches a pipeline over the context's streams
+        0..n_streams-1 really keeps in flight in this process, and which kind of stream the context created"""
+        eff, mode = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.bu_context_query_in_flight(self._h, int(n_streams), ctypes.byref(eff), ctypes.byref(mode)))
+        return eff.value, ("cu_mask" if mode.value == 1 else "pool")
 
     def block_api_on_device(self, enable):
         """Per-block API: False (default) = the library's own block code on the calling thread, True = a one-block kernel launch."""
@@ -191,6 +203,15 @@ class Context:
         st = self._lib.bu_uastc_transcode_device(self._h, int(fmt), _ptr(d_in), int(n_blocks), _ptr(d_out), int(blocks_per_row),
                                                  int(block_index_base), _ptr(d_status), _stream_ptr(stream))
         self._check(st)
+
+    def transcode_device_sync(self, fmt, d_in, n_blocks, d_out, blocks_per_row=0, block_index_base=0):
+        """bu_uastc_transcode_device_sync: a contiguous device-resident range, blocking; from 2^22 blocks on as launches in flight on the context's own
+        streams.  Returns the status word (STATUS_WORD_CLEAR or lowest failing block << 8 | status); never raises for a block error"""
+        word = ctypes.c_uint64(0)
+        st = self._lib.bu_uastc_transcode_device_sync(self._h, int(fmt), _ptr(d_in), int(n_blocks), _ptr(d_out), int(blocks_per_row), int(block_index_base),
+                                                      ctypes.byref(word))
+        self._check(st)
+        return word.value
 
     def transcode_batch_in_flight(self, fmt, d_ins, n_blocks, d_outs, blocks_per_row=0, index_base=None, d_status=None, n_streams=4):
         """bu_uastc_transcode_batch_in_flight: independent slices as a pipeline of launches on the context's own streams; only enqueues --

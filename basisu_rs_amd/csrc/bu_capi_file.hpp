@@ -684,7 +684,7 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
             BU_HIP(ctx, hipGetLastError());
         }
     }
-    bool used_extra = false;
+    int used_extra = 0;  // own streams 0..used_extra-1 carry pieces (forked behind the status reset, joined on the host)
     size_t run_piece_bytes = (size_t)16 << 20;  // upper bound; a run is cut into >= 4 pieces of >= 4 MiB (below)
     bool piece_fixed = false;
     if (const char* e = getenv("BU_RUN_PIECE_MIB")) {  // 0 disables the pieced pipeline
@@ -713,16 +713,21 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                     if (piece_bytes < ((size_t)4 << 20)) piece_bytes = (size_t)4 << 20;
                     if (piece_bytes > run_piece_bytes) piece_bytes = run_piece_bytes;
                 }
-                if (target != BU_READ_RGBA && direct_out && piece_bytes && run_bytes >= 2 * piece_bytes) {
+                // The same pieces with the output in DEVICE memory (pageable `out`), from a run of 2^22 blocks (64 MiB) on: piece i's upload and its
+                // launch share a stream, four streams carry the pieces round-robin under the shared launch policy, so that a piece's transcode lies
+                // under the next pieces' uploads and the launches of different pieces run side by side (the pipeline of the slice-level batch call,
+                // fed over PCIe); the streams are joined on the host in front of the status download.
+                const bool big_run = run_bytes / 16 >= bu_range_in_flight_min();
+                if (target != BU_READ_RGBA && (direct_out || big_run) && piece_bytes && run_bytes >= 2 * piece_bytes) {
                     pieced = true;
+                    const int n_ps = direct_out ? 2 : 4;  // streams that carry pieces: the context's internal one and n_ps - 1 of its own
                     {
-                        const bu_status sst = bu_ctx_streams(ctx, 1);
+                        const bu_status sst = bu_ctx_streams(ctx, n_ps - 1);
                         if (sst) return sst;
                     }
-                    if (!used_extra) {
+                    if (used_extra < n_ps - 1) {
                         BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));  // the status words are reset on the context stream
-                        BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[0], ctx->ev0, 0));
-                        used_extra = true;
+                        for (; used_extra < n_ps - 1; used_extra++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[used_extra], ctx->ev0, 0));
                     }
                     const bu_target pbt = target == BU_READ_ASTC ? BU_TARGET_ASTC : target == BU_READ_BC7 ? BU_TARGET_BC7
                                           : target == BU_READ_ETC1 ? BU_TARGET_ETC1 : BU_TARGET_ETC2;
@@ -730,11 +735,12 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                     size_t piece_no = 0;
                     for (size_t done = 0; done < run_bytes; done += piece_bytes, piece_no++) {
                         const size_t nbytes = run_bytes - done < piece_bytes ? run_bytes - done : piece_bytes;
-                        hipStream_t ps = (piece_no & 1) ? ctx->extra_streams[0] : ctx->stream;
+                        const size_t lane = piece_no % (size_t)n_ps;
+                        hipStream_t ps = lane ? ctx->extra_streams[lane - 1].load(std::memory_order_acquire) : ctx->stream;
                         BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k] + done, file + s.file_ofs + done, nbytes, hipMemcpyHostToDevice, ps));
                         crc_enqueue(d_in + in_off[k] + done, (size_t)s.file_ofs + done, nbytes, ps);
                         st = bu_launch_uastc(ctx, pbt, d_in + in_off[k] + done, nbytes / 16, d_out + im.offset + (done / 16) * obytes, 1, done / 16, d_status + k, ps,
-                                             BU_ZEROCOPY_GRID);
+                                             direct_out ? BU_ZEROCOPY_GRID : 0, direct_out ? BU_POLICY_EXCLUSIVE : BU_POLICY_SHARED);
                         if (st) return st;
                     }
                 } else {
@@ -759,15 +765,13 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
         if (st) return st;
     }
     lap("reserve + enqueue");
-    if (used_extra) {  // the status words are read on the context stream: it must see the second stream's kernels
-        BU_HIP(ctx, hipEventRecord(ctx->ev1, ctx->extra_streams[0]));
-        BU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
-    }
+    // the status words (and the CRC registers of the pieces) are read on the context stream: it must see the other streams' kernels.  Joined on the
+    // HOST -- a cross-stream event wait costs 70-80 us on this runtime, a wait for streams that are nearly done costs nothing
+    for (int i = 0; i < used_extra; i++) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[i]));
     BU_HIP(ctx, hipGetLastError());
     BU_HIP(ctx, hipMemcpyAsync(words.data(), d_status, 8 * n_img, hipMemcpyDeviceToHost, ctx->stream));
     if (crc_pieces) BU_HIP(ctx, hipMemcpyAsync(crc_parts.data(), d_crc, 2 * crc_pieces, hipMemcpyDeviceToHost, ctx->stream));
     if (p.out_bytes && !direct_out) BU_HIP(ctx, hipMemcpyAsync(out, d_out, p.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (used_extra) BU_HIP(ctx, hipStreamSynchronize(ctx->extra_streams[0]));
     BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain.armed = false;
     lap("download + synchronise");

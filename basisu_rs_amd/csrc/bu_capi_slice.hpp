@@ -72,12 +72,17 @@ bu_status bu_context_create(int device, bu_context** out_ctx)
         const size_t lim = (size_t)max_lds > margin ? (size_t)max_lds - margin : 0;
         ctx->etc1s_lds_limit = lim < BU_ETC1S_LDS_MAX ? lim : BU_ETC1S_LDS_MAX;
     }
+    {
+        const char* e = getenv("BU_ENQUEUE_THREADS");
+        ctx->single_thread_enqueue.store(e && e[0] == '0', std::memory_order_relaxed);
+    }
     bu_status st = BU_OK;
     do {
         if (hipSetDevice(device) != hipSuccess) { st = BU_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTablesAll)) != hipSuccess) { st = BU_ERR_HIP; break; }
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }  // eight words: [0] the blocking calls', [0..7] one per own stream (bu_range_in_flight)
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), 64, hipHostMallocDefault) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { st = BU_ERR_HIP; break; }
         BuTablesAll* h = new (std::nothrow) BuTablesAll();
         if (!h) { st = BU_ERR_HIP; break; }
@@ -114,6 +119,7 @@ void bu_context_destroy(bu_context* ctx)
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_crc_tables) (void)hipFree(ctx->d_crc_tables);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_aux) (void)hipFree(ctx->d_aux);
@@ -125,6 +131,9 @@ void bu_context_destroy(bu_context* ctx)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_end)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->probe_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->probe_ev0) (void)hipEventDestroy(ctx->probe_ev0);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (hipStream_t es : ctx->extra_streams)
         if (es) (void)hipStreamDestroy(es);
@@ -270,6 +279,150 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
     return bu_launch_runs(ctx, target, runs.data(), runs.size(), blocks_per_row, d_status, static_cast<hipStream_t>(stream), -1);
 }
 
+}  // extern "C"
+namespace {
+// launches groups[j] for j = first, first + step, ... on stream `s` (one stream's share of a pipelined batch, in order)
+bu_status bu_enqueue_groups(bu_context* ctx, bu_target target, const std::vector<BuRun>& runs, const std::vector<BuRun>& extra, const std::vector<BuLaunchGroup>& groups,
+                            size_t first, size_t step, size_t blocks_per_row, uint64_t* d_status, hipStream_t s, int policy)
+{
+    for (size_t j = first; j < groups.size(); j += step) {
+        const BuLaunchGroup& g = groups[j];
+        const BuRun* r = g.first >= runs.size() ? &extra[g.first - runs.size()] : &runs[g.first];
+        const bu_status st = bu_launch_runs(ctx, target, r, g.count, blocks_per_row, d_status, s, policy);
+        if (st) return st;
+    }
+    return BU_OK;
+}
+
+// From this many launches on, a pipelined batch is enqueued by one host thread per stream (the calling thread takes stream 0): one enqueue costs
+// 4.6-4.8 us of host time against a period of 5.5-5.7 us per 2^20-block launch, so a single enqueueing thread is 20 % from setting the pace
+// itself (and does set it under a profiler, where an enqueue costs 6-8 us).  Starting the threads costs ~0.1 ms: worth it from a few hundred
+// microseconds of GPU work.  The order inside every stream is the plan's; between streams it is whatever the threads make it, which the
+// results cannot depend on (independent slices) and the status word does not (a minimum over failing blocks).
+constexpr size_t BU_ENQUEUE_THREADS_MIN_LAUNCHES = 64;
+
+// the launches of a planned batch on the context's streams 0..n_streams-1, launch j on stream j % n_streams
+bu_status bu_issue_in_flight(bu_context* ctx, bu_target target, const std::vector<BuRun>& runs, const std::vector<BuRun>& extra, const std::vector<BuLaunchGroup>& groups,
+                             size_t blocks_per_row, uint64_t* d_status, int n_streams, int policy)
+{
+    hipStream_t ss[8];
+    for (int i = 0; i < n_streams; i++) ss[i] = ctx->extra_streams[i].load(std::memory_order_acquire);
+    if (n_streams > 1 && groups.size() >= BU_ENQUEUE_THREADS_MIN_LAUNCHES && !ctx->single_thread_enqueue.load(std::memory_order_relaxed)) {
+        bu_status sts[8] = {BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK, BU_OK};
+        std::vector<std::thread> th;
+        int started = 1;  // (stream 0 is the calling thread's)
+        for (int si = 1; si < n_streams; si++) {
+            try {
+                th.emplace_back([&, si] {
+                    if (hipSetDevice(ctx->device) != hipSuccess) {
+                        sts[si] = bu_fail(ctx, hipGetLastError(), "hipSetDevice");
+                        return;
+                    }
+                    sts[si] = bu_enqueue_groups(ctx, target, runs, extra, groups, (size_t)si, (size_t)n_streams, blocks_per_row, d_status, ss[si], policy);
+                });
+                started++;
+            } catch (const std::exception&) {  // (no thread to be had: this stream's share is enqueued by the calling thread below)
+                break;
+            }
+        }
+        sts[0] = bu_enqueue_groups(ctx, target, runs, extra, groups, 0, (size_t)n_streams, blocks_per_row, d_status, ss[0], policy);
+        for (int si = started; si < n_streams; si++)
+            sts[si] = bu_enqueue_groups(ctx, target, runs, extra, groups, (size_t)si, (size_t)n_streams, blocks_per_row, d_status, ss[si], policy);
+        for (auto& t : th) t.join();
+        for (int si = 0; si < n_streams; si++)
+            if (sts[si]) return sts[si];
+        return BU_OK;
+    }
+    for (size_t j = 0; j < groups.size(); j++) {
+        const bu_status st = bu_enqueue_groups(ctx, target, runs, extra, groups, j, groups.size(), blocks_per_row, d_status, ss[j % (size_t)n_streams], policy);
+        if (st) return st;
+    }
+    return BU_OK;
+}
+
+// ---- the pipeline inside the BLOCKING entry points (bu_uastc_transcode_device_sync, bu_array_transcode_sharded, bu_read_to) -------------
+// A large contiguous range is worth cutting into launches on the context's streams (a 2^25-block array: 0.76-0.78 of the roofline as four
+// launches in flight against 0.70 as one), but a fork / join over streams INSIDE a stream-ordered call costs 70-80 us per cross-stream
+// event wait on this runtime (profiles/r05_fork_join_cost_inside_a_stream_ordered_call.txt).  The blocking entry points end in a host-side
+// wait anyway, so they join THERE and need no cross-stream dependency at all: every stream carries its own status word (d_status[j], reset at
+// the head of stream j, copied to page-locked h_status[j] at its tail), the host waits for the streams it used and takes the minimum.
+// begin() only enqueues (several contexts -- devices -- can be started before the first is waited for); end() waits and decodes.
+// Caller holds ctx->lock (the status words are the context's).
+constexpr size_t BU_RANGE_IN_FLIGHT_MIN_DEFAULT = (size_t)1 << 22;  // blocks; below it one exclusive launch (profiles/r06_range_in_flight_threshold.txt)
+inline size_t bu_range_in_flight_min()
+{
+    static const size_t v = [] {
+        const char* e = getenv("BU_RANGE_IN_FLIGHT_MIN_LOG2");  // diagnostic knob of the threshold sweep
+        return e ? (size_t)1 << atoi(e) : BU_RANGE_IN_FLIGHT_MIN_DEFAULT;
+    }();
+    return v;
+}
+struct BuRangeJob {
+    int n_used = 0;           // own streams that carry a piece (0: the one launch on ctx->stream)
+    bool started = false;
+};
+bu_status bu_range_in_flight_begin(bu_context* ctx, bu_target target, const void* in, size_t nb, void* out, size_t bpr, uint64_t base, BuRangeJob* job)
+{
+    *job = BuRangeJob();
+    if (nb == 0) return BU_OK;
+    const size_t bb = bu_target_block_bytes(target);
+    constexpr int S = 4;
+    int effective = 1;
+    if (nb >= bu_range_in_flight_min()) {
+        const bu_status st = bu_ctx_in_flight_streams(ctx, S, &effective, nullptr);
+        if (st) return st;
+    }
+    std::vector<BuRun> runs(1, BuRun{static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), nb, base}), extra;
+    std::vector<BuLaunchGroup> groups;
+    if (effective >= 3) bu_plan_in_flight(runs, S, bpr, bb, (size_t)BU_MULTI_RUNS, groups, extra);
+    if (groups.size() < 2) {  // one launch, exclusive shape, the context's internal stream
+        BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
+        const bu_status st = bu_launch_uastc(ctx, target, in, nb, out, bpr, base, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream, 0, BU_POLICY_EXCLUSIVE);
+        if (st) return st;
+        BU_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        job->started = true;
+        return BU_OK;
+    }
+    const int used = groups.size() < (size_t)S ? (int)groups.size() : S;
+    job->n_used = used;
+    job->started = true;
+    for (int j = 0; j < used; j++) {
+        hipStream_t s = ctx->extra_streams[j].load(std::memory_order_acquire);
+        BU_HIP(ctx, hipMemsetAsync(ctx->d_status + j, 0xFF, sizeof(uint64_t), s));
+        const bu_status st = bu_enqueue_groups(ctx, target, runs, extra, groups, (size_t)j, (size_t)used, bpr, reinterpret_cast<uint64_t*>(ctx->d_status + j), s, BU_POLICY_SHARED);
+        if (st) return st;
+        BU_HIP(ctx, hipMemcpyAsync(ctx->h_status + j, ctx->d_status + j, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    }
+    return BU_OK;
+}
+// waits for the job's streams (polling: a blocking wait adds the 10-20 us a sleeping host thread needs to wake up to every call -- as long as a
+// tenth of a 2^25-block array; after BU_RANGE_SPIN_MS of polling the wait turns into a blocking one) and gives the lowest status word
+constexpr double BU_RANGE_SPIN_MS = 5.0;
+bu_status bu_range_in_flight_end(bu_context* ctx, const BuRangeJob& job, uint64_t* word)
+{
+    *word = BU_STATUS_WORD_CLEAR;
+    if (!job.started) return BU_OK;
+    const int n = job.n_used ? job.n_used : 1;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double, std::milli>(BU_RANGE_SPIN_MS);
+    for (int j = 0; j < n; j++) {
+        hipStream_t s = job.n_used ? ctx->extra_streams[j].load(std::memory_order_acquire) : ctx->stream;
+        for (unsigned k = 0;; k++) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipStreamQuery");
+            (void)hipGetLastError();
+            if ((k & 63u) == 63u && std::chrono::steady_clock::now() > deadline) {
+                BU_HIP(ctx, hipStreamSynchronize(s));
+                break;
+            }
+        }
+        if (ctx->h_status[j] < *word) *word = ctx->h_status[j];
+    }
+    return BU_OK;
+}
+}  // namespace
+extern "C" {
+
 // The same loop at the rate of a PIPELINE of launches (include/basisu_hip.h): the runs are grouped into launches of about one 4096^2 atlas
 // or more, a batch that makes fewer launches than streams has its largest runs cut into equal pieces, and launch j goes to context stream
 // j % n_streams under the shared launch policy.  Only enqueues; bu_context_synchronize (or the streams) waits.
@@ -283,20 +436,61 @@ bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, 
     if (st) return st;
     if (runs.empty()) return BU_OK;
     BU_HIP(ctx, hipSetDevice(ctx->device));
-    st = bu_ctx_streams(ctx, n_streams);
+    // the streams, and how many launches they really keep in flight in this process (creation-time probe, bu_streams.hpp)
+    int effective = n_streams;
+    st = bu_ctx_in_flight_streams(ctx, n_streams, &effective, nullptr);
     if (st) return st;
+    // Degraded: the streams share hardware queues whatever the library tried (plain streams AND CU-mask streams; or BU_STREAM_MODE=plain), so
+    // "n launches in flight" would run as `effective`.  A pipeline two deep is 7.3 us per 2^20-block BC7 launch; ONE stream-ordered batch launch --
+    // a persistent grid that walks all the runs with the next tile's loads in flight -- is 6.4 from eight such slices on, and a run that is one
+    // allocation is a single launch at 0.70 of the roofline.  BC7 / ASTC / RGBA32 have that kernel; ETC1 / ETC2 keep the shallow pipeline (13.1 / 16.3
+    // us with two in flight against 17.7 / 22.1 one at a time).  bu_context_query_in_flight tells the caller which of the two it got.
+    const bool persist_target = target == BU_TARGET_BC7 || target == BU_TARGET_ASTC || target == BU_TARGET_RGBA32;
+    if (n_streams > 1 && effective < n_streams && effective <= 2 && persist_target)
+        return bu_launch_runs(ctx, target, runs.data(), runs.size(), blocks_per_row, d_status, ctx->extra_streams[0].load(std::memory_order_acquire), BU_POLICY_EXCLUSIVE);
     // launches of about 2^20 blocks or more; a batch with fewer launches than streams has its largest runs cut (bu_batch_plan.hpp)
     std::vector<BuRun> extra;
     std::vector<BuLaunchGroup> groups;
     bu_plan_in_flight(runs, n_streams, blocks_per_row, bu_target_block_bytes(target), (size_t)BU_MULTI_RUNS, groups, extra);
-    // 3. launch j on stream j % n_streams, shared policy (a single launch gets the exclusive shape: nothing runs beside it)
+    // launch j on stream j % n_streams, shared policy (a single launch gets the exclusive shape: nothing runs beside it)
     const int policy = groups.size() > 1 && n_streams > 1 ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE;
-    for (size_t j = 0; j < groups.size(); j++) {
-        const BuLaunchGroup& g = groups[j];
-        const BuRun* first = g.first >= runs.size() ? &extra[g.first - runs.size()] : &runs[g.first];
-        st = bu_launch_runs(ctx, target, first, g.count, blocks_per_row, d_status, ctx->extra_streams[j % (size_t)n_streams], policy);
-        if (st) return st;
-    }
+    return bu_issue_in_flight(ctx, target, runs, extra, groups, blocks_per_row, d_status, n_streams, policy);
+}
+
+// What bu_uastc_transcode_batch_in_flight(..., n_streams) gets in THIS process (include/basisu_hip.h)
+bu_status bu_context_query_in_flight(bu_context* ctx, int n_streams, int* out_effective_streams, int* out_stream_mode)
+{
+    if (!ctx || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    int eff = n_streams, mode = 0;
+    const bu_status st = bu_ctx_in_flight_streams(ctx, n_streams, &eff, &mode);
+    if (st) return st;
+    if (out_effective_streams) *out_effective_streams = eff;
+    if (out_stream_mode) *out_stream_mode = mode == BU_STREAMS_CU_MASK ? BU_STREAM_QUEUE_CU_MASK : BU_STREAM_QUEUE_POOL;
+    return BU_OK;
+}
+
+// bu_uastc_transcode_device that WAITS (include/basisu_hip.h): a range of 2^22 blocks or more goes out as launches in flight on the context's
+// own streams, joined on the host
+bu_status bu_uastc_transcode_device_sync(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t blocks_per_row,
+                                         uint64_t block_index_base, uint64_t* out_status_word)
+{
+    if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
+    if (bu_target_block_bytes(target) == 0) return BU_ERR_ARGUMENT;
+    if (target == BU_TARGET_RGBA32 && (blocks_per_row == 0 || n_blocks % blocks_per_row != 0)) return BU_ERR_ARGUMENT;
+    if (out_status_word) *out_status_word = BU_STATUS_WORD_CLEAR;
+    if (n_blocks == 0) return BU_OK;
+    std::lock_guard<std::mutex> g(ctx->lock);
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    BuDrain drain(ctx);
+    BuRangeJob job;
+    bu_status st = bu_range_in_flight_begin(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, &job);
+    if (st) return st;
+    uint64_t word = BU_STATUS_WORD_CLEAR;
+    st = bu_range_in_flight_end(ctx, job, &word);
+    if (st) return st;
+    drain.armed = false;
+    if (out_status_word) *out_status_word = word;
     return BU_OK;
 }
 
@@ -320,14 +514,15 @@ bu_status bu_uastc_decode_to_rgba(bu_context* ctx, const uint8_t* in, size_t in_
 // ---- launch policy of the slice-level device entry points (include/basisu_hip.h; shapes: bu_context.hpp, BuBigShape) ----
 bu_status bu_context_set_launch_policy(bu_context* ctx, bu_launch_policy policy)
 {
-    if (!ctx || (policy != BU_LAUNCH_EXCLUSIVE && policy != BU_LAUNCH_SHARED)) return BU_ERR_ARGUMENT;
-    ctx->launch_policy.store(policy == BU_LAUNCH_SHARED ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE, std::memory_order_relaxed);
+    if (!ctx || (policy != BU_LAUNCH_EXCLUSIVE && policy != BU_LAUNCH_SHARED && policy != BU_LAUNCH_AUTO)) return BU_ERR_ARGUMENT;
+    static_assert((int)BU_LAUNCH_EXCLUSIVE == BU_POLICY_EXCLUSIVE && (int)BU_LAUNCH_SHARED == BU_POLICY_SHARED && (int)BU_LAUNCH_AUTO == BU_POLICY_AUTO, "one numbering");
+    ctx->launch_policy.store((int)policy, std::memory_order_relaxed);
     return BU_OK;
 }
 bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* out_policy)
 {
     if (!ctx || !out_policy) return BU_ERR_ARGUMENT;
-    *out_policy = ctx->launch_policy.load(std::memory_order_relaxed) == BU_POLICY_SHARED ? BU_LAUNCH_SHARED : BU_LAUNCH_EXCLUSIVE;
+    *out_policy = static_cast<bu_launch_policy>(ctx->launch_policy.load(std::memory_order_relaxed));
     return BU_OK;
 }
 
@@ -346,21 +541,15 @@ bu_status bu_context_synchronize(bu_context* ctx)
     if (!ctx) return BU_ERR_ARGUMENT;
     BU_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->stream) BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipStream_t es[8];
-    {  // (another thread may be creating a stream through bu_context_stream)
-        std::lock_guard<std::mutex> g(ctx->stream_lock);
-        for (int i = 0; i < 8; i++) es[i] = ctx->extra_streams[i];
-    }
-    for (hipStream_t e : es)
+    for (int i = 0; i < 8; i++) {  // (published streams are final: bu_streams.hpp)
+        hipStream_t e = ctx->extra_streams[i].load(std::memory_order_acquire);
         if (e) BU_HIP(ctx, hipStreamSynchronize(e));
+    }
     return BU_OK;
 }
 
-// Do the context's streams 0..n_streams-1 really run side by side?  One sleeping wave (200 us) is launched on every one of them behind a common
-// event; streams on different hardware queues sleep together (the whole probe takes one sleep), streams that share a queue sleep one after
-// the other.  *out_max_sharing = round(time of the probe / one sleep) = the largest number of the probed streams on one queue: 1 = every
-// stream has a queue of its own.  (The HIP runtime has no call that says which queue a stream is on; GPU_MAX_HW_QUEUES decides, see
-// bu_ctx_streams.)  Waits for the probe; ~0.3 ms.
+// Do the context's streams 0..n_streams-1 really run side by side -- now, as opposed to when they were created (bu_streams.hpp: a sleeping wave
+// on every stream behind a common event)?  *out_max_sharing = the largest number of the probed streams on one hardware queue.  Waits; ~0.4 ms.
 bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_sharing)
 {
     if (!ctx || !out_max_sharing || n_streams < 1 || n_streams > 8) return BU_ERR_ARGUMENT;
@@ -369,33 +558,8 @@ bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_
         const bu_status st = bu_ctx_streams(ctx, n_streams);
         if (st) return st;
     }
-    std::lock_guard<std::mutex> g(ctx->lock);  // (ev0 / ev_end are the context's)
-    for (int i = 0; i < n_streams; i++)
-        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_end[i], hipEventDisableSystemFence));  // (timing only, as in bu_streams_window)
-    constexpr unsigned long long TICKS = 20000;  // 200 us of the 100 MHz clock
-    BuDrain drain(ctx);
-    float best = 0;
-    for (int pass = 0; pass < 2; pass++) {  // (the first pass pays for loading the kernel)
-        BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->extra_streams[0]));
-        for (int i = 1; i < n_streams; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->ev0, 0));
-        for (int i = 0; i < n_streams; i++) {
-            hipLaunchKernelGGL(bu_sleep_kernel, dim3(1), dim3(64), 0, ctx->extra_streams[i], TICKS);
-            BU_HIP(ctx, hipGetLastError());
-            BU_HIP(ctx, hipEventRecord(ctx->ev_end[i], ctx->extra_streams[i]));
-        }
-        float worst = 0;
-        for (int i = 0; i < n_streams; i++) {
-            BU_HIP(ctx, hipEventSynchronize(ctx->ev_end[i]));
-            float ms = 0;
-            BU_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_end[i]));
-            if (ms > worst) worst = ms;
-        }
-        best = worst;
-    }
-    drain.armed = false;
-    const int k = (int)(best / 0.2f + 0.5f);
-    *out_max_sharing = k < 1 ? 1 : (k > n_streams ? n_streams : k);
-    return BU_OK;
+    std::lock_guard<std::mutex> g(ctx->stream_lock);  // (the probe events are the context's)
+    return bu_probe_streams_locked(ctx, n_streams, out_max_sharing);
 }
 
 // ---- per-block API (lib.rs:29-53) -----------------------------------------------------------------------------------------------

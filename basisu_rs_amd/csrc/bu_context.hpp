@@ -24,12 +24,21 @@ struct bu_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_start[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per-stream events of bu_time_uastc_launches_streams_window
     hipEvent_t ev_end[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t extra_streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::atomic<int> launch_policy{0};  // BU_POLICY_*: how much of a CU one large launch of the mode-sorted kernel takes (bu_context_set_launch_policy)
+    // the context's own streams (bu_streams.hpp): created in groups of four under stream_lock, final once published (readers load without the lock)
+    std::atomic<hipStream_t> extra_streams[8] = {{nullptr}, {nullptr}, {nullptr}, {nullptr}, {nullptr}, {nullptr}, {nullptr}, {nullptr}};
+    int streams_made = 0;                // 0, 4 or 8 (stream_lock)
+    int stream_mode[2] = {0, 0};         // BU_STREAMS_* of each group of four (stream_lock)
+    int stream_sharing[2] = {0, 0};      // the creation-time probe over streams 0..3 / 0..7: the largest number of them on one hardware queue (stream_lock)
+    hipEvent_t probe_ev0 = nullptr, probe_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bu_probe_streams_locked (stream_lock)
+    std::atomic<long long> last_big_enqueue_ns[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};  // host clock of the last large launch enqueued on each own stream (bu_auto_policy)
+    std::atomic<int> launch_policy{2};  // BU_POLICY_*: how much of a CU one large launch of the mode-sorted kernel takes (bu_context_set_launch_policy); default BU_POLICY_AUTO
+    // host-joined pipeline of the blocking entry points (bu_range_in_flight): one status word per own stream in d_status[0..7], read back into page-locked h_status
+    unsigned long long* h_status = nullptr;
     float win_start_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, win_end_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last streams window: per-stream event times (bu_time_last_window_streams)
     int win_streams = 0;
     float win_enqueue_ms = 0;  // host time the last streams window spent enqueueing its win_enqueued launches (and their events)
     int win_enqueued = 0;
+    std::atomic<bool> single_thread_enqueue{false};  // BU_ENQUEUE_THREADS=0 (diagnostic knob, bu_context_create): the pipelined batch call enqueues from the calling thread alone
     std::atomic<int> time_enqueue_threads{0};  // bu_time_set_enqueue_threads: the streams windows enqueue from one host thread per stream
     std::atomic<bool> block_api_on_device{false};  // per-block API: host build of the block code (default) or a 1-block launch
     size_t etc1s_lds_limit = 0;  // what the device reports a workgroup may use, less a margin (bu_context_create)
@@ -72,24 +81,8 @@ struct BuDrain {
     }
 };
 
-// The context's own streams 0..n-1 (n <= 8), created on first use: plain non-blocking streams at normal priority.
-// Whether launches on two of them overlap is decided by the HIP runtime, which multiplexes ALL streams of a process over a pool of
-// hardware queues per priority level (GPU_MAX_HW_QUEUES, 4 by default); two streams that share a hardware queue run their kernels one
-// after the other exactly as one stream would (kernel trace: profiles/r05_stream_creation_modes_queues_and_drift.txt -- in a
-// process whose default stream and context stream already hold two of the four queues, four more streams landed on the other two and
-// "4 launches in flight" ran as 2: 7.3 instead of 5.9 us per atlas).  Measured ways out, all equivalent in throughput
-// (same file, profiles/r05_hip_hw_queue_knobs_vs_streams.txt): GPU_MAX_HW_QUEUES=8 in the environment before the process first touches
-// HIP (what bench.py does and INTEGRATION.md recommends: equal priorities keep the streams in step), streams spread over the priority
-// levels (each level has its own pool; the high-priority streams then run ahead of the others), streams created with a full CU mask
-// (a dedicated queue each, but blocking with respect to the NULL stream).
-bu_status bu_ctx_streams(bu_context* ctx, int n)
-{
-    if (n < 0 || n > 8) return BU_ERR_ARGUMENT;
-    std::lock_guard<std::mutex> g(ctx->stream_lock);
-    for (int i = 0; i < n; i++)
-        if (!ctx->extra_streams[i]) BU_HIP(ctx, hipStreamCreateWithFlags(&ctx->extra_streams[i], hipStreamNonBlocking));
-    return BU_OK;
-}
+enum { BU_STREAMS_NONE = 0, BU_STREAMS_PLAIN = 1, BU_STREAMS_CU_MASK = 2 };
+bu_status bu_ctx_streams(bu_context* ctx, int n);  // bu_streams.hpp
 
 bu_status bu_reserve(bu_context* ctx, void** p, size_t* cap, size_t need)
 {
@@ -148,7 +141,8 @@ struct BuShape {
 //   RGBA32      1024 x 1, one per CU (16 waves, 69 KiB)             19.6 / 14.7 / 13.4 / 13.1   (14.7 / 14.2 / 13.8 / 13.6)
 // Alone on the chip a shared-policy launch is 15-40 % slower than an exclusive one: the policy is for callers that keep >= 2
 // streams busy (bu_context_set_launch_policy).
-enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1 };
+enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1, BU_POLICY_AUTO = 2 };
+int bu_auto_policy(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: BU_POLICY_AUTO resolved for one launch on `s`
 template <int TARGET, int POLICY> struct BuBigShape;
 template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_EXCLUSIVE> : BuShape<512, 2, 1, true, true, 4> {};
 template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_SHARED> : BuShape<256, 4, 1, true, true, 2> {};
@@ -254,9 +248,9 @@ void bu_launch_sorted_rgba(const BuPiece& p, unsigned cu_count, int policy, unsi
 }
 
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups.
-// policy = BU_POLICY_* of this launch, or -1 for the context's (bu_context_set_launch_policy): only the device-pointer slice entry
-// points pass -1 -- the host-pointer and whole-file entry points issue their launches one after another on one stream, for which the
-// exclusive shapes are the right ones whatever the context says.
+// policy = BU_POLICY_* of this launch, or -1 for the context's (bu_context_set_launch_policy; BU_POLICY_AUTO there is resolved per launch by
+// bu_auto_policy): only the device-pointer slice entry points pass -1 -- the host-pointer and whole-file entry points issue their launches one
+// after another on one stream, for which the exclusive shapes are the right ones whatever the context says.
 bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t bpr,
                           uint64_t base, uint64_t* d_status, hipStream_t stream, unsigned grid_cap = 0, int policy = BU_POLICY_EXCLUSIVE)
 {
@@ -271,6 +265,8 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         if (target == BU_TARGET_RGBA32) piece = bpr <= piece ? (piece / bpr) * bpr : bpr;
         const size_t obytes = bu_target_block_bytes(target);
         if (policy < 0) policy = ctx->launch_policy.load(std::memory_order_relaxed);
+        // BU_LAUNCH_AUTO: decided per call, and only where the shapes differ (a launch of more than one tile per CU)
+        if (policy == BU_POLICY_AUTO) policy = (grid_cap == 0 && n_blocks > (size_t)BU_HOST_TILE * ctx->cu_count) ? bu_auto_policy(ctx, stream) : (int)BU_POLICY_EXCLUSIVE;
         constexpr size_t RW = BU_RECT_W;
         BuPiece p;
         p.status = st;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -23,6 +24,8 @@
 #include <future>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/basisu_hip.h"
 #include "bu_basis.hpp"
@@ -31,6 +34,7 @@
 
 #include "bu_kernels.hpp"        // device code
 #include "bu_context.hpp"        // bu_context, launcher, host-pointer driver
+#include "bu_streams.hpp"        // the context's own streams (hardware-queue check), BU_LAUNCH_AUTO
 #include "bu_capi_slice.hpp"     // extern "C": slice level
 #include "bu_capi_file.hpp"      // extern "C": whole-file level
 #include "bu_capi_measure.hpp"   // extern "C": measurement helpers

@@ -33,11 +33,11 @@ def gpu_transcode_fn(ctx, fmt):
         n = d_in.shape[0]
         if n == 0:
             return _CLEAR
-        status = torch.empty(1, dtype=torch.int64, device=d_in.device)
-        ctx.status_word_reset(status)
-        ctx.transcode_device(int(fmt), d_in, n, out, block_index_base=int(base), d_status=status)
-        # deliberate sync point: the error contract is "first failing block aborts the call"
-        word = int(status.item()) & 0xFFFFFFFFFFFFFFFF
+        # the rank's inputs were produced on torch's stream; the library's own streams do not wait for it
+        torch.cuda.current_stream(d_in.device).synchronize()
+        # bu_uastc_transcode_device_sync: the range as launches in flight on the context's own streams (from 2^22 blocks on), joined on the host --
+        # the deliberate sync point of the error contract ("first failing block aborts the call"), and the same code bu_array_transcode_sharded runs per device
+        word = ctx.transcode_device_sync(int(fmt), d_in, n, out, block_index_base=int(base))
         return _CLEAR if word == _lib.STATUS_WORD_CLEAR else word
 
     fn.block_bytes = _lib.BLOCK_BYTES[int(fmt)]

@@ -78,40 +78,56 @@ const char* bu_last_error(const bu_context* ctx);
 size_t bu_target_block_bytes(bu_target target);
 
 /* ---- launch policy -------------------------------------------------------------------------------
- * How much of the chip ONE large launch of the slice-level transcode takes (a property of the context, read by
- * bu_uastc_transcode_device / _batch_device -- the entry points that take the caller's stream -- at the moment they enqueue; the
- * host-pointer and whole-file entry points issue their launches one after another and always use the exclusive shapes; results never
- * depend on it).
+ * How much of the chip ONE large launch of the slice-level transcode takes (read by bu_uastc_transcode_device / _batch_device -- the
+ * entry points that take a stream -- at the moment they enqueue; the host-pointer entry points issue one launch at a time and always use
+ * the exclusive shapes; results never depend on it).
  * The reference's slice loop (uastc.rs:112-165, basis.rs:246-257) runs slices one after another; on the GPU a launch over one
  * 4096 x 4096 slice spends its first ~3.4 us waiting for HBM with the ALUs idle and the rest computing with HBM idle, and launches
  * queued on ONE stream never overlap (the queue drains between two dispatches).  A caller with several independent slices gets
- * both resources busy by issuing them round-robin on 2-4 streams:
- *   BU_LAUNCH_EXCLUSIVE (default)  a launch is shaped to fill the chip by itself: lowest latency for a single slice (UASTC->BC7,
- *                                  2^20 blocks: 8.4 us); 6.3-6.7 us per slice with 2-3 streams (head / tail overlap only)
+ * both resources busy by issuing them round-robin on 2-4 of the context's streams (bu_context_stream):
+ *   BU_LAUNCH_EXCLUSIVE            a launch is shaped to fill the chip by itself: lowest latency for a single slice (UASTC->BC7,
+ *                                  2^20 blocks: 8.4 us); 6.2-6.7 us per slice with 2-4 streams (head / tail overlap only)
  *   BU_LAUNCH_SHARED               a launch keeps at most half of every CU's wave slots, registers and LDS, so launches from different
  *                                  streams run side by side on each CU: 5.45-5.6 us per slice with 4 streams (BC7; ASTC 5.4), ETC1 17.7 -> 12.1,
  *                                  ETC2 22.1 -> 15.0, RGBA32 14.9 -> 13.1; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
- * Figures: profiles/r05_ab_bc7_two_launches_in_flight.txt, r05_ab_wave_priorities_with_launches_in_flight.txt, r05_ab_etc_shared_shapes_x_streams.txt.  Small launches (at most one 1024-block tile per CU) are the same under both. */
-typedef enum bu_launch_policy { BU_LAUNCH_EXCLUSIVE = 0, BU_LAUNCH_SHARED = 1 } bu_launch_policy;
+ *   BU_LAUNCH_AUTO (default)       chosen PER CALL: shared when the launch goes to one of the context's own streams and another of them has
+ *                                  work that has not completed (enqueued there within the last 20 us of host time, else one hipStreamQuery per
+ *                                  stream ever used), exclusive otherwise -- a lone slice, and every launch on a stream of the caller's own, which
+ *                                  the library cannot see beside.  The first launch of a pipeline goes out exclusive, the rest shared.
+ * Figures: profiles/r05_ab_bc7_two_launches_in_flight.txt, r05_ab_wave_priorities_with_launches_in_flight.txt, r05_ab_etc_shared_shapes_x_streams.txt,
+ * r06_auto_policy_matrix.txt.  Small launches (at most one 1024-block tile per CU) are the same under all three. */
+typedef enum bu_launch_policy { BU_LAUNCH_EXCLUSIVE = 0, BU_LAUNCH_SHARED = 1, BU_LAUNCH_AUTO = 2 } bu_launch_policy;
 bu_status bu_context_set_launch_policy(bu_context* ctx, bu_launch_policy policy);
 bu_status bu_context_get_launch_policy(const bu_context* ctx, bu_launch_policy* out_policy);
-/* The context's own streams, index 0..7 (hipStream_t, non-blocking, normal priority, created on first use, destroyed with the
- * context): what a caller that wants several launches in flight can issue them on.  Launches only overlap when their streams sit on
- * DIFFERENT hardware queues, and the HIP runtime multiplexes all streams of a process over GPU_MAX_HW_QUEUES (default 4) queues per
- * priority level -- two streams that share one run their kernels strictly one after the other.  A process that wants four launches in
- * flight should start with GPU_MAX_HW_QUEUES=8 in its environment (set before the first HIP call; bench.py does): with the default a
- * process's NULL stream and the context's internal stream already hold two of the four queues.  A process
- * that holds an RCCL communicator as well needs more (16): the communicator's streams take queues too. */
+/* The context's own streams, index 0..7 (hipStream_t, created on first use in groups of four, destroyed with the context): what a caller
+ * that wants several launches in flight issues them on.  Launches only overlap when their streams sit on DIFFERENT hardware queues, and
+ * the HIP runtime multiplexes all ordinary streams of a process over GPU_MAX_HW_QUEUES (default 4) queues per priority level -- two
+ * streams that share one run their kernels strictly one after the other.  The library does not depend on that variable: a new group
+ * is created as ordinary non-blocking streams, checked (a 200 us sleeping wave on every stream behind a common event: streams with a queue each
+ * sleep together), and if two streams share a queue the group is re-created with full CU masks (hipExtStreamCreateWithCUMask: a hardware
+ * queue of its own per stream whatever the pool size) and checked again, before anybody sees a handle (~1 ms, once per group).  CU-mask streams
+ * have default-stream semantics towards the process's NULL stream (they wait for work queued there and it waits for them); a process that keeps
+ * GPU_MAX_HW_QUEUES >= its number of streams (bench.py: 8, 16 beside an RCCL communicator; set before the first HIP call) keeps ordinary
+ * non-blocking streams.  bu_context_query_in_flight says which kind the context got and whether the check passed. */
 bu_status bu_context_stream(bu_context* ctx, int index, void** out_stream);
 /* waits until everything enqueued on the context's own streams (bu_context_stream) and on its internal stream has completed: the
  * host-side join for a caller without a HIP binding of its own (examples/slices_in_flight.c) */
 bu_status bu_context_synchronize(bu_context* ctx);
-/* Do the context's streams 0..n_streams-1 (1..8) really run side by side in THIS process?  A 200 us sleeping wave is launched on each of them
- * behind a common event: streams on different hardware queues sleep together, streams sharing a queue one after the other.
- * *out_max_sharing = the largest number of the probed streams found on one queue -- 1: every stream has its own; 2 and more: raise
- * GPU_MAX_HW_QUEUES (above) before the process first touches HIP.  Blocks for about 0.3 ms; call it once after setting a process up
- * (other libraries' streams -- an RCCL communicator's -- take queues too, so probe after they exist). */
+/* Do the context's streams 0..n_streams-1 (1..8) really run side by side in THIS process, NOW?  The creation-time check repeated on demand
+ * (other libraries' streams -- an RCCL communicator's -- created later take queues of the pool too): *out_max_sharing = the largest number
+ * of the probed streams found on one queue -- 1: every stream has its own.  Blocks for about 0.4 ms. */
 bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_sharing);
+/* What a pipeline over the context's streams 0..n_streams-1 gets in this process, by the creation-time check (creates the streams if need be):
+ *   *out_effective_streams  how many launches the streams really keep in flight: n_streams when every stream has a hardware queue of its own,
+ *                           n_streams / (streams per queue) when neither kind of stream got one (not seen on ROCm 7.2; BU_STREAM_MODE=plain in the
+ *                           environment forces ordinary streams and reproduces it).  bu_uastc_transcode_batch_in_flight then degrades by itself:
+ *                           with <= 2 effective streams BC7 / ASTC / RGBA32 batches go out as the stream-ordered batch launch on stream 0 (6.4 us
+ *                           per 2^20-block slice from eight slices on, against 7.3 for a pipeline two deep); results are the same either way.
+ *   *out_stream_mode        BU_STREAM_QUEUE_POOL: ordinary non-blocking streams on the runtime's queue pool; BU_STREAM_QUEUE_CU_MASK: CU-mask streams
+ * Either pointer may be NULL. */
+#define BU_STREAM_QUEUE_POOL 0
+#define BU_STREAM_QUEUE_CU_MASK 1
+bu_status bu_context_query_in_flight(bu_context* ctx, int n_streams, int* out_effective_streams, int* out_stream_mode);
 
 /* ---- UASTC slice level, host pointers ------------------------------------------------------- */
 
@@ -184,10 +200,23 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
  * the context's own stream j % n_streams (1..8; bu_context_stream) under the shared launch policy, whatever the context's policy is.
  * It only ENQUEUES: bu_context_synchronize(ctx), or synchronising those streams, waits for the results, and nothing the caller enqueued on
  * other streams is waited for -- inputs and the status word must be ready before the call (bu_status_word_reset + a synchronise).  The streams
- * need a hardware queue each (bu_context_probe_streams).  Results, status reporting and argument rules are those of the call above. */
+ * need a hardware queue each; the library sees to that itself and reports it (bu_context_stream, bu_context_query_in_flight).  A batch of 64
+ * launches or more is enqueued by one host thread per stream (the calling thread among them; all joined before the call returns), so that
+ * the host's ~4.7 us per enqueue stays off the pipeline's critical path.  Results, status reporting and argument rules are those of the call above. */
 bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
                                              const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
                                              const uint64_t* index_base, uint64_t* d_status, int n_streams);
+
+/* bu_uastc_transcode_device that WAITS: the per-slice loop of basis.rs:246-257 over one contiguous device-resident range (a slice, or the
+ * slices a rank owns of a texture array: basis.rs:531-552), as a blocking call.  A range of 2^22 blocks or more is cut into launches that
+ * run in flight on the context's own streams under the shared policy and are joined on the HOST (every stream reports into its own status
+ * word; no cross-stream event wait, which costs 70-80 us on this runtime): a 2^25-block array 0.76 of the HBM roofline against 0.70 as one
+ * launch; smaller ranges are one exclusive launch.  *out_status_word (optional) = BU_STATUS_WORD_CLEAR or the LOWEST
+ * (block_index_base + block) << 8 | status over the range -- bu_status_word_decode turns it into the reference's error; ranks of a
+ * multi-process job reduce it with MIN before anyone raises (basisu_rs_amd/sharded.py).  The call takes the context's lock (one blocking
+ * call per context at a time).  bu_array_transcode_sharded runs every device's range through the same code. */
+bu_status bu_uastc_transcode_device_sync(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
+                                         size_t blocks_per_row, uint64_t block_index_base, uint64_t* out_status_word);
 
 /* value a status word must hold before the launches that report into it (all ones) */
 #define BU_STATUS_WORD_CLEAR 0xFFFFFFFFFFFFFFFFull

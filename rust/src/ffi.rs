@@ -95,14 +95,17 @@ extern "C" {
     pub fn bu_status_string(st: c_int) -> *const c_char;
     pub fn bu_last_error(ctx: *const bu_context) -> *const c_char;
     pub fn bu_target_block_bytes(target: c_int) -> usize;
-    // launch policy of the slice-level device entry points: 0 = BU_LAUNCH_EXCLUSIVE (default), 1 = BU_LAUNCH_SHARED
+    // launch policy of the slice-level device entry points: 0 = BU_LAUNCH_EXCLUSIVE, 1 = BU_LAUNCH_SHARED, 2 = BU_LAUNCH_AUTO (default: chosen per call)
     pub fn bu_context_set_launch_policy(ctx: *mut bu_context, policy: c_int) -> c_int;
     pub fn bu_context_get_launch_policy(ctx: *const bu_context, out_policy: *mut c_int) -> c_int;
-    // the context's own streams (hipStream_t), index 0..7, on different hardware queues: for several launches in flight
+    // the context's own streams (hipStream_t), index 0..7, for several launches in flight.  The library checks at creation that each has a hardware
+    // queue of its own and re-creates them with CU masks when the runtime's pool (GPU_MAX_HW_QUEUES) is too small: bu_context_query_in_flight reports
     pub fn bu_context_stream(ctx: *mut bu_context, index: c_int, out_stream: *mut *mut c_void) -> c_int;
     pub fn bu_context_synchronize(ctx: *mut bu_context) -> c_int;
     // the largest number of the context's streams 0..n_streams-1 that share one hardware queue in this process (1 = none do)
     pub fn bu_context_probe_streams(ctx: *mut bu_context, n_streams: c_int, out_max_sharing: *mut c_int) -> c_int;
+    // how many launches a pipeline over streams 0..n_streams-1 really keeps in flight in this process; stream mode 0 = queue pool, 1 = CU-mask streams
+    pub fn bu_context_query_in_flight(ctx: *mut bu_context, n_streams: c_int, out_effective_streams: *mut c_int, out_stream_mode: *mut c_int) -> c_int;
     // slice level, host pointers (uastc.rs:89-146)
     pub fn bu_uastc_transcode(ctx: *mut bu_context, target: c_int, input: *const u8, in_bytes: usize, out: *mut u8, out_bytes: usize,
                               first_bad_block: *mut u64) -> c_int;
@@ -126,6 +129,9 @@ extern "C" {
     pub fn bu_uastc_transcode_batch_in_flight(ctx: *mut bu_context, target: c_int, n_slices: usize, d_in: *const *const c_void, n_blocks: *const usize,
                                               d_out: *const *mut c_void, blocks_per_row: usize, index_base: *const u64, d_status: *mut u64,
                                               n_streams: c_int) -> c_int;
+    // bu_uastc_transcode_device that waits: a range of 2^22 blocks or more as launches in flight on the context's own streams, joined on the host
+    pub fn bu_uastc_transcode_device_sync(ctx: *mut bu_context, target: c_int, d_in: *const c_void, n_blocks: usize, d_out: *mut c_void,
+                                          blocks_per_row: usize, block_index_base: u64, out_status_word: *mut u64) -> c_int;
     pub fn bu_status_word_reset(ctx: *mut bu_context, d_status: *mut u64, stream: *mut c_void) -> c_int;
     pub fn bu_status_word_decode(word: u64, first_bad_block: *mut u64) -> c_int;
     pub fn bu_host_alloc(ctx: *mut bu_context, bytes: usize, out_ptr: *mut *mut c_void) -> c_int;

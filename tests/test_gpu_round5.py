@@ -101,12 +101,15 @@ def test_policy_round_trip_and_argument_check():
     ctx = Context(0)
     lib = ctx._lib
     p = ctypes.c_int(-1)
-    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 0
+    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 2  # BU_LAUNCH_AUTO is the default (round 6)
     assert lib.bu_context_set_launch_policy(ctx.handle, 1) == 0
     assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 1
     assert lib.bu_context_set_launch_policy(ctx.handle, 7) == _lib.ERR_ARGUMENT
     assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 1
     assert lib.bu_context_set_launch_policy(ctx.handle, 0) == 0
+    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 0
+    assert lib.bu_context_set_launch_policy(ctx.handle, 2) == 0
+    assert lib.bu_context_get_launch_policy(ctx.handle, ctypes.byref(p)) == 0 and p.value == 2
     ctx.close()
 
 

@@ -1,0 +1,290 @@
+"""Round-6 GPU tests: the pipeline behind the product's own entry points and independent of the process environment.
+
+  * the context's streams get a hardware queue each WITHOUT GPU_MAX_HW_QUEUES in the environment (child processes that unset it): CU-mask
+    streams, reported by bu_context_query_in_flight; with BU_STREAM_MODE=plain (ordinary streams forced) the in-flight call degrades to the
+    stream-ordered batch launch and says so -- results identical either way;
+  * BU_LAUNCH_AUTO (the default): same bytes and status words as the explicit policies, alone and with four launches in flight;
+  * bu_uastc_transcode_device_sync: a range as launches in flight joined on the host -- every target, ragged sizes, both sides of the threshold,
+    lowest failing block across pieces;
+  * bu_array_transcode_sharded over ranges large enough to take the pipeline (virtual ranks on one device).
+Everything goes through the C ABI; bit-exact.  Run on the GPU box: pytest -m gpu."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from basisu_rs_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TB = {"astc": (_lib.ASTC, 16), "bc7": (_lib.BC7, 16), "rgba": (_lib.RGBA32, 64), "etc1": (_lib.ETC1, 8), "etc2": (_lib.ETC2, 16)}
+
+# ---- a child process without GPU_MAX_HW_QUEUES: 64 atlases through bu_uastc_transcode_batch_in_flight -------------------------------------
+_CHILD = r"""
+import ctypes, json, os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from basisu_rs_amd import Context, _lib, synth
+assert "GPU_MAX_HW_QUEUES" not in os.environ
+golden = synth.load_golden(os.path.join(%(root)r, "tests", "golden", "uastc_kat.bin"))
+dev = torch.device("cuda", 0)
+torch.zeros(1, device=dev)            # torch's NULL stream exists and holds a queue of the pool, as in any torch process
+ctx = Context(0)
+lib = ctx._lib
+g_u, g_b = torch.from_numpy(golden["uastc"]).to(dev), torch.from_numpy(golden["bc7"]).to(dev)
+N, NB = 64, 1 << 20
+idxs = [torch.randint(0, 608, (NB,), device=dev, generator=torch.Generator(device=dev).manual_seed(77 + k)) for k in range(N)]
+ins = [g_u[i].contiguous() for i in idxs]
+outs = [torch.zeros((NB, 16), dtype=torch.uint8, device=dev) for _ in range(N)]
+status = torch.empty(1, dtype=torch.int64, device=dev)
+ctx.status_word_reset(status)
+torch.cuda.synchronize()
+eff, mode = ctx.query_in_flight(4)
+sharing_now = ctx.probe_streams(4)
+def run():
+    ctx.transcode_batch_in_flight(_lib.BC7, ins, [NB] * N, outs, blocks_per_row=1024, d_status=status, n_streams=4)
+    ctx.synchronize()
+run()                                  # correctness pass
+ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(N))
+word = int(status.item()) & 0xFFFFFFFFFFFFFFFF
+for _ in range(6): run()               # clocks
+best = 1e9
+for _ in range(5):
+    t0 = time.perf_counter(); run(); run(); run(); run(); dt = (time.perf_counter() - t0) / (4 * N) * 1e6
+    best = min(best, dt)
+ctx.close()
+print(json.dumps({"effective": eff, "mode": mode, "sharing_now": sharing_now, "ok": ok, "clear": word == _lib.STATUS_WORD_CLEAR, "us_per_atlas": best}))
+"""
+
+
+def _child(extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "BU_STREAM_MODE", "DEBUG_HIP_DYNAMIC_QUEUES")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_in_flight_without_the_environment_variable():
+    """a host process that never heard of GPU_MAX_HW_QUEUES (a Rust binary): the library gives its streams a hardware queue each by itself, says so,
+    and 64 atlases through ONE call of the in-flight entry point come out right at the pipeline's rate -- or the call reports fewer effective streams"""
+    r = _child({})
+    assert r["ok"] and r["clear"], r
+    assert r["effective"] < 4 or r["us_per_atlas"] <= 6.2, r
+    if r["effective"] == 4:
+        assert r["sharing_now"] == 1, r
+    print("in flight without GPU_MAX_HW_QUEUES:", r)
+
+
+def test_in_flight_degrades_by_itself_when_the_streams_share_queues():
+    """BU_STREAM_MODE=plain forces ordinary streams on the default pool of four queues (two of them taken): the context reports fewer effective
+    streams than requested and the in-flight call goes out as the stream-ordered batch launch -- same bytes, and faster than a pipeline two deep"""
+    r = _child({"BU_STREAM_MODE": "plain"})
+    assert r["ok"] and r["clear"], r
+    assert r["mode"] == "pool", r
+    if r["effective"] < 4:  # (a runtime whose pool has room gives four queues anyway: then there is nothing to degrade)
+        assert r["us_per_atlas"] <= 7.0, r
+    print("in flight, plain streams on the default pool:", r)
+
+
+# ---- BU_LAUNCH_AUTO ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2", "rgba"])
+def test_auto_policy_alone_and_in_flight_known_answers(golden, target):
+    """the default policy picks a shape per call; whatever it picks, the bytes are the known answers: one launch at a time on torch's stream
+    (exclusive), on one context stream (exclusive), and 12 launches round-robin on four context streams (the first exclusive, the others shared)"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    t, bb = TB[target]
+    bpr, rows = 1024, 1040  # > 3 tiles per CU: the large shapes of every target; ragged against the 2048-block ETC tiles
+    n = bpr * rows
+    K = 12
+    gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden[target]).cuda()
+    idxs = [torch.from_numpy(synth.gold_indices(n, seed=900 + k)).cuda() for k in range(K)]
+    ins = [gu[i].contiguous() for i in idxs]
+    shape = (rows * 4, bpr * 16) if target == "rgba" else (n, bb)
+    outs = [torch.zeros(shape, dtype=torch.uint8, device="cuda") for _ in range(K)]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+
+    def check(k):
+        got = outs[k]
+        if target == "rgba":
+            got = got.view(rows, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64)
+        assert torch.equal(got, gt[idxs[k]]), (target, k)
+        outs[k].zero_()
+
+    ctx.transcode_device(t, ins[0], n, outs[0], blocks_per_row=bpr, d_status=status)  # torch's stream
+    torch.cuda.synchronize()
+    check(0)
+    ctx.transcode_device(t, ins[1], n, outs[1], blocks_per_row=bpr, d_status=status, stream=ctx.stream(0))  # a lone launch on an own stream
+    ctx.synchronize()
+    check(1)
+    torch.cuda.synchronize()
+    for k in range(K):
+        ctx.transcode_device(t, ins[k], n, outs[k], blocks_per_row=bpr, d_status=status, stream=ctx.stream(k % 4))
+    ctx.synchronize()
+    for k in range(K):
+        check(k)
+    ctx.status_word_check(int(status.item()))
+    ctx.close()
+
+
+# ---- bu_uastc_transcode_device_sync --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2", "rgba"])
+def test_device_sync_pieces_in_flight_known_answers_and_lowest_error(golden, target):
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    t, bb = TB[target]
+    gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden[target]).cuda()
+    # below the threshold (one launch), at it, ragged above it (pieces that end on tile boundaries but not on equal sizes), two pieces only
+    for bpr, rows in [(1024, 1024), (1024, 4096), (1024, 4096 + 1031), (2048, 2049 + 1024), (512, 16400)]:
+        n = bpr * rows
+        idx = torch.from_numpy(synth.gold_indices(n, seed=4000 + rows)).cuda()
+        d_in = gu[idx].contiguous()
+        shape = (rows * 4, bpr * 16) if target == "rgba" else (n, bb)
+        d_out = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        word = ctx.transcode_device_sync(t, d_in, n, d_out, blocks_per_row=bpr, block_index_base=1000)
+        assert word == _lib.STATUS_WORD_CLEAR
+        got = d_out.view(rows, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64) if target == "rgba" else d_out
+        assert torch.equal(got, gt[idx]), (target, bpr, rows)
+        # failing blocks in the last piece, in the second and (lowest) in the first
+        for bad in (n - 3, n // 2 + 17, n // 9 + 1):
+            d_in[bad, 0] = 69
+            torch.cuda.synchronize()
+            word = ctx.transcode_device_sync(t, d_in, n, d_out, blocks_per_row=bpr, block_index_base=1000)
+            with pytest.raises(BasisuError) as e:
+                ctx.status_word_check(word)
+            assert e.value.status == _lib.ERR_INVALID_MODE and e.value.first_bad_block == 1000 + bad, (target, bpr, rows, bad)
+        del d_in, d_out
+    # arguments
+    lib = ctx._lib
+    w = ctypes.c_uint64(0)
+    assert lib.bu_uastc_transcode_device_sync(ctx.handle, t, None, 5, None, 0, 0, ctypes.byref(w)) == _lib.ERR_ARGUMENT
+    assert lib.bu_uastc_transcode_device_sync(ctx.handle, t, None, 0, None, 1, 0, ctypes.byref(w)) == 0 and w.value == _lib.STATUS_WORD_CLEAR
+    ctx.close()
+
+
+def test_device_sync_against_the_oracle_on_random_blocks(oracle):
+    """4.25 Mi random valid + high-contrast blocks through the pieces in flight (shared-policy shapes, four streams) against the CPU restatement"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    n = (1 << 22) + (1 << 18)
+    blocks = np.concatenate([synth.atlas_rand(1 << 22, seed=61), synth.atlas_contrast(1 << 18, seed=62)])
+    d_in = torch.from_numpy(blocks).cuda()
+    for target in ("bc7", "etc2"):
+        t, bb = TB[target]
+        d_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert ctx.transcode_device_sync(t, d_in, n, d_out, blocks_per_row=1024) == _lib.STATUS_WORD_CLEAR
+        want, st = oracle.batch(target, blocks)
+        assert (st == 0).all()
+        assert (d_out.cpu().numpy() == want.reshape(n, bb)).all(), target
+    ctx.close()
+
+
+# ---- bu_array_transcode_sharded with ranges that take the pipeline ---------------------------------------------------------------------------
+def _ptr_array(vals):
+    return (ctypes.c_void_p * len(vals))(*vals)
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2, 3])
+def test_array_transcode_sharded_large_ranges_take_the_pipeline(golden, n_ctx):
+    """a 200-slice array of 65 536-block slices: 13 Mi blocks, 4.4-13 Mi per virtual rank -- every range goes out as launches in flight on its context's
+    own streams; all contexts' full buffers equal the unsharded result, and the lowest failing block of the whole array is the one reported"""
+    import torch
+
+    from basisu_rs_amd import Context, sharded
+
+    lib = _lib.load()
+    n_slices, bps = 200, 65536
+    gu, gb = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden["bc7"]).cuda()
+    idx = torch.randint(0, 608, (n_slices * bps,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    blocks = gu[idx].contiguous()
+    want = gb[idx]
+    ctxs = [Context(0) for _ in range(n_ctx)]
+    try:
+        ins, fulls = [], []
+        for r in range(n_ctx):
+            lo, hi = sharded.partition(n_slices, n_ctx, r)
+            ins.append(blocks[lo * bps:hi * bps].clone())
+            fulls.append(torch.zeros((n_slices * bps, 16), dtype=torch.uint8, device="cuda"))
+        torch.cuda.synchronize()
+        handles = _ptr_array([c.handle.value for c in ctxs])
+        bad = ctypes.c_uint64(0)
+        args = lambda: (handles, n_ctx, _lib.BC7, _ptr_array([t.data_ptr() for t in ins]), n_slices, bps, _ptr_array([t.data_ptr() for t in fulls]), 1, ctypes.byref(bad))  # noqa: E731
+        st = lib.bu_array_transcode_sharded(*args())
+        assert st == 0, (lib.bu_status_string(st), lib.bu_last_error(ctxs[0].handle))
+        torch.cuda.synchronize()
+        for r in range(n_ctx):
+            assert torch.equal(fulls[r], want), r
+        lo_last = sharded.partition(n_slices, n_ctx, n_ctx - 1)[0]
+        n_last = ins[-1].shape[0]
+        ins[-1][n_last - 2, 0] = 69       # in the last piece of the last range
+        ins[0][3 * bps + 9, 0] = 69       # in the first piece of the first
+        torch.cuda.synchronize()
+        st = lib.bu_array_transcode_sharded(*args())
+        assert st == _lib.ERR_INVALID_MODE and bad.value == 3 * bps + 9
+        ins[0][3 * bps + 9, 0] = int(blocks[3 * bps + 9, 0].item())
+        torch.cuda.synchronize()
+        st = lib.bu_array_transcode_sharded(*args())
+        assert st == _lib.ERR_INVALID_MODE and bad.value == lo_last * bps + n_last - 2
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_sharded_gpu_transcode_fn_takes_the_pipeline(golden):
+    """the torch.distributed driver's per-shard function (sharded.gpu_transcode_fn) on one rank: a 2^23-block shard through bu_uastc_transcode_device_sync"""
+    import torch
+
+    from basisu_rs_amd import Context, sharded
+
+    ctx = Context(0)
+    n_slices, bps = 128, 65536
+    gu, gb = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden["bc7"]).cuda()
+    idx = torch.randint(0, 608, (n_slices * bps,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    slices = gu[idx].view(n_slices, bps, 16).contiguous()
+    out = sharded.transcode_array_sharded(slices, sharded.gpu_transcode_fn(ctx, _lib.BC7), gather=False)
+    assert torch.equal(out.view(-1, 16), gb[idx])
+    slices[100, 77, 0] = 69
+    with pytest.raises(Exception) as e:
+        sharded.transcode_array_sharded(slices, sharded.gpu_transcode_fn(ctx, _lib.BC7), gather=False)
+    assert getattr(e.value, "first_bad_block", None) == 100 * bps + 77
+    ctx.close()
+
+
+def test_read_to_bc7_large_file_takes_the_piece_pipeline(ctx, golden):
+    """bu_read_to on a UASTC file whose slices form one run of 2^22 blocks (64 MiB): pageable output, pieces on four streams under the shared policy;
+    also astc / etc1 (8-byte blocks) and a damaged block in the third slice"""
+    import basisu_rs_amd as bu
+    from basisu_rs_amd import BasisuError
+
+    nbx, nby, n_slices = 1024, 1024, 4
+    idx = [synth.gold_indices(nbx * nby, seed=7100 + k) for k in range(n_slices)]
+    slices = [golden["uastc"][i].copy() for i in idx]
+    f = bu.write_uastc_file([dict(data=s, orig_w=4 * nbx, orig_h=4 * nby, nbx=nbx, nby=nby, image_index=k) for k, s in enumerate(slices)])
+    for name, fn, bb in (("bc7", bu.read_to_bc7, 16), ("astc", bu.read_to_astc, 16), ("etc1", bu.read_to_etc1, 8)):
+        imgs = fn(f, ctx)
+        assert len(imgs) == n_slices
+        for k in range(n_slices):
+            assert (np.asarray(imgs[k].data).reshape(-1, bb) == golden[name][idx[k]]).all(), (name, k)
+    slices[2][4242, 0] = 69
+    f = bu.write_uastc_file([dict(data=s, orig_w=4 * nbx, orig_h=4 * nby, nbx=nbx, nby=nby, image_index=k) for k, s in enumerate(slices)])
+    with pytest.raises(BasisuError) as e:
+        bu.read_to_bc7(f, ctx)
+    assert e.value.status == _lib.ERR_INVALID_MODE

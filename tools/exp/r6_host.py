@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""tools/exp/r6_host.py [matrix] [range] [enqueue] : round-6 host-side measurements on one MI355X (UASTC -> BC7).
+  matrix   launch policy {exclusive, shared, auto} x launches in flight {1..4}: us per 2^20-block atlas (streams window, 256 timed launches)
+  range    bu_uastc_transcode_device_sync over 2^20..2^25 blocks: one launch (threshold off) against pieces in flight (threshold at 2^20), host clock per call
+  enqueue  bu_uastc_transcode_batch_in_flight over 512 atlases in separate allocations, call + synchronize: enqueue threads on / off
+Run with GPU_MAX_HW_QUEUES=8 for the pool-stream figures, without it for the CU-mask ones."""
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from basisu_rs_amd import Context, _lib, synth  # noqa: E402
+
+what = set(sys.argv[1:]) or {"matrix", "range", "enqueue"}
+dev = torch.device("cuda", 0)
+golden = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
+g_u, g_b = torch.from_numpy(golden["uastc"]).to(dev), torch.from_numpy(golden["bc7"]).to(dev)
+NB = 1 << 20
+print("GPU_MAX_HW_QUEUES=%s BU_STREAM_MODE=%s" % (os.environ.get("GPU_MAX_HW_QUEUES"), os.environ.get("BU_STREAM_MODE")))
+
+
+def atlases(n):
+    idxs = [torch.randint(0, 608, (NB,), device=dev, generator=torch.Generator(device=dev).manual_seed(11 + k)) for k in range(n)]
+    return idxs, [g_u[i].contiguous() for i in idxs], [torch.zeros((NB, 16), dtype=torch.uint8, device=dev) for _ in range(n)]
+
+
+if "matrix" in what:
+    ctx = Context(0)
+    lib = ctx._lib
+    print("in flight:", ctx.query_in_flight(4), "sharing now:", ctx.probe_streams(4))
+    nbuf = 64
+    idxs, ins, outs = atlases(nbuf)
+    PA = ctypes.c_void_p * nbuf
+    ip, op = PA(*[t.data_ptr() for t in ins]), PA(*[t.data_ptr() for t in outs])
+    status = torch.empty(1, dtype=torch.int64, device=dev)
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    rot = [0]
+
+    def win(lead, k, nfl):
+        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+        tail = nfl if nfl > 1 else 0
+        st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, ip, op, nbuf, rot[0] % nbuf, NB, 1024, lead, k, tail, nfl,
+                                                       ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None)
+        assert st == 0
+        rot[0] += lead + k + tail
+        return max(ev.value, host.value) * 1e3 / k
+
+    for _ in range(20):
+        win(0, 256, 4)
+    for rnd in range(2):
+        for pol in ("exclusive", "shared", "auto"):
+            ctx.set_launch_policy({"exclusive": False, "shared": True, "auto": "auto"}[pol])
+            row = []
+            for nfl in (1, 2, 3, 4):
+                win(64, 256, nfl)
+                row.append(min(win(512, 256, nfl) for _ in range(3)))
+            print("%-10s " % pol + "  ".join("S%d %.2f" % (i + 1, v) for i, v in enumerate(row)))
+    torch.cuda.synchronize()
+    ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(nbuf))
+    print("verified:", ok)
+    ctx.close()
+    del ins, outs
+
+if "range" in what:
+    big = 1 << 25
+    idx = torch.randint(0, 608, (big,), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    d_in = g_u[idx].contiguous()
+    d_out = torch.zeros((big, 16), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    import subprocess
+
+    if "--child" not in sys.argv:  # (the threshold is read once per process: each setting runs in a child)
+        del d_in, d_out
+        for thr in ("30", "20"):
+            env = dict(os.environ, BU_RANGE_IN_FLIGHT_MIN_LOG2=thr)
+            print("-- threshold 2^%s (%s)" % (thr, "one launch" if thr == "30" else "pieces in flight"))
+            sys.stdout.flush()
+            subprocess.run([sys.executable, os.path.abspath(__file__), "range", "--child"], env=env, check=True)
+    else:
+        ctx = Context(0)
+        for lg in (20, 21, 22, 23, 24, 25):
+            n = 1 << lg
+            reps = max(8, (1 << 27) >> lg)
+            # cold rotation inside the 2^25-block buffers
+            slots = big // n
+            for _ in range(3):
+                ctx.transcode_device_sync(_lib.BC7, d_in, n, d_out, blocks_per_row=1024)
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for r in range(reps):
+                    o = (r % slots) * n
+                    assert ctx.transcode_device_sync(_lib.BC7, d_in[o:o + n], n, d_out[o:o + n], blocks_per_row=1024) == _lib.STATUS_WORD_CLEAR
+                best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+            print("2^%d blocks: %8.2f us per call  %.3f of 8 TB/s" % (lg, best, 32.0 * n / best / 1e6 / 8000.0))
+        ok = bool(torch.equal(d_out, g_b[idx]))
+        print("verified:", ok)
+        ctx.close()
+
+if "enqueue" in what and "--child" not in sys.argv:
+    n = 512
+    idxs, ins, outs = atlases(64)
+    # 512 slices over 64 buffers would alias outputs: use 512 distinct (in, out) views of 8 big allocations instead -> separate runs (gaps between them)
+    ins = ins * 8
+    outs2 = [torch.zeros((NB, 16), dtype=torch.uint8, device=dev) for _ in range(64)]
+    for label, envv in (("enqueue threads (default)", None), ("one enqueue thread", "0")):
+        if envv is None:
+            os.environ.pop("BU_ENQUEUE_THREADS", None)
+        else:
+            os.environ["BU_ENQUEUE_THREADS"] = envv
+        ctx = Context(0)
+        status = torch.empty(1, dtype=torch.int64, device=dev)
+        ctx.status_word_reset(status)
+        torch.cuda.synchronize()
+        outs_all = (outs + outs2) * 4
+        ins_all = ins[:128] * 4
+
+        def run():
+            ctx.transcode_batch_in_flight(_lib.BC7, ins_all, [NB] * n, outs_all, blocks_per_row=1024, d_status=status, n_streams=4)
+            ctx.synchronize()
+
+        for _ in range(4):
+            run()
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            run()
+            ts.append((time.perf_counter() - t0) / n * 1e6)
+        ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(64))
+        print("%-28s %.3f us per atlas (median of 7; min %.3f)  verified %s  in flight %s" % (label, sorted(ts)[3], min(ts), ok, ctx.query_in_flight(4)))
+        ctx.close()
