@@ -205,8 +205,8 @@ class Context:
         self._check(st)
 
     def transcode_device_sync(self, fmt, d_in, n_blocks, d_out, blocks_per_row=0, block_index_base=0):
-        """bu_uastc_transcode_device_sync: a contiguous device-resident range, blocking; from 2^22 blocks on as launches in flight on the context's own
-        streams.  Returns the status word (STATUS_WORD_CLEAR or lowest failing block << 8 | status); never raises for a block error"""
+        """bu_uastc_transcode_device_sync: a contiguous device-resident range, blocking; one exclusive launch, tile tickets on long walks.
+        Returns the status word (STATUS_WORD_CLEAR or lowest failing block << 8 | status); never raises for a block error"""
         word = ctypes.c_uint64(0)
         st = self._lib.bu_uastc_transcode_device_sync(self._h, int(fmt), _ptr(d_in), int(n_blocks), _ptr(d_out), int(blocks_per_row), int(block_index_base),
                                                       ctypes.byref(word))

