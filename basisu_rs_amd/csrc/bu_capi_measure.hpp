@@ -159,6 +159,17 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
 // host_ms = steady clock from "every start event seen complete" to "every end event seen complete".
 // n_streams == 1, tail == 0 is bu_time_uastc_launches_window on a context stream.
 }  // extern "C"
+// the per-stream window events.  Timing-only: no system-scope fence when they complete (hipEventDisableSystemFence) -- a default event writes the
+// caches back and invalidates them, under the launches that are running beside it on the other streams
+static bu_status bu_window_events(bu_context* ctx, int n_streams)
+{
+    for (int i = 0; i < n_streams; i++) {
+        if (!ctx->ev_start[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_start[i], hipEventDisableSystemFence));
+        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_end[i], hipEventDisableSystemFence));
+    }
+    return BU_OK;
+}
+
 template <class LAUNCH>  // bu_status launch(int i, hipStream_t s): enqueue launch number i (lead, timed and tail launches are numbered through) on s
 static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int tail, int n_streams, float* out_event_ms, float* out_host_ms,
                                    float* out_fill_drain_ms, int* out_late, LAUNCH launch)
@@ -169,11 +180,12 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
         const bu_status sst = bu_ctx_streams(ctx, n_streams);
         if (sst) return sst;
     }
-    for (int i = 0; i < n_streams; i++) {
-        // timing-only events: no system-scope fence when they complete (hipEventDisableSystemFence) -- a default event writes the caches back and
-        // invalidates them, under the launches that are running beside it on the other streams; the streams are synchronised before the call returns
-        if (!ctx->ev_start[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_start[i], hipEventDisableSystemFence));
-        if (!ctx->ev_end[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_end[i], hipEventDisableSystemFence));
+    // (ev0, the per-stream events and the win_* fields are the context's: a whole-file or host-pointer call on the same context from another thread
+    //  re-records ev0 -- one window at a time, and not beside those calls)
+    std::lock_guard<std::mutex> window_guard(ctx->lock);
+    {
+        const bu_status est = bu_window_events(ctx, n_streams);
+        if (est) return est;
     }
     BuDrain drain(ctx);
     BU_HIP(ctx, hipEventRecord(ctx->ev0, ctx->extra_streams[0]));  // the reference point of every time below
@@ -216,6 +228,7 @@ static bu_status bu_streams_window(bu_context* ctx, int lead, int launches, int 
         }
         for (auto& t : th) t.join();
         if (!spawned) {
+            std::lock_guard<std::mutex> eg(ctx->err_lock);
             snprintf(ctx->err, sizeof(ctx->err), "bu_streams_window: could not start an enqueue thread");
             return BU_ERR_HIP;
         }
@@ -283,6 +296,65 @@ extern "C" {
 // event (behind its last lead launch), out_end_ms[i] = its end event (behind its last timed launch), -1 for a stream without timed
 // launches; both arrays hold 8 floats.  Streams that run in step start and end within a few periods of each other; streams that share a
 // hardware queue with something else fall behind, and "latest start to latest end" then no longer brackets `launches` completions.
+// Window events around PRODUCT calls (bench.py times bu_uastc_transcode_batch_in_flight with them): which = 0 records the context's start
+// event, which = 1 its end event, on every own stream 0..n_streams-1, behind whatever the caller enqueued there so far.  The pattern is that of
+// bu_streams_window: a call that enqueues lead work, mark 0, the call that enqueues the timed work, mark 1, a call that enqueues tail work,
+// bu_time_marks_elapsed.  Only enqueues.
+bu_status bu_time_mark_streams(bu_context* ctx, int n_streams, int which)
+{
+    if (!ctx || n_streams < 1 || n_streams > 8 || (which != 0 && which != 1)) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    bu_status st = bu_ctx_streams(ctx, n_streams);
+    if (st) return st;
+    std::lock_guard<std::mutex> g(ctx->lock);
+    st = bu_window_events(ctx, n_streams);
+    if (st) return st;
+    for (int i = 0; i < n_streams; i++) BU_HIP(ctx, hipEventRecord(which ? ctx->ev_end[i] : ctx->ev_start[i], ctx->extra_streams[i]));
+    return BU_OK;
+}
+
+// waits for both marks of streams 0..n_streams-1 (polling), then: *out_event_ms = latest end event - LATEST start event (the timed work's
+// completions in a pipeline that is full at both instants), *out_strict_ms (optional) = latest end - EARLIEST start (first instruction of the
+// timed work to its last), *out_host_ms (optional) = host clock from "every start event seen complete" to "every end event seen complete" (valid
+// when the caller came here before the start events completed).  The per-stream times are left for bu_time_last_window_streams (ms from the earliest start).
+bu_status bu_time_marks_elapsed(bu_context* ctx, int n_streams, float* out_event_ms, float* out_strict_ms, float* out_host_ms)
+{
+    if (!ctx || n_streams < 1 || n_streams > 8 || !out_event_ms) return BU_ERR_ARGUMENT;
+    BU_HIP(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> g(ctx->lock);
+    for (int i = 0; i < n_streams; i++)
+        if (!ctx->ev_start[i] || !ctx->ev_end[i]) return BU_ERR_ARGUMENT;
+    std::chrono::steady_clock::time_point t0, t1, t;
+    for (int i = 0; i < n_streams; i++) {
+        const bu_status st = bu_spin_event(ctx, ctx->ev_start[i], &t);
+        if (st) return st;
+        if (i == 0 || t > t0) t0 = t;
+    }
+    t1 = t0;
+    for (int i = 0; i < n_streams; i++) {
+        const bu_status st = bu_spin_event(ctx, ctx->ev_end[i], &t);
+        if (st) return st;
+        if (t > t1) t1 = t;
+    }
+    float s[8], e[8], s_min = 0, s_max = 0, e_max = 0;
+    for (int i = 0; i < n_streams; i++) {
+        BU_HIP(ctx, hipEventElapsedTime(&s[i], ctx->ev_start[0], ctx->ev_start[i]));
+        BU_HIP(ctx, hipEventElapsedTime(&e[i], ctx->ev_start[0], ctx->ev_end[i]));
+        if (i == 0 || s[i] < s_min) s_min = s[i];
+        if (i == 0 || s[i] > s_max) s_max = s[i];
+        if (i == 0 || e[i] > e_max) e_max = e[i];
+    }
+    ctx->win_streams = n_streams;
+    for (int i = 0; i < n_streams; i++) {
+        ctx->win_start_ms[i] = s[i] - s_min;
+        ctx->win_end_ms[i] = e[i] - s_min;
+    }
+    *out_event_ms = e_max - s_max;
+    if (out_strict_ms) *out_strict_ms = e_max - s_min;
+    if (out_host_ms) *out_host_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    return BU_OK;
+}
+
 bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, float* out_end_ms, int* out_n_streams)
 {
     if (!ctx || !out_start_ms || !out_end_ms || !out_n_streams) return BU_ERR_ARGUMENT;

@@ -53,19 +53,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ETC1S_UNPINNED = "unpinned: the reference holds no ETC1S / BasisLZ vectors (tests/corpus_tests.rs:54-73 are #[ignore]d, the corpus absent); checked against the oracle's reading of the source"
 
 
-IN_STEP_PERIODS = 16  # start events of a window's streams further apart than this many launch periods: the streams are not in step
+IN_STEP_PERIODS = 16  # start events of a window's streams further apart than this many launch periods: the streams are not in step (long windows)
 
 
-def streams_out_of_step(streams, period_us, in_flight, queue_sharing=1):
+def in_step_periods(steps, in_flight):
+    """the spread of the start events, in launch periods, up to which a window of `steps` timed launches counts as in step.  A pipeline in step has its start
+    events in_flight - 1 periods apart, give or take a burst (recorded: 15-35 us at 5.7 us per period); an absolute bound of 16 periods is 80 % of a K = 20
+    window -- a stream that far behind finishes its last timed launches with fewer partners and `latest start -> latest end` reads short -- so short windows
+    get a bound that scales with them: K / 2 periods, at least in_flight + 4, at most 16.  (The window also carries TWO tail launches per stream, so a
+    stream up to 2 x in_flight periods behind still has partners until its end event.)"""
+    if not steps:
+        return IN_STEP_PERIODS
+    return max(in_flight + 4, min(IN_STEP_PERIODS, steps // 2))
+
+
+def streams_out_of_step(streams, period_us, in_flight, queue_sharing=1, steps=None):
     """(out_of_step, start-event spread in us) of a pipelined window.  `streams` = {"start_us": [...], "end_us": [...]} per stream (-1: a stream
     without timed launches), from bu_time_last_window_streams.  A window "latest start event -> latest end event" holds its K completions only
     while the streams run in step: their start events then lie in_flight - 1 periods apart, give or take a burst.  Streams that share a hardware
-    queue (`queue_sharing` > 1, bu_context_probe_streams) run at a fraction of the others' pace and end up thousands of microseconds behind."""
+    queue (`queue_sharing` > 1, bu_context_probe_streams) run at a fraction of the others' pace and end up thousands of microseconds behind.
+    `steps` = the window's K (None: the absolute bound of long windows)."""
     if not streams or in_flight <= 1:
         return False, 0.0
     st = [x for x in streams["start_us"] if x >= 0]
     spread = (max(st) - min(st)) if st else 0.0
-    return bool(spread > IN_STEP_PERIODS * period_us or queue_sharing > 1), spread
+    return bool(spread > in_step_periods(steps, in_flight) * period_us or queue_sharing > 1), spread
 
 
 def pmc_traffic():
@@ -626,6 +638,52 @@ def measure_gather(env, full_buf, shard_bytes, verify=None, reps=10):
     return out
 
 
+class ProductWindow:
+    """A timed window around the PRODUCT's own pipelined entry point.  A step = one contiguous run of `nb` blocks (an atlas, or the slices a rank owns of a
+    texture array); steps rotate through `ins` / `outs`.  window(lead, K, tail) is three calls of bu_uastc_transcode_batch_in_flight -- `lead` steps, the K
+    timed steps, `tail` steps, each call one slice per step -- with the context's timing-only events recorded on its streams between the calls
+    (bu_time_mark_streams) and no host synchronisation in between: the window runs from the last lead launch's completion to the last timed launch's
+    (bu_time_marks_elapsed), exactly as the helper-driven windows do, but every launch inside it was planned, shaped and enqueued by the call a user makes."""
+
+    def __init__(self, env, target, ins, outs, nb, bpr, status, n_streams=4):
+        self.env, self.lib, self.ctx, self.target, self.nb, self.bpr, self.n_streams = env, env.lib, env.ctx, target, nb, bpr, n_streams
+        self.ins, self.outs, self.status = list(ins), list(outs), ctypes.c_void_p(status)
+        self.rot = 0
+        self.streams = None
+
+    def _args(self, steps):
+        n = len(self.ins)
+        VP, SZ = ctypes.c_void_p * steps, ctypes.c_size_t * steps
+        a = (steps, VP(*[self.ins[(self.rot + i) % n] for i in range(steps)]), SZ(*([self.nb] * steps)), VP(*[self.outs[(self.rot + i) % n] for i in range(steps)]))
+        self.rot = (self.rot + steps) % n
+        return a
+
+    def _call(self, a):
+        check(self.env, self.lib.bu_uastc_transcode_batch_in_flight(self.ctx.handle, self.target, a[0], a[1], a[2], a[3], self.bpr, None, self.status, self.n_streams),
+              "bu_uastc_transcode_batch_in_flight")
+
+    def window(self, lead, steps, tail=None):
+        """(event ms, strict-bracket ms, host ms) of `steps` timed steps"""
+        if tail is None:
+            tail = 2 * self.n_streams if lead else 0
+        parts = [self._args(k) if k else None for k in (lead, steps, tail)]  # (argument arrays first: nothing but the calls between the marks)
+        h, S = self.ctx.handle, self.n_streams
+        if parts[0]:
+            self._call(parts[0])
+        check(self.env, self.lib.bu_time_mark_streams(h, S, 0), "bu_time_mark_streams")
+        self._call(parts[1])
+        check(self.env, self.lib.bu_time_mark_streams(h, S, 1), "bu_time_mark_streams")
+        if parts[2]:
+            self._call(parts[2])
+        ev, strict, host = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+        check(self.env, self.lib.bu_time_marks_elapsed(h, S, ctypes.byref(ev), ctypes.byref(strict), ctypes.byref(host)), "bu_time_marks_elapsed")
+        a_, b_, n_ = (ctypes.c_float * 8)(), (ctypes.c_float * 8)(), ctypes.c_int(0)
+        if self.lib.bu_time_last_window_streams(h, a_, b_, ctypes.byref(n_)) == 0:
+            self.streams = {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
+        self.ctx.synchronize()  # (the tail)
+        return ev.value, strict.value, host.value
+
+
 def run_array512(env):
     """BASELINE config 5: one texture array of 512 slices x (1024x1024 px = 65 536 blocks) -> BC7, strong scaling"""
     torch, dist, lib, ctx, args = env.torch, env.dist, env.lib, env.ctx, env.args
@@ -636,7 +694,8 @@ def run_array512(env):
     per = -(-n_slices // world)  # slots of the gather buffer (ragged world sizes pad the last shards)
     shard_bytes = per * bps * 16
     # rotation: enough distinct shard inputs / full outputs that a step's traffic cannot sit in the 256 MiB Infinity Cache
-    nrot = min(8, max(2, world))
+    # (and enough that the steps in flight together -- --in-flight of them, plus the one being enqueued -- never share an output buffer)
+    nrot = max(min(8, max(2, world)), min(8, args.in_flight + 2))
 
     def slice_idx(s):  # A-gold arrangement of slice s: any rank can regenerate any slice (verification after the gather)
         gen = torch.Generator(device=dev)
@@ -652,36 +711,41 @@ def run_array512(env):
     fulls = [RawDeviceBuffer(env, world * shard_bytes) for _ in range(nrot)]
     status = torch.empty(1, dtype=torch.int64, device=dev)
     ctx.status_word_reset(status)
-    # A rank issues its range of slices as P equal pieces on P context streams under the shared launch policy (--in-flight, default 4): launches
-    # queued on one stream never overlap and even a 2^25-block launch leaves a seventh of the HBM rate unused (one launch 189 us = 0.71 of the
-    # roofline; four launches of 2^23 blocks in flight 172-177 us = 0.76-0.78).  P = 1 (ragged splits, --in-flight 1): one launch over the range.
-    P = args.in_flight if (args.in_flight > 1 and (hi - lo) % args.in_flight == 0) else 1
-    ctx.set_launch_policy(P > 1 and args.policy == "shared")
+    # P steps (arrays) are in flight together on P context streams (--in-flight, default 4): launches queued on one stream never overlap, and launches of
+    # different streams fill each other's load phases and tails (2^25-block launches: one at a time 188.5 us fixed walk / 174 with tile tickets, four in
+    # flight 167-171 us per array).  P = 1 (--in-flight 1): one launch over the range at a time.
+    P = args.in_flight if args.in_flight > 1 else 1
+    ctx.set_launch_policy("auto")  # (the pipelined entry point shapes its own launches; the one-launch fallback picks per call)
     lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
-    queue_sharing = ctx.probe_streams(P) if P > 1 else 1  # (the communicator of the N > 1 branch exists by now)
-    npiece = nb // P
-    PtrArr = ctypes.c_void_p * (nrot * P)
-    in_ptrs = PtrArr(*[t.data_ptr() + q * npiece * 16 for t in ins for q in range(P)])
-    out_ptrs = PtrArr(*[f.ptr + rank * shard_bytes + q * npiece * 16 for f in fulls for q in range(P)])
-    rot = [0]  # in steps; step r uses buffer entries r*P .. r*P + P - 1
+    effective_streams, stream_mode = ctx.query_in_flight(P) if P > 1 else (1, "pool")
+    queue_sharing = ctx.probe_streams(P) if P > 1 else 1  # measured NOW (the communicator of the N > 1 branch exists by now)
+    rot = [0]  # in steps
     PtrArr1 = ctypes.c_void_p * nrot
     in_ptrs1 = PtrArr1(*[t.data_ptr() for t in ins])  # the range as ONE launch (the fallback when the streams are out of step)
     out_ptrs1 = PtrArr1(*[f.ptr + rank * shard_bytes for f in fulls])
     last_streams = [None]
 
+    # The timed region issues the PRODUCT's pipelined entry point: one call of bu_uastc_transcode_batch_in_flight carries K steps, each step = this rank's
+    # whole range as one slice (-> one launch under the shared policy, step i on context stream i % P: P steps in flight), with the context's timing-only
+    # events between the lead, timed and tail calls (ProductWindow).  What a rank of a real job calls is what is timed, for every N.
+    pw = ProductWindow(env, env._lib.BC7, [t.data_ptr() for t in ins], [f.ptr + rank * shard_bytes for f in fulls], nb, 256, status.data_ptr(), P) if P > 1 else None
+
     def window(lead_steps, steps, pieces=None):
-        """`steps` passes over this rank's range (`pieces` launches each, default P), behind `lead_steps` untimed ones; (event ms, host ms) of the timed part"""
+        """`steps` passes over this rank's range behind `lead_steps` untimed ones; (event ms, host ms) of the timed part.  pieces = 1 (the fallback when the
+        streams are out of step, and --in-flight 1): one bu_uastc_transcode_device per step on the context's stream 0, one launch at a time"""
         q = P if pieces is None else pieces
-        ip, op = (in_ptrs, out_ptrs) if q == P else (in_ptrs1, out_ptrs1)
+        if q > 1:
+            pw.rot = rot[0] % nrot
+            ev_, _strict, host_ = pw.window(lead_steps, steps)
+            rot[0] = pw.rot
+            last_streams[0] = pw.streams
+            return ev_, host_
         ev, host = ctypes.c_float(0), ctypes.c_float(0)
-        tail = q if (q > 1 and lead_steps > 0) else 0
-        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, env._lib.BC7, ip, op, nrot * q, (rot[0] % nrot) * q, nb // q, 256, lead_steps * q, steps * q,
-                                                             tail, q, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None),
+        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, env._lib.BC7, in_ptrs1, out_ptrs1, nrot, rot[0] % nrot, nb, 256, lead_steps, steps,
+                                                             0, 1, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), None, None),
               "bu_time_uastc_launches_streams_window")
-        rot[0] = (rot[0] + lead_steps + steps + (1 if tail else 0)) % nrot
-        a_, b_, n_ = (ctypes.c_float * 8)(), (ctypes.c_float * 8)(), ctypes.c_int(0)
-        if lib.bu_time_last_window_streams(ctx.handle, a_, b_, ctypes.byref(n_)) == 0:
-            last_streams[0] = {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
+        rot[0] = (rot[0] + lead_steps + steps) % nrot
+        last_streams[0] = None
         return ev.value, host.value
 
     def run(launches):
@@ -711,8 +775,8 @@ def run_array512(env):
     torch.cuda.synchronize()
 
     def warm_async(i, ssp):
-        k = ((rot[0] + i) % nrot) * P
-        lib.bu_uastc_transcode_device(ctx.handle, env._lib.BC7, ctypes.c_void_p(in_ptrs[k]), npiece, ctypes.c_void_p(out_ptrs[k]), 256, 0, None, ssp)
+        k = (rot[0] + i) % nrot
+        lib.bu_uastc_transcode_device(ctx.handle, env._lib.BC7, ctypes.c_void_p(in_ptrs1[k]), nb, ctypes.c_void_p(out_ptrs1[k]), 256, 0, None, ssp)
 
     busy_barrier(env, warm_async, max(2, 12 // world))  # ~3 ms of work
     # timed region as in run_atlas4096: lead untimed steps, K timed steps, (P > 1: one tail launch per stream), no host sync in between;
@@ -726,18 +790,17 @@ def run_array512(env):
     # the streams have to be in step for the window to hold `steps` completions of every stream (run_atlas4096 has the story): start events more than
     # 16 launch periods apart mean two streams share a hardware queue -- then the range is timed again as ONE launch per step on one stream
     timed_streams = last_streams[0]
-    oos_, spread_us = streams_out_of_step(timed_streams, ev_ms * 1e3 / (args.steps * P), P, queue_sharing)
+    oos_, spread_us = streams_out_of_step(timed_streams, ev_ms * 1e3 / args.steps, P, queue_sharing, steps=args.steps)
     oos = torch.tensor([1.0 if oos_ else 0.0], dtype=torch.float64, device=dev)
     if env.use_dist:
         dist.all_reduce(oos, op=dist.ReduceOp.MAX)
     out_of_step = bool(oos.item() > 0)
     P_timed = P
     if out_of_step:
-        ctx.set_launch_policy(False)
+        ctx.set_launch_policy("auto")
         window(0, 2, pieces=1)
         ev_ms, host_ms = window(4, args.steps, pieces=1)
         torch.cuda.synchronize()
-        ctx.set_launch_policy(P > 1 and args.policy == "shared")
         P_timed = 1
     dt = max(host_ms, ev_ms) / 1e3
     if env.use_dist:
@@ -763,9 +826,12 @@ def run_array512(env):
         "ms_per_step": round(dt_max / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "UASTC->BC7, texture array of 512 slices x 65 536 blocks (512 MiB in, 512 MiB out) per step; rank r owns "
-                               "slices [r*512/N, (r+1)*512/N) and issues its contiguous range as %d launch(es) of %d blocks on %d context stream(s) (%s launch "
-                               "policy); A-gold blocks; %d rotated input shards / full output buffers per rank" % (P, npiece, P, "shared" if (P > 1 and args.policy == "shared") else "exclusive", nrot),
-                   "launches_in_flight": P_timed,
+                               "slices [r*512/N, (r+1)*512/N); the timed region is ONE call of the product's pipelined entry point "
+                               "(bu_uastc_transcode_batch_in_flight) carrying the K steps, each step = the rank's contiguous range of %d blocks as one slice = one launch, "
+                               "step i on context stream i %% %d (shared launch shapes; lead and tail steps through the same call in front of and behind it); A-gold blocks; "
+                               "%d rotated input shards / full output buffers per rank" % (nb, P, nrot),
+                   "launches_in_flight": P_timed, "timed_through": "bu_uastc_transcode_batch_in_flight" if P_timed > 1 else "bu_uastc_transcode_device (one launch at a time, context stream 0)",
+                   "effective_streams": effective_streams, "stream_mode": stream_mode,
                    "timed_region": {"streams": timed_streams, "start_event_spread_us": round(spread_us, 1), "streams_in_step": not out_of_step,
                                     "streams_on_one_hardware_queue_max": queue_sharing,
                                     "note": None if not out_of_step else (
@@ -876,7 +942,7 @@ def run_atlas4096(env):
         per stream, `tail` untimed launches (default: one per stream when the pipeline was filled by lead launches)"""
         nfl = in_flight or args.in_flight
         if tail is None:
-            tail = nfl if (nfl > 1 and lead >= nfl) else 0
+            tail = 2 * nfl if (nfl > 1 and lead >= nfl) else 0  # (two per stream: a stream a few periods behind still has partners until its end event)
         ev, host, fd, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
         st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, in_ptrs, out_ptrs, nbuf, rot[0] % nbuf, N_BLOCKS, NBX, lead, launches, tail,
                                                        nfl, ctypes.c_void_p(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(fd), ctypes.byref(late))
@@ -927,6 +993,7 @@ def run_atlas4096(env):
     lib.bu_time_set_enqueue_threads(ctx.handle, args.enqueue_threads)
     # does every stream of the timed region have a hardware queue of its own in this process (the communicator of the N > 1 branch exists by now)?
     queue_sharing = ctx.probe_streams(args.in_flight) if args.in_flight > 1 else 1
+    effective_streams, stream_mode = ctx.query_in_flight(args.in_flight) if args.in_flight > 1 else (1, "pool")  # (what the library found when it created its streams)
     ctx.status_word_reset(status)
     torch.cuda.synchronize()  # (the context's streams do not wait for torch's)
     run_window(0, nbuf)       # one launch per atlas, round-robin over the streams
@@ -1002,7 +1069,7 @@ def run_atlas4096(env):
         ks_ = {(lead + j) % args.in_flight: ks_[j] for j in range(args.in_flight)}
         rate_ = sum(ks_[s_] / (sk_["end_us"][s_] - sk_["start_us"][s_]) for s_ in range(args.in_flight) if sk_["start_us"][s_] >= 0 and sk_["end_us"][s_] > sk_["start_us"][s_])
         by_rates_us = round(1.0 / rate_, 3) if rate_ > 0 else None
-    oos_, start_spread_us = streams_out_of_step(sk_, period_s * 1e6, args.in_flight, queue_sharing)
+    oos_, start_spread_us = streams_out_of_step(sk_, period_s * 1e6, args.in_flight, queue_sharing, steps=args.steps)
     out_of_step = torch.tensor([1.0 if oos_ else 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(out_of_step, op=dist.ReduceOp.MAX)
@@ -1075,14 +1142,17 @@ def run_atlas4096(env):
         # launches in flight x launch policy (the headline's cell among its neighbours; same window method, same rotation, 256 timed launches)
         try:
             mat = {}
-            for pol in ("exclusive", "shared"):
+            pol_arg = {"exclusive": False, "shared": True, "auto": "auto"}
+            for pol in ("exclusive", "shared", "auto"):
                 mat[pol] = {}
                 for nfl in (1, 2, 3, 4):
-                    srow(64, nfl, pol == "shared")
-                    mat[pol][str(nfl)] = round(srow(256, nfl, pol == "shared") * 1e6, 3)
+                    srow(64, nfl, pol_arg[pol])
+                    mat[pol][str(nfl)] = round(srow(256, nfl, pol_arg[pol]) * 1e6, 3)
             torch.cuda.synchronize()
             extra["launches_in_flight_matrix"] = {"us_per_atlas": mat, "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
-                                                  "note": "UASTC->BC7, 2^20 blocks per launch, step i on context stream i %% n; rows = launch policy, columns = launches in flight; "
+                                                  "auto_matches_the_better_row": all(mat["auto"][c] <= 1.03 * min(mat["exclusive"][c], mat["shared"][c]) for c in ("1", "4")),
+                                                  "note": "UASTC->BC7, 2^20 blocks per launch, step i on context stream i %% n; rows = launch policy (auto = BU_LAUNCH_AUTO, the default: chosen "
+                                                          "per call -- exclusive for a launch that is alone, shared once another of the context's streams has work in flight), columns = launches in flight; "
                                                           "every one of the %d rotated outputs compared with the known answers afterwards" % nbuf}
             # cross-check of the overlap claim through the product's other route to it: TWO atlases in ONE launch -- two slices that are contiguous in
             # memory handed to bu_uastc_transcode_batch_device, which merges them into one plain launch of 2^21 blocks (exclusive policy, one stream,
@@ -1317,6 +1387,70 @@ def run_atlas4096(env):
                                                                 "allocation; the call cuts the run into four launches of 2^23 blocks on four context streams): 16 calls back to back, "
                                                                 "then bu_context_synchronize, host clock around all of it / 16 (median of five).  us_per_array_one_call_then_wait: a "
                                                                 "single call and the wait, starting on an idle chip and ending with a wake-up"}
+                # ... and the array through the product's pipelined entry point the way `--config array512` times it for every N: K arrays per call, one launch
+                # per array, four arrays in flight; lead / timed / tail calls with the context's timing-only events between them (ProductWindow)
+                try:
+                    more_in = [torch.roll(big_in[0], shifts=977 * (r_ + 1), dims=0).contiguous() for r_ in range(4)]
+                    more_out = [torch.empty((nbig, 16), dtype=torch.uint8, device=dev) for _ in range(4)]
+                    pwa = ProductWindow(env, _lib.BC7, [t.data_ptr() for t in big_in + more_in], [t.data_ptr() for t in big_out + more_out], nbig, 256, status.data_ptr(), 4)
+                    for t_ in big_out:
+                        t_.zero_()
+                    torch.cuda.synchronize()
+                    pwa.window(0, 6)
+                    pw_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0])) and bool(torch.equal(more_out[1], torch.roll(big_out[0], shifts=977 * 2, dims=0)))
+                    t_big = time.perf_counter()
+                    while args.prewarm_ms > 0 and (time.perf_counter() - t_big) * 1e3 < 4 * args.prewarm_ms:
+                        pwa.window(0, 12)
+                    pw_runs = sorted(pwa.window(24, 40) for _ in range(3))
+                    pw_ev, pw_strict, pw_host = pw_runs[1]
+                    pw_s = max(pw_ev, pw_host) / 1e3 / 40
+                    extra["array512_through_product_api"] = {
+                        "blocks": nbig, "us_per_array": round(pw_s * 1e6, 2), "mblocks_s": round(nbig / pw_s / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * nbig / pw_s / 1e9, 1),
+                        "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / pw_s / 1e9 / HBM_PEAK_GBS, 4), "verified": pw_ok,
+                        "us_per_array_strict_bracket": round(pw_strict / 40 * 1e3, 2), "streams": pwa.streams,
+                        "ratio_to_four_launches_in_flight": round(pw_s / b4_s, 4),
+                        "note": "the 512-slice array through bu_uastc_transcode_batch_in_flight exactly as `--config array512` times it: ONE call carries 40 arrays (one "
+                                "slice = one 2^25-block launch each, array i on context stream i % 4, shared shapes), 24 lead arrays in the call in front, 8 tail arrays "
+                                "in the call behind, the context's timing-only events between the calls (bu_time_mark_streams / bu_time_marks_elapsed): last lead "
+                                "launch complete -> last timed launch complete; median of three windows; six rotated 1 GiB pairs"}
+                    del more_in, more_out, pwa
+                except Exception as e:
+                    extra["array512_through_product_api_error"] = repr(e)
+                # ONE launch over the array on one of the context's OWN streams: the exclusive shape with tile tickets (workgroups draw their tiles from
+                # counters instead of walking fixed shares; `array512_one_launch` above runs on the caller's stream and keeps the fixed walk)
+                try:
+                    ctx.set_launch_policy("auto")
+
+                    def big1(lead, launches):
+                        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+                        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, bi, bo, 2, 0, nbig, 256, lead, launches, 0, 1, ctypes.c_void_p(status.data_ptr()),
+                                                                             ctypes.byref(ev), ctypes.byref(host), None, None), "bu_time_uastc_launches_streams_window")
+                        return max(ev.value, host.value) / 1e3 / launches
+
+                    for t_ in big_out:
+                        t_.zero_()
+                    torch.cuda.synchronize()
+                    big1(0, 2)
+                    torch.cuda.synchronize()
+                    tk_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0]))
+                    big1(0, 24)
+                    tk_s = big1(8, 40)
+                    t0_ = time.perf_counter()
+                    n_sync = 12
+                    for r_ in range(n_sync):
+                        assert ctx.transcode_device_sync(_lib.BC7, big_in[r_ % 2], nbig, big_out[r_ % 2], blocks_per_row=256) == _lib.STATUS_WORD_CLEAR
+                    sync_s = (time.perf_counter() - t0_) / n_sync
+                    extra["array512_one_launch_tile_tickets"] = {
+                        "blocks": nbig, "us_per_launch": round(tk_s * 1e6, 2), "mblocks_s": round(nbig / tk_s / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * nbig / tk_s / 1e9, 1),
+                        "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / tk_s / 1e9 / HBM_PEAK_GBS, 4), "verified": tk_ok,
+                        "blocking_call_us_per_array": round(sync_s * 1e6, 2), "blocking_call_frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / sync_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "one launch per array, one at a time, on context stream 0 (8 lead + 40 timed launches between events): from 16 tiles per workgroup on "
+                                "the persistent workgroups draw their tiles by ticket (eight counters in device memory, drawn one tile ahead) instead of walking fixed "
+                                "shares -- the launch ends when the tiles do, not when the slowest share does (profiles/r06_ab_tile_tickets.txt).  blocking_call: "
+                                "bu_uastc_transcode_device_sync per array on the host clock (launch from an idle chip + kernel + completion seen by polling), what "
+                                "bu_array_transcode_sharded and sharded.gpu_transcode_fn run per device"}
+                except Exception as e:
+                    extra["array512_one_launch_tile_tickets_error"] = repr(e)
             finally:
                 ctx.set_launch_policy(policy_now[0])
             a512 = pmc_array512()
@@ -1607,6 +1741,7 @@ def run_atlas4096(env):
                                    nbuf, ("%d launches in flight on %d streams (step i on context stream i %% %d), %s launch policy" % (
                                        args.in_flight, args.in_flight, args.in_flight, args.policy)) if args.in_flight > 1 else "one launch at a time on one stream, %s launch policy" % args.policy),
                    "launches_in_flight": args.in_flight, "launch_policy": args.policy,
+                   "effective_streams": effective_streams, "stream_mode": stream_mode,
                    "hip_runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "streams_on_one_hardware_queue_max": queue_sharing,
                                        "note": "bu_context_probe_streams over the streams of the timed region: 1 = every stream has its own hardware queue"},
                    "blocks_per_step_per_gpu": N_BLOCKS, "gb_s_in": round(value * 16 / 1e3, 1),
@@ -1617,15 +1752,15 @@ def run_atlas4096(env):
                                     "streams_of_median_window": wins[m_][4], "streams_of_strict_bracket": strict_streams,
                                     "start_event_spread_us": round(start_spread_us, 1), "streams_in_step": not out_of_step,
                                     "us_per_step_by_stream_rates": by_rates_us,
-                                    "tail_launches": args.in_flight if args.in_flight > 1 else 0,
+                                    "tail_launches": 2 * args.in_flight if args.in_flight > 1 else 0,
                                     "note": "barrier + synchronize, then -- everything enqueued up front, step i on stream i % in_flight -- lead untimed launches, a start "
-                                            "event per stream behind its last lead launch, K timed launches, an end event per stream behind its last timed launch, one untimed "
-                                            "tail launch per stream.  Launches in flight are a pipeline, so the K steps are counted as completions: window = from the LAST "
+                                            "event per stream behind its last lead launch, K timed launches, an end event per stream behind its last timed launch, two untimed "
+                                            "tail launches per stream.  Launches in flight are a pipeline, so the K steps are counted as completions: window = from the LAST "
                                             "start event (every lead launch has completed) to the LAST end event (every timed launch has completed) on the device clock; "
                                             "host clock from every start event seen complete to every end event seen complete; value uses max(host, event).  The pipeline "
                                             "is full at both instants (what the first timed launches got done beside the last lead launches, the tail launches get done "
                                             "beside the last timed ones).  us_per_step_by_stream_rates: the same window read stream by stream -- 1 / sum over the streams of "
-                                            "(its timed launches / (its end event - its start event)); streams_in_step: the start events lie within 16 periods and no two "
+                                            "(its timed launches / (its end event - its start event)); streams_in_step: the start events lie within max(in_flight + 4, min(16, K / 2)) periods and no two "
                                             "streams share a hardware queue (bu_context_probe_streams).  --steps 512 gives the same figure with the ends weighing 25 times less"}},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,

@@ -452,6 +452,14 @@ bu_status bu_time_last_window_streams(bu_context* ctx, float* out_start_ms, floa
  * *out_ms / *out_launches = an UPPER bound of what one enqueue costs this host (waits for space in a full hardware queue are inside); at or
  * above the pipeline's period the host, not the chip, may be setting the pace */
 bu_status bu_time_last_window_enqueue(bu_context* ctx, float* out_ms, int* out_launches);
+/* The same window around PRODUCT calls instead of the helper's own launches (bench.py --config array512 and the *_through_product_api rows time
+ * bu_uastc_transcode_batch_in_flight this way): bu_time_mark_streams(ctx, n, 0) records a timing-only start event, (ctx, n, 1) an end event, on the
+ * context's own streams 0..n-1 behind what has been enqueued there -- call that enqueues lead work, mark 0, call that enqueues the timed work,
+ * mark 1, call that enqueues tail work -- and bu_time_marks_elapsed waits for the marks: *out_event_ms = latest end - LATEST start (the timed
+ * work's completions in a full pipeline), *out_strict_ms = latest end - EARLIEST start, *out_host_ms = the host clock between "all starts
+ * seen complete" and "all ends seen complete"; the per-stream times are read with bu_time_last_window_streams. */
+bu_status bu_time_mark_streams(bu_context* ctx, int n_streams, int which);
+bu_status bu_time_marks_elapsed(bu_context* ctx, int n_streams, float* out_event_ms, float* out_strict_ms, float* out_host_ms);
 #define BU_TIME_COPY_CEILING 100 /* as `target` of the call below: the uint4 -> uint4 copy kernel (bu_copy_ceiling_device) in place of a transcode */
 bu_status bu_time_uastc_launches_streams_window(bu_context* ctx, bu_target target, const void* const* d_in, void* const* d_out,
                                                 size_t n_buffers, size_t first_buffer, size_t n_blocks, size_t blocks_per_row,

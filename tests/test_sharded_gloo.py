@@ -218,6 +218,7 @@ def test_bench_in_step_rule_on_recorded_windows():
     a512 = {"start_us": [2744.9, 2775.6, 2829.7, 2860.7], "end_us": [6214.3, 6270.5, 6299.9, 6350.5]}
     oos, spread = bench.streams_out_of_step(plain, 5.82, 4)
     assert not oos and abs(spread - 33.4) < 0.01
+    spread_plain = spread
     oos, spread = bench.streams_out_of_step(dist8, 5.74, 4)
     assert oos and spread > 5000
     oos, spread = bench.streams_out_of_step(a512, 174.5 / 4, 4)
@@ -227,3 +228,9 @@ def test_bench_in_step_rule_on_recorded_windows():
     assert bench.streams_out_of_step(dist8, 5.74, 1) == (False, 0.0)             # one launch at a time: nothing to be in step with
     assert bench.streams_out_of_step(None, 5.8, 4) == (False, 0.0)
     assert bench.IN_STEP_PERIODS == 16
+    # the bound scales with the window (round 6): K = 20 -> 10 periods, K = 8 -> in_flight + 4, K = 512 -> 16
+    assert [bench.in_step_periods(k, 4) for k in (None, 8, 20, 24, 512)] == [16, 8, 10, 12, 16]
+    assert bench.streams_out_of_step(plain, 5.82, 4, steps=20) == (False, spread_plain)     # 33.4 us = 5.7 periods: in step
+    lag = {"start_us": [100.0, 105.0, 111.0, 100.0 + 13 * 5.8], "end_us": [220.0, 226.0, 231.0, 300.0]}
+    assert not bench.streams_out_of_step(lag, 5.8, 4)[0]                                     # 13 periods: inside the absolute bound ...
+    assert bench.streams_out_of_step(lag, 5.8, 4, steps=20)[0]                               # ... but 65 % of a K = 20 window
