@@ -46,14 +46,18 @@ inline void bu_merge_runs(size_t n_slices, const void* const* d_in, const size_t
 // The launches of bu_uastc_transcode_batch_in_flight.
 // 1. Consecutive runs are grouped into launches of about 2^20 blocks (below that a launch is bound by the host's ~4 us): a group is closed
 //    when it holds 2^20 blocks or `max_runs` runs, a run of 2^20 blocks or more is a group of its own.
-// 2. A batch that makes fewer launches than streams has its largest single-run groups cut into equal pieces, as long as a piece keeps at
-//    least 2^20 blocks.  Pieces end on tile boundaries: 1024 blocks, and with a pitch 16 block rows of it (the rectangular tiles of the
-//    kernels; RGBA32 needs whole block rows) -- lcm(16 * blocks_per_row, 1024).
+// 2. With more than one stream, a single-run group of more than 2^23 blocks is cut into equal pieces of at most 2^23: launches of 2^22-2^23 blocks
+//    are what a pipeline of four runs best on (per 2^25-block array, four in flight: 2^20-block launches 179 us, 2^22 175, 2^23 175-176, 2^25
+//    178-184 -- a launch's 512 persistent workgroups walk fixed shares, and the longer the walk the longer its uneven tail;
+//    profiles/r06_in_flight_launch_size.txt).
+// 3. A batch that still makes fewer launches than streams has its largest single-run groups cut further, as long as a piece keeps at least 2^20
+//    blocks.  Pieces end on tile boundaries: 1024 blocks, and with a pitch 16 block rows of it (the rectangular tiles of the kernels; RGBA32
+//    needs whole block rows) -- lcm(16 * blocks_per_row, 1024).
 // Every block of every run is in exactly one launch, in order; pieces carry their share of the run's block numbering.
 inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, size_t blocks_per_row, size_t block_bytes, size_t max_runs,
                               std::vector<BuLaunchGroup>& groups, std::vector<BuRun>& pieces)
 {
-    constexpr size_t GROUP_BLOCKS = (size_t)1 << 20;
+    constexpr size_t GROUP_BLOCKS = (size_t)1 << 20, MAX_LAUNCH_BLOCKS = (size_t)1 << 23;
     groups.clear();
     pieces.clear();
     for (size_t i = 0; i < runs.size();) {
@@ -66,7 +70,18 @@ inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, siz
         }
         groups.push_back(g);
     }
-    if (groups.empty() || groups.size() >= (size_t)n_streams) return;
+    if (groups.empty() || n_streams <= 1) return;
+    // pieces per group: by size first ...
+    std::vector<size_t> want(groups.size(), 1);
+    size_t launches = 0;
+    bool any_cut = false;
+    for (size_t k = 0; k < groups.size(); k++) {
+        if (groups[k].count == 1 && groups[k].blocks > MAX_LAUNCH_BLOCKS) {
+            want[k] = (groups[k].blocks + MAX_LAUNCH_BLOCKS - 1) / MAX_LAUNCH_BLOCKS;
+            any_cut = true;
+        }
+        launches += want[k];
+    }
     size_t align = 1024;
     if (blocks_per_row) {
         size_t a = blocks_per_row * 16, b = 1024;  // gcd
@@ -77,29 +92,36 @@ inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, siz
         }
         align = blocks_per_row * 16 / a * 1024;
     }
-    std::vector<BuLaunchGroup> cut;
-    size_t spare = (size_t)n_streams - groups.size();  // additional launches wanted
-    const size_t n_groups = groups.size();
-    for (const BuLaunchGroup& g : groups) {
-        size_t n_pieces = 1;
-        if (g.count == 1 && spare > 0) {
-            n_pieces = 1 + (spare + n_groups - 1) / n_groups;
-            while (n_pieces > 1 && ((g.blocks / n_pieces) / align) * align < GROUP_BLOCKS) n_pieces--;
+    // ... then, if the batch still has fewer launches than streams, more pieces for the single-run groups while a piece keeps 2^20 blocks
+    if (launches < (size_t)n_streams) {
+        const size_t spare = (size_t)n_streams - launches, n_groups = groups.size();
+        for (size_t k = 0; k < groups.size() && launches < (size_t)n_streams; k++) {
+            const BuLaunchGroup& g = groups[k];
+            if (g.count != 1) continue;
+            size_t n_pieces = want[k] + (spare + n_groups - 1) / n_groups;
+            while (n_pieces > want[k] && ((g.blocks / n_pieces) / align) * align < GROUP_BLOCKS) n_pieces--;
+            if (n_pieces > want[k]) {
+                launches += n_pieces - want[k];
+                want[k] = n_pieces;
+                any_cut = true;
+            }
         }
-        if (n_pieces <= 1) {
+    }
+    if (!any_cut) return;
+    std::vector<BuLaunchGroup> cut;
+    for (size_t k = 0; k < groups.size(); k++) {
+        const BuLaunchGroup& g = groups[k];
+        if (want[k] <= 1) {
             cut.push_back(g);
             continue;
         }
         const BuRun r = runs[g.first];
-        const size_t per = ((r.n + n_pieces - 1) / n_pieces + align - 1) / align * align;
-        size_t made = 0;
+        const size_t per = ((r.n + want[k] - 1) / want[k] + align - 1) / align * align;
         for (size_t done = 0; done < r.n; done += per) {
             const size_t n = r.n - done < per ? r.n - done : per;
             pieces.push_back(BuRun{r.in + done * 16, r.out + done * block_bytes, n, r.base + done});
             cut.push_back(BuLaunchGroup{runs.size() + pieces.size() - 1, 1, n});
-            made++;
         }
-        spare -= made - 1 < spare ? made - 1 : spare;
     }
     groups.swap(cut);
 }

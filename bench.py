@@ -1332,6 +1332,43 @@ def run_atlas4096(env):
                                             "verified": big_ok,
                                             "note": "BASELINE config 5 on ONE GPU: 512 slices x 65 536 blocks contiguous, one launch per step, cold (two 1 GiB "
                                                     "pairs rotated), 8 lead + 40 timed launches between events; `--config array512` is the sharded form"}
+            # ONE launch over the array on one of the context's OWN streams: the exclusive shape with tile tickets (workgroups draw their tiles from
+            # counters instead of walking fixed shares; `array512_one_launch` above runs on the caller's stream and keeps the fixed walk)
+            try:
+                ctx.set_launch_policy(False)  # (exclusive, as the row above; BU_LAUNCH_AUTO picks the same for a launch that is alone)
+
+                def big1(lead, launches):
+                    ev, host = ctypes.c_float(0), ctypes.c_float(0)
+                    check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, bi, bo, 2, 0, nbig, 256, lead, launches, 0, 1, ctypes.c_void_p(status.data_ptr()),
+                                                                         ctypes.byref(ev), ctypes.byref(host), None, None), "bu_time_uastc_launches_streams_window")
+                    return max(ev.value, host.value) / 1e3 / launches
+
+                for t_ in big_out:
+                    t_.zero_()
+                torch.cuda.synchronize()
+                big1(0, 2)
+                torch.cuda.synchronize()
+                tk_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0]))
+                t_big = time.perf_counter()
+                while args.prewarm_ms > 0 and (time.perf_counter() - t_big) * 1e3 < 4 * args.prewarm_ms:  # (as the row above: these launches take ~100 ms to settle the clocks)
+                    big1(0, 8)
+                tk_s = sorted(big1(8, 40) for _ in range(3))[1]
+                t0_ = time.perf_counter()
+                n_sync = 12
+                for r_ in range(n_sync):
+                    assert ctx.transcode_device_sync(_lib.BC7, big_in[r_ % 2], nbig, big_out[r_ % 2], blocks_per_row=256) == _lib.STATUS_WORD_CLEAR
+                sync_s = (time.perf_counter() - t0_) / n_sync
+                extra["array512_one_launch_tile_tickets"] = {
+                    "blocks": nbig, "us_per_launch": round(tk_s * 1e6, 2), "mblocks_s": round(nbig / tk_s / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * nbig / tk_s / 1e9, 1),
+                    "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / tk_s / 1e9 / HBM_PEAK_GBS, 4), "verified": tk_ok,
+                    "blocking_call_us_per_array": round(sync_s * 1e6, 2), "blocking_call_frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / sync_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "one launch per array, one at a time, on context stream 0 (8 lead + 40 timed launches between events): from 16 tiles per workgroup on "
+                            "the persistent workgroups draw their tiles by ticket (eight counters in device memory, drawn one tile ahead) instead of walking fixed "
+                            "shares -- the launch ends when the tiles do, not when the slowest share does (profiles/r06_ab_tile_tickets.txt).  blocking_call: "
+                            "bu_uastc_transcode_device_sync per array on the host clock (launch from an idle chip + kernel + completion seen by polling), what "
+                            "bu_array_transcode_sharded and sharded.gpu_transcode_fn run per device"}
+            except Exception as e:
+                extra["array512_one_launch_tile_tickets_error"] = repr(e)
             # the same array as FOUR launches of 2^23 blocks in flight on four context streams (shared policy): what `--config array512` does per rank
             try:
                 bi4 = (ctypes.c_void_p * 8)(*[t.data_ptr() + q * (nbig // 4) * 16 for t in big_in for q in range(4)])
@@ -1416,41 +1453,6 @@ def run_atlas4096(env):
                     del more_in, more_out, pwa
                 except Exception as e:
                     extra["array512_through_product_api_error"] = repr(e)
-                # ONE launch over the array on one of the context's OWN streams: the exclusive shape with tile tickets (workgroups draw their tiles from
-                # counters instead of walking fixed shares; `array512_one_launch` above runs on the caller's stream and keeps the fixed walk)
-                try:
-                    ctx.set_launch_policy("auto")
-
-                    def big1(lead, launches):
-                        ev, host = ctypes.c_float(0), ctypes.c_float(0)
-                        check(env, lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, bi, bo, 2, 0, nbig, 256, lead, launches, 0, 1, ctypes.c_void_p(status.data_ptr()),
-                                                                             ctypes.byref(ev), ctypes.byref(host), None, None), "bu_time_uastc_launches_streams_window")
-                        return max(ev.value, host.value) / 1e3 / launches
-
-                    for t_ in big_out:
-                        t_.zero_()
-                    torch.cuda.synchronize()
-                    big1(0, 2)
-                    torch.cuda.synchronize()
-                    tk_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0]))
-                    big1(0, 24)
-                    tk_s = big1(8, 40)
-                    t0_ = time.perf_counter()
-                    n_sync = 12
-                    for r_ in range(n_sync):
-                        assert ctx.transcode_device_sync(_lib.BC7, big_in[r_ % 2], nbig, big_out[r_ % 2], blocks_per_row=256) == _lib.STATUS_WORD_CLEAR
-                    sync_s = (time.perf_counter() - t0_) / n_sync
-                    extra["array512_one_launch_tile_tickets"] = {
-                        "blocks": nbig, "us_per_launch": round(tk_s * 1e6, 2), "mblocks_s": round(nbig / tk_s / 1e6, 1), "gb_s": round(BYTES_PER_BLOCK * nbig / tk_s / 1e9, 1),
-                        "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / tk_s / 1e9 / HBM_PEAK_GBS, 4), "verified": tk_ok,
-                        "blocking_call_us_per_array": round(sync_s * 1e6, 2), "blocking_call_frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / sync_s / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": "one launch per array, one at a time, on context stream 0 (8 lead + 40 timed launches between events): from 16 tiles per workgroup on "
-                                "the persistent workgroups draw their tiles by ticket (eight counters in device memory, drawn one tile ahead) instead of walking fixed "
-                                "shares -- the launch ends when the tiles do, not when the slowest share does (profiles/r06_ab_tile_tickets.txt).  blocking_call: "
-                                "bu_uastc_transcode_device_sync per array on the host clock (launch from an idle chip + kernel + completion seen by polling), what "
-                                "bu_array_transcode_sharded and sharded.gpu_transcode_fn run per device"}
-                except Exception as e:
-                    extra["array512_one_launch_tile_tickets_error"] = repr(e)
             finally:
                 ctx.set_launch_policy(policy_now[0])
             a512 = pmc_array512()

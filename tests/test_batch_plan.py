@@ -71,14 +71,15 @@ def test_large_slices_one_launch_each_small_ones_grouped(plan):
     assert [int(x) for x in rows[:, 0]] == [0, 1, 2, 2, 2, 2, 3]
 
 
-def test_contiguous_array_is_cut_into_one_piece_per_stream(plan):
+def test_contiguous_array_is_cut_into_pieces_of_at_most_2_23_blocks_and_one_per_stream_at_least(plan):
     n_slices, per = 512, 65536
     in_addr = [0x4000_0000 + k * per * 16 for k in range(n_slices)]
     out_addr = [0x9000_0000_00 + k * per * 16 for k in range(n_slices)]
-    for streams in (1, 2, 3, 4, 8):
+    for streams, want in ((1, 1), (2, 4), (3, 4), (4, 4), (8, 8)):  # 2^25 blocks: one launch on one stream, else pieces of <= 2^23, at least one per stream
         rows, launches = plan(in_addr, [per] * n_slices, out_addr, 16, None, streams, 256)
         _check_cover(rows, in_addr, [per] * n_slices, out_addr, 16, None)
-        assert launches == streams and len(rows) == streams
+        assert launches == want and len(rows) == want, (streams, launches)
+        assert streams == 1 or max(int(r[3]) for r in rows) <= (1 << 23)
         align = 16 * 256  # lcm(16 rows of 256 blocks, 1024)
         assert all(int(r[3]) % align == 0 for r in rows[:-1])
         assert max(int(r[3]) for r in rows) - min(int(r[3]) for r in rows) <= align
@@ -89,6 +90,11 @@ def test_contiguous_array_is_cut_into_one_piece_per_stream(plan):
     rows, launches = plan(in_addr, [per] * 8, out_addr, 64, None, 4, bpr)
     _check_cover(rows, in_addr, [per] * 8, out_addr, 64, None)
     assert launches == 4 and all(int(r[3]) % bpr == 0 and int(r[3]) % 1024 == 0 for r in rows[:-1]) and int(rows[-1][3]) % bpr == 0
+    # several large arrays in one call (more launches than streams already): every one is still cut to <= 2^23-block launches
+    big = 1 << 25
+    rows, launches = plan([0x4000_0000 + k * (big * 16 + 4096) for k in range(5)], [big] * 5, [0x9000_0000_00 + k * (big * 16 + 4096) for k in range(5)], 16, None, 4, 256)
+    _check_cover(rows, [0x4000_0000 + k * (big * 16 + 4096) for k in range(5)], [big] * 5, [0x9000_0000_00 + k * (big * 16 + 4096) for k in range(5)], 16, None)
+    assert launches == 20 and all(int(r[3]) == (1 << 23) for r in rows)
     # a piece never falls below 2^20 blocks: 3 Mi blocks on 8 streams make three launches, 1.5 Mi blocks one
     for total, want in ((3 << 20, 3), (3 << 19, 1)):
         rows, launches = plan([0x4000_0000], [total], [0x9000_0000_00], 16, None, 8, 0)
@@ -128,3 +134,4 @@ def test_random_slice_tables_cover_every_block_once(plan):
         for j, ns in per_launch.items():
             # a launch of several runs stops growing at 2^20 blocks: without its last run it is below
             assert len(ns) == 1 or sum(ns[:-1]) < (1 << 20), (case, j, ns)
+            assert streams == 1 or len(ns) > 1 or ns[0] <= (1 << 23), (case, j, ns)

@@ -139,3 +139,84 @@ if "enqueue" in what and "--child" not in sys.argv:
         ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(64))
         print("%-28s %.3f us per atlas (median of 7; min %.3f)  verified %s  in flight %s" % (label, sorted(ts)[3], min(ts), ok, ctx.query_in_flight(4)))
         ctx.close()
+
+if "pw" in what:
+    # the same 2^25-block launches, four in flight, shared shapes: (a) the measurement helper's window (bu_uastc_transcode_device per launch), (b) the product's
+    # pipelined entry point (three calls of bu_uastc_transcode_batch_in_flight, timing marks between them) -- alternating, one process
+    ctx = Context(0)
+    lib = ctx._lib
+    big, nbuf = 1 << 25, int(os.environ.get("PW_NBUF", "8"))
+    idx0 = torch.randint(0, 608, (big,), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    ins = [g_u[idx0].contiguous()]
+    ins += [torch.roll(ins[0], shifts=977 * (k + 1), dims=0).contiguous() for k in range(nbuf - 1)]
+    outs = [torch.zeros((big, 16), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    status = torch.empty(1, dtype=torch.int64, device=dev)
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    PA = ctypes.c_void_p * nbuf
+    ip, op = PA(*[t.data_ptr() for t in ins]), PA(*[t.data_ptr() for t in outs])
+    sp = ctypes.c_void_p(status.data_ptr())
+    bpr = int(os.environ.get("PW_BPR", "256"))
+
+    def helper(lead, k):
+        ctx.set_launch_policy(True)
+        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+        assert lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, ip, op, nbuf, 0, big, bpr, lead, k, 8 if lead else 0, 4, sp, ctypes.byref(ev), ctypes.byref(host), None, None) == 0
+        return ev.value * 1e3 / k
+
+    def args_for(first, steps):
+        VP, SZ = ctypes.c_void_p * steps, ctypes.c_size_t * steps
+        return steps, VP(*[ins[(first + i) % nbuf].data_ptr() for i in range(steps)]), SZ(*([big] * steps)), VP(*[outs[(first + i) % nbuf].data_ptr() for i in range(steps)])
+
+    def product(lead, k):
+        ctx.set_launch_policy("auto")
+        parts = [args_for(0, lead) if lead else None, args_for(lead, k), args_for(lead + k, 8) if lead else None]
+        call = lambda a: lib.bu_uastc_transcode_batch_in_flight(ctx.handle, _lib.BC7, a[0], a[1], a[2], a[3], bpr, None, sp, 4)  # noqa: E731
+        if parts[0]:
+            assert call(parts[0]) == 0
+        assert lib.bu_time_mark_streams(ctx.handle, 4, 0) == 0
+        assert call(parts[1]) == 0
+        assert lib.bu_time_mark_streams(ctx.handle, 4, 1) == 0
+        if parts[2]:
+            assert call(parts[2]) == 0
+        ev, strict, host = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+        assert lib.bu_time_marks_elapsed(ctx.handle, 4, ctypes.byref(ev), ctypes.byref(strict), ctypes.byref(host)) == 0
+        ctx.synchronize()
+        return ev.value * 1e3 / k
+
+    for _ in range(4):
+        helper(0, 16)
+    for rnd in range(3):
+        print("round %d: helper window %.2f us per array   product calls %.2f   helper %.2f   product %.2f" % (rnd, helper(24, 40), product(24, 40), helper(24, 40), product(24, 40)))
+    torch.cuda.synchronize()
+    print("verified:", bool(torch.equal(outs[0], g_b[idx0])))
+    ctx.close()
+
+if "one" in what:
+    # ONE exclusive 2^25-block launch at a time on context stream 0 (tile tickets unless BU_TILE_TICKETS=0), PW_NBUF rotated pairs, PW_BPR blocks per row
+    ctx = Context(0)
+    lib = ctx._lib
+    big, nbuf = 1 << 25, int(os.environ.get("PW_NBUF", "8"))
+    bpr = int(os.environ.get("PW_BPR", "256"))
+    idx0 = torch.randint(0, 608, (big,), device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    ins = [g_u[idx0].contiguous()]
+    ins += [torch.roll(ins[0], shifts=977 * (k + 1), dims=0).contiguous() for k in range(nbuf - 1)]
+    outs = [torch.zeros((big, 16), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    status = torch.empty(1, dtype=torch.int64, device=dev)
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    PA = ctypes.c_void_p * nbuf
+    ip, op = PA(*[t.data_ptr() for t in ins]), PA(*[t.data_ptr() for t in outs])
+    sp = ctypes.c_void_p(status.data_ptr())
+    ctx.set_launch_policy(False)
+
+    def one(lead, k, st=sp):
+        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+        assert lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, ip, op, nbuf, 0, big, bpr, lead, k, 0, 1, st, ctypes.byref(ev), ctypes.byref(host), None, None) == 0
+        return ev.value * 1e3 / k
+
+    one(0, 24)
+    print("nbuf %d bpr %d tickets %s: with status word %.2f %.2f   without %.2f %.2f us per launch" % (nbuf, bpr, os.environ.get("BU_TILE_TICKETS", "1"), one(8, 40), one(8, 40), one(8, 40, None), one(8, 40, None)))
+    torch.cuda.synchronize()
+    print("verified:", bool(torch.equal(outs[0], g_b[idx0])))
+    ctx.close()
