@@ -246,10 +246,17 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         // 8.4 for plain launches one after another and 9.2-10.2 through the round-4 table kernel without the prefetch); ETC1 / ETC2 keep
         // the one-tile-at-a-time shape (their large shape sorts 4096-block tiles, the table numbers 1024-block ones).
         const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
+        // Launch policy of a grouped launch.  Under the shared policy (launches of other streams run beside this one: bu_uastc_transcode_batch_in_flight
+        // with groups of small runs) the PERSISTENT grid is capped at half of every CU -- two workgroups of 512 threads for BC7 / ASTC (16 of the 32 wave
+        // slots, 56 of the 160 KiB), one for RGBA32 -- so that two such launches fit side by side; the one-tile-per-CU shape and the ETC shape are the same
+        // under both policies (a tile's 1024 threads cannot be halved; the ETC tiles are resident one at a time anyway).
+        int pol = policy < 0 ? ctx->launch_policy.load(std::memory_order_relaxed) : policy;
+        if (pol == BU_POLICY_AUTO) pol = one_per_cu ? (int)BU_POLICY_EXCLUSIVE : bu_auto_policy(ctx, s);
+        const bool half = pol == BU_POLICY_SHARED;
         auto go = [&](auto tgt) {
             constexpr int T = decltype(tgt)::value;
             constexpr bool PERSIST = T == BU_TGT_BC7 || T == BU_TGT_ASTC || T == BU_TGT_RGBA;
-            const size_t cap = (size_t)ctx->cu_count * (PERSIST ? (T == BU_TGT_RGBA ? 2 : 4) : 7);  // (beyond seven workgroups per CU they walk the tiles, as bu_launch_uastc)
+            const size_t cap = (size_t)ctx->cu_count * (PERSIST ? (T == BU_TGT_RGBA ? (half ? 1 : 2) : (half ? 2 : 4)) : 7);  // (beyond seven workgroups per CU they walk the tiles, as bu_launch_uastc)
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
             if (one_per_cu)
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
