@@ -1230,6 +1230,23 @@ def run_atlas4096(env):
                 "note": "ONE call of bu_uastc_transcode_batch_in_flight over 512 slices of 2^20 blocks in separate allocations (the 64 atlases eight times over) on four "
                         "context streams + bu_context_synchronize, host clock around both (median of five calls): the headline's pipeline as an entry point, its fill, "
                         "drain and the final wake-up included"}
+            # ... and the headline's window itself around that entry point: [call over 2048 lead atlases][start marks][call over K timed atlases][end marks]
+            # [call over 8 tail atlases], the context's timing-only events between the calls (ProductWindow) -- every launch of the window planned, shaped and
+            # enqueued by the call a user makes (from 256 launches per call on: by one enqueue thread per stream)
+            pwh = ProductWindow(env, _lib.BC7, list(in_ptrs), list(out_ptrs), N_BLOCKS, NBX, status.data_ptr(), 4)
+            k_pw = max(args.steps, 256)
+            pwh.window(0, 256)
+            pw_h = sorted(pwh.window(2048, k_pw) for _ in range(3))[1]
+            pw_hs = max(pw_h[0], pw_h[2]) / 1e3 / k_pw
+            torch.cuda.synchronize()
+            extra["headline_through_product_api"] = {
+                "us_per_atlas": round(pw_hs * 1e6, 3), "mblocks_s": round(N_BLOCKS / pw_hs / 1e6, 1), "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / pw_hs / 1e9 / HBM_PEAK_GBS, 4),
+                "timed_atlases": k_pw, "us_per_atlas_strict_bracket": round(pw_h[1] / k_pw * 1e3, 3), "streams": pwh.streams,
+                "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
+                "note": "the headline's timed window with bu_uastc_transcode_batch_in_flight doing the launches: one call carries the timed atlases (one slice = one launch each, "
+                        "launch i on context stream i % 4, shared shapes), 2048 lead atlases in the call in front, 8 tail atlases in the call behind, timing-only events of "
+                        "the context between the calls (bu_time_mark_streams / bu_time_marks_elapsed): last lead launch complete -> last timed launch complete; median of "
+                        "three windows; max(event, host) clock"}
         except Exception as e:  # secondary rows must never break the headline line
             extra["launches_in_flight_matrix_error"] = repr(e)
         # a loop over 64 independent slices of 65 536 blocks (256 x 256 blocks: a 1024 x 1024 px mip), the shape of the per-slice
