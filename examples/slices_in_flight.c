@@ -78,18 +78,20 @@ int main(int argc, char** argv)
 
     st = bu_context_create(0, &ctx);
     if (st) return fail(NULL, "bu_context_create", st);
-    st = bu_context_set_launch_policy(ctx, BU_LAUNCH_SHARED); /* a launch keeps at most half of every CU: launches interleave */
-    if (st) return fail(ctx, "bu_context_set_launch_policy", st);
+    /* the launch policy stays at its default, BU_LAUNCH_AUTO: a launch on one of the context's streams takes the half-CU shape exactly when
+       another of them has work in flight (here: every launch but the first) */
     for (t = 0; t < STREAMS; t++) {
         st = bu_context_stream(ctx, t, &streams[t]);
         if (st) return fail(ctx, "bu_context_stream", st);
     }
-    {   /* are the four streams on four hardware queues?  (results never depend on it; the overlap does) */
-        int sharing = 0;
-        st = bu_context_probe_streams(ctx, STREAMS, &sharing);
-        if (st) return fail(ctx, "bu_context_probe_streams", st);
-        if (sharing > 1)
-            fprintf(stderr, "note: up to %d of the %d streams share a hardware queue and will not overlap: start with GPU_MAX_HW_QUEUES=8 (or more)\n", sharing, STREAMS);
+    {   /* does every stream have a hardware queue of its own?  The context saw to that when it created them (ordinary streams if the runtime's
+           pool has room, CU-mask streams otherwise); results never depend on it, the overlap does */
+        int effective = 0, mode = 0;
+        st = bu_context_query_in_flight(ctx, STREAMS, &effective, &mode);
+        if (st) return fail(ctx, "bu_context_query_in_flight", st);
+        if (effective < STREAMS)
+            fprintf(stderr, "note: the %d streams keep only %d launches in flight in this process (%s streams)\n", STREAMS, effective,
+                    mode == BU_STREAM_QUEUE_CU_MASK ? "CU-mask" : "ordinary");
     }
     st = bu_device_alloc(ctx, (size_t)flen, &d_in);
     if (!st) st = bu_device_alloc(ctx, out_slice_bytes * (size_t)n_slices, &d_out);
