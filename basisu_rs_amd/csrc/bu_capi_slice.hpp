@@ -533,7 +533,9 @@ bu_status bu_context_probe_streams(bu_context* ctx, int n_streams, int* out_max_
         if (st) return st;
     }
     std::lock_guard<std::mutex> g(ctx->stream_lock);  // (the probe events are the context's)
-    return bu_probe_streams_locked(ctx, n_streams, out_max_sharing);
+    hipStream_t ss[8];
+    for (int i = 0; i < n_streams; i++) ss[i] = ctx->extra_streams[i].load(std::memory_order_acquire);
+    return bu_probe_streams_locked(ctx, ss, n_streams, out_max_sharing);
 }
 
 // ---- per-block API (lib.rs:29-53) -----------------------------------------------------------------------------------------------

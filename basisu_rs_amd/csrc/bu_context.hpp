@@ -145,6 +145,7 @@ struct BuShape {
 // streams busy (bu_context_set_launch_policy).
 enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1, BU_POLICY_AUTO = 2 };
 int bu_auto_policy(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: BU_POLICY_AUTO resolved for one launch on `s`
+void bu_note_big_enqueue(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: a large launch under an explicit policy goes to `s`
 unsigned* bu_ticket_for(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: the tile-ticket pair of an own stream, nullptr for anybody else's
 template <int TARGET, int POLICY> struct BuBigShape;
 template <> struct BuBigShape<BU_TGT_BC7, BU_POLICY_EXCLUSIVE> : BuShape<512, 2, 1, true, true, 4> {};
@@ -281,7 +282,9 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         const size_t obytes = bu_target_block_bytes(target);
         if (policy < 0) policy = ctx->launch_policy.load(std::memory_order_relaxed);
         // BU_LAUNCH_AUTO: decided per call, and only where the shapes differ (a launch of more than one tile per CU)
-        if (policy == BU_POLICY_AUTO) policy = (grid_cap == 0 && n_blocks > (size_t)BU_HOST_TILE * ctx->cu_count) ? bu_auto_policy(ctx, stream) : (int)BU_POLICY_EXCLUSIVE;
+        const bool big = grid_cap == 0 && n_blocks > (size_t)BU_HOST_TILE * ctx->cu_count;
+        if (policy == BU_POLICY_AUTO) policy = big ? bu_auto_policy(ctx, stream) : (int)BU_POLICY_EXCLUSIVE;
+        else if (big) bu_note_big_enqueue(ctx, stream);
         constexpr size_t RW = BU_RECT_W;
         BuPiece p;
         p.ticket = grid_cap == 0 ? bu_ticket_for(ctx, stream) : nullptr;

@@ -10,30 +10,30 @@ namespace {
 // *out_sharing = round(time of the probe / one sleep) = the largest number of the probed streams on one queue.  The HIP runtime has no
 // call that says which queue a stream is on.  Caller holds ctx->stream_lock (the probe events are the context's).
 constexpr unsigned long long BU_PROBE_TICKS = 20000;  // 200 us
-bu_status bu_probe_streams_locked(bu_context* ctx, int n, int* out_sharing)
+bu_status bu_probe_streams_locked(bu_context* ctx, const hipStream_t* streams, int n, int* out_sharing)
 {
     if (!ctx->probe_ev0) BU_HIP(ctx, hipEventCreate(&ctx->probe_ev0));
     for (int i = 0; i < n; i++)
         if (!ctx->probe_ev[i]) BU_HIP(ctx, hipEventCreateWithFlags(&ctx->probe_ev[i], hipEventDisableSystemFence));  // (timing only)
     struct Drain {  // an error return must not leave sleeping waves behind events that are about to be reused
-        bu_context* c;
+        const hipStream_t* s;
         int n;
         bool armed = true;
         ~Drain()
         {
             if (!armed) return;
             for (int i = 0; i < n; i++)
-                if (c->extra_streams[i]) (void)hipStreamSynchronize(c->extra_streams[i]);
+                if (s[i]) (void)hipStreamSynchronize(s[i]);
         }
-    } drain{ctx, n};
+    } drain{streams, n};
     float best = 0;
     for (int pass = 0; pass < 2; pass++) {  // (the first pass pays for loading the kernel)
-        BU_HIP(ctx, hipEventRecord(ctx->probe_ev0, ctx->extra_streams[0]));
-        for (int i = 1; i < n; i++) BU_HIP(ctx, hipStreamWaitEvent(ctx->extra_streams[i], ctx->probe_ev0, 0));
+        BU_HIP(ctx, hipEventRecord(ctx->probe_ev0, streams[0]));
+        for (int i = 1; i < n; i++) BU_HIP(ctx, hipStreamWaitEvent(streams[i], ctx->probe_ev0, 0));
         for (int i = 0; i < n; i++) {
-            hipLaunchKernelGGL(bu_sleep_kernel, dim3(1), dim3(64), 0, ctx->extra_streams[i], BU_PROBE_TICKS);
+            hipLaunchKernelGGL(bu_sleep_kernel, dim3(1), dim3(64), 0, streams[i], BU_PROBE_TICKS);
             BU_HIP(ctx, hipGetLastError());
-            BU_HIP(ctx, hipEventRecord(ctx->probe_ev[i], ctx->extra_streams[i]));
+            BU_HIP(ctx, hipEventRecord(ctx->probe_ev[i], streams[i]));
         }
         float worst = 0;
         for (int i = 0; i < n; i++) {
@@ -105,39 +105,39 @@ bu_status bu_ctx_streams(bu_context* ctx, int n)
         hipStream_t made[4] = {nullptr, nullptr, nullptr, nullptr};
         bu_status st = bu_make_stream_group(ctx, made, mode);
         if (st) return st;
-        const auto publish = [&] {
-            for (int i = 0; i < 4; i++) ctx->extra_streams[g0 + i].store(made[i], std::memory_order_release);
-        };
-        const auto unpublish = [&] {
+        // the group is probed together with the streams that exist already, and PUBLISHED (made visible to readers that load the handles without the
+        // lock: bu_context_synchronize, bu_auto_policy) only in its final form
+        hipStream_t all[8];
+        for (int i = 0; i < g0; i++) all[i] = ctx->extra_streams[i].load(std::memory_order_acquire);
+        const auto destroy = [&](hipStream_t* four) {
             for (int i = 0; i < 4; i++) {
-                if (made[i]) (void)hipStreamDestroy(made[i]);
-                made[i] = nullptr;
-                ctx->extra_streams[g0 + i].store(nullptr, std::memory_order_release);
+                if (four[i]) (void)hipStreamDestroy(four[i]);
+                four[i] = nullptr;
             }
         };
-        publish();
+        for (int i = 0; i < 4; i++) all[g0 + i] = made[i];
         int sharing = 1;
-        st = bu_probe_streams_locked(ctx, g0 + 4, &sharing);
+        st = bu_probe_streams_locked(ctx, all, g0 + 4, &sharing);
         if (st) {
-            unpublish();
+            destroy(made);
             return st;
         }
         if (sharing > 1 && mode == BU_STREAMS_PLAIN && forced == 0) {
             hipStream_t masked[4] = {nullptr, nullptr, nullptr, nullptr};
             if (bu_make_stream_group(ctx, masked, BU_STREAMS_CU_MASK) == BU_OK) {  // (a runtime without the extension keeps its plain streams)
-                unpublish();
-                for (int i = 0; i < 4; i++) made[i] = masked[i];
-                publish();
+                destroy(made);
+                for (int i = 0; i < 4; i++) all[g0 + i] = made[i] = masked[i];
                 mode = BU_STREAMS_CU_MASK;
-                st = bu_probe_streams_locked(ctx, g0 + 4, &sharing);
+                st = bu_probe_streams_locked(ctx, all, g0 + 4, &sharing);
                 if (st) {
-                    unpublish();
+                    destroy(made);
                     return st;
                 }
             } else {
                 (void)hipGetLastError();
             }
         }
+        for (int i = 0; i < 4; i++) ctx->extra_streams[g0 + i].store(made[i], std::memory_order_release);
         ctx->stream_mode[grp] = mode;
         ctx->stream_sharing[grp] = sharing;
         ctx->streams_made = g0 + 4;
@@ -158,6 +158,19 @@ bu_status bu_ctx_in_flight_streams(bu_context* ctx, int n, int* out_effective, i
     return BU_OK;
 }
 
+inline long long bu_now_ns() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// a large launch is being enqueued on `s` under an EXPLICIT policy: if `s` is one of the context's own streams, remember when (bu_auto_policy reads it
+// for launches that are left to BU_LAUNCH_AUTO on the other streams -- e.g. a lone bu_uastc_transcode_device beside a running in-flight batch)
+void bu_note_big_enqueue(bu_context* ctx, hipStream_t s)
+{
+    if (!s) return;
+    for (int i = 0; i < 8; i++)
+        if (ctx->extra_streams[i].load(std::memory_order_acquire) == s) {
+            ctx->last_big_enqueue_ns[i].store(bu_now_ns(), std::memory_order_relaxed);
+            return;
+        }
+}
+
 // ---- the launch policy of ONE call (BU_LAUNCH_AUTO) ----------------------------------------------------------------------------
 // A large launch shaped to fill the chip (exclusive) is the fastest way through one slice that is alone (8.4 us per 2^20 blocks against 11.6 for
 // the half-CU shape) and the slower one as soon as launches of other streams run beside it (6.2 against 5.6 with four in flight).  Which of
@@ -167,7 +180,6 @@ bu_status bu_ctx_in_flight_streams(bu_context* ctx, int n, int* out_effective, i
 // ever used, only on this slow path).  Launches on the caller's own streams are exclusive: the library cannot see what runs beside them
 // (bu_context_set_launch_policy(ctx, BU_LAUNCH_SHARED) is the override for such callers).
 constexpr long long BU_AUTO_RECENT_NS = 20000;
-inline long long bu_now_ns() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int bu_auto_policy(bu_context* ctx, hipStream_t s)
 {
     if (!s) return BU_POLICY_EXCLUSIVE;
