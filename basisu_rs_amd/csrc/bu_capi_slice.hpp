@@ -252,7 +252,7 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         // under both policies (a tile's 1024 threads cannot be halved; the ETC tiles are resident one at a time anyway).
         int pol = policy < 0 ? ctx->launch_policy.load(std::memory_order_relaxed) : policy;
         if (pol == BU_POLICY_AUTO) pol = one_per_cu ? (int)BU_POLICY_EXCLUSIVE : bu_auto_policy(ctx, s);
-        const bool half = pol == BU_POLICY_SHARED;
+        const bool half = pol == BU_POLICY_SHARED || pol == BU_POLICY_SHARED_FEW;
         auto go = [&](auto tgt) {
             constexpr int T = decltype(tgt)::value;
             constexpr bool PERSIST = T == BU_TGT_BC7 || T == BU_TGT_ASTC || T == BU_TGT_RGBA;

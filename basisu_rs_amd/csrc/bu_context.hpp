@@ -143,7 +143,8 @@ struct BuShape {
 //   RGBA32      1024 x 1, one per CU (16 waves, 69 KiB)             19.6 / 14.7 / 13.4 / 13.1   (14.7 / 14.2 / 13.8 / 13.6)
 // Alone on the chip a shared-policy launch is 15-40 % slower than an exclusive one: the policy is for callers that keep >= 2
 // streams busy (bu_context_set_launch_policy).
-enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1, BU_POLICY_AUTO = 2 };
+enum { BU_POLICY_EXCLUSIVE = 0, BU_POLICY_SHARED = 1, BU_POLICY_AUTO = 2,
+       BU_POLICY_SHARED_FEW = 3 };  // (internal, picked by bu_auto_policy only: the shared kernels on one-tile workgroups, for one or two other launches in flight)
 int bu_auto_policy(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: BU_POLICY_AUTO resolved for one launch on `s`
 void bu_note_big_enqueue(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: a large launch under an explicit policy goes to `s`
 unsigned* bu_ticket_for(bu_context* ctx, hipStream_t s);  // bu_streams.hpp: the tile-ticket pair of an own stream, nullptr for anybody else's
@@ -238,7 +239,14 @@ void bu_launch_sorted(const BuPiece& p, unsigned cu_count, int policy, unsigned 
     } else if (p.nb <= (size_t)BU_HOST_TILE * cu_count) {
         bu_go<TARGET, BuOneTileShape<TARGET>>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
     } else if (bu_big_from_one_tile_per_cu(TARGET) || p.nb > (size_t)3 * BU_HOST_TILE * cu_count) {
-        if (policy == BU_POLICY_SHARED) bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_SHARED>>(p, cu_count, false);
+        // BU_POLICY_SHARED_FEW (BC7 / ASTC, from bu_auto_policy when one or two other launches are in flight): the shared policy's kernel with the grid at four
+        // workgroups per CU -- 1024 one-tile workgroups dealt by the hardware dispatcher instead of 512 persistent ones walking two tiles each.  With two /
+        // three launches in flight 6.07 / 5.7 us per 2^20-block atlas against 6.95 / 6.1 (shared) and 6.85 / 6.3 (exclusive); with four the persistent form wins
+        // (5.60 against 5.77): profiles/r06_ab_bc7_shared_one_tile_workgroups.txt
+        using SharedShape = BuBigShape<TARGET, BU_POLICY_SHARED>;
+        if (policy == BU_POLICY_SHARED_FEW && bu_big_from_one_tile_per_cu(TARGET))
+            bu_go_big<TARGET, BuShape<SharedShape::WGS, SharedShape::BPT, SharedShape::MINW, SharedShape::PREFETCH, SharedShape::RECT, 4>>(p, cu_count, false);
+        else if (policy == BU_POLICY_SHARED || policy == BU_POLICY_SHARED_FEW) bu_go_big<TARGET, SharedShape>(p, cu_count, false);
         else bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_EXCLUSIVE>>(p, cu_count, true);
     } else {
         bu_go<TARGET, BuEtcMidShape>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
@@ -253,6 +261,7 @@ void bu_launch_sorted(const BuPiece& p, unsigned cu_count, int policy, unsigned 
 void bu_launch_sorted_rgba(const BuPiece& p, unsigned cu_count, int policy, unsigned grid_cap)
 {
     const size_t tiles = (p.nb + BU_HOST_TILE - 1) / BU_HOST_TILE;
+    if (policy == BU_POLICY_SHARED_FEW) policy = BU_POLICY_SHARED;
     const size_t cap = grid_cap ? (size_t)grid_cap : (size_t)cu_count * (policy == BU_POLICY_SHARED ? 1 : 2);
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     // generation priorities only when every workgroup walks at least two tiles (2^19 blocks 10.7 -> 10.3 us and

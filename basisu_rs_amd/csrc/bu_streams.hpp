@@ -175,11 +175,10 @@ void bu_note_big_enqueue(bu_context* ctx, hipStream_t s)
 // A large launch shaped to fill the chip (exclusive) is the fastest way through one slice that is alone (8.4 us per 2^20 blocks against 11.6 for
 // the half-CU shape) and the slower one as soon as launches of other streams run beside it (6.2 against 5.6 with four in flight).  Which of
 // the two a call is in is known at the moment it enqueues: the launch goes to one of the context's OWN streams and another of them has work
-// that has not completed.  "Has work": something was enqueued there within the last BU_AUTO_RECENT_NS of host time (a caller that feeds four
-// streams round-robin comes back every ~5 us: no runtime call at all on that path), else hipStreamQuery says so (one call per stream that was
-// ever used, only on this slow path).  Launches on the caller's own streams are exclusive: the library cannot see what runs beside them
-// (bu_context_set_launch_policy(ctx, BU_LAUNCH_SHARED) is the override for such callers).
-constexpr long long BU_AUTO_RECENT_NS = 20000;
+// that has not completed.  With ONE or TWO others busy the launch takes the shared kernels on one-tile workgroups (BU_POLICY_SHARED_FEW, BC7 / ASTC),
+// with three or more the shared policy's persistent shape.  Launches on the caller's own streams are exclusive: the library cannot see what runs
+// beside them (bu_context_set_launch_policy(ctx, BU_LAUNCH_SHARED) is the override for such callers).
+constexpr long long BU_AUTO_RECENT_NS = 40000;
 int bu_auto_policy(bu_context* ctx, hipStream_t s)
 {
     if (!s) return BU_POLICY_EXCLUSIVE;
@@ -188,29 +187,33 @@ int bu_auto_policy(bu_context* ctx, hipStream_t s)
         if (ctx->extra_streams[i].load(std::memory_order_acquire) == s) me = i;
     if (me < 0) return BU_POLICY_EXCLUSIVE;
     const long long now = bu_now_ns();
-    bool busy = false;
-    for (int j = 0; j < 8 && !busy; j++) {
+    // how many OTHER own streams have work in flight: enqueued there within the last BU_AUTO_RECENT_NS of host time (a caller that feeds n streams
+    // round-robin comes back to each every n x ~5 us: no runtime call at all on that path) ...
+    int busy = 0;
+    bool stale[8] = {false, false, false, false, false, false, false, false};
+    for (int j = 0; j < 8; j++) {
         if (j == me) continue;
         const long long t = ctx->last_big_enqueue_ns[j].load(std::memory_order_relaxed);
-        busy = t != 0 && now - t < BU_AUTO_RECENT_NS;
+        if (t != 0 && now - t < BU_AUTO_RECENT_NS) busy++;
+        else stale[j] = t != 0;
     }
-    if (!busy) {
+    // ... else hipStreamQuery says so (one call per stream that was ever used, only when nothing was enqueued recently)
+    if (busy == 0) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
         if (cap == hipStreamCaptureStatusNone) {  // (a stream query is not something to issue in the middle of a capture)
-            for (int j = 0; j < 8 && !busy; j++) {
-                if (j == me || ctx->last_big_enqueue_ns[j].load(std::memory_order_relaxed) == 0) continue;
+            for (int j = 0; j < 8; j++) {
+                if (!stale[j]) continue;
                 hipStream_t o = ctx->extra_streams[j].load(std::memory_order_acquire);
                 if (!o) continue;
-                busy = hipStreamQuery(o) == hipErrorNotReady;
+                if (hipStreamQuery(o) == hipErrorNotReady) busy++;
                 (void)hipGetLastError();  // (hipErrorNotReady is not an error)
             }
         }
     }
     ctx->last_big_enqueue_ns[me].store(now, std::memory_order_relaxed);
-    return busy ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE;
+    return busy == 0 ? BU_POLICY_EXCLUSIVE : (busy <= 2 ? BU_POLICY_SHARED_FEW : BU_POLICY_SHARED);
 }
-
 
 // The tile-ticket set a persistent launch on `s` draws its tiles from (kernel, `ticket`), or nullptr for the fixed walk.  A pair must never
 // serve two launches at once, and the kernel zeroes it when its last workgroup leaves: launches of ONE stream run one after the other, so every

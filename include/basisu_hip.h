@@ -90,10 +90,12 @@ size_t bu_target_block_bytes(bu_target target);
  *   BU_LAUNCH_SHARED               a launch keeps at most half of every CU's wave slots, registers and LDS, so launches from different
  *                                  streams run side by side on each CU: 5.45-5.6 us per slice with 4 streams (BC7; ASTC 5.4), ETC1 17.7 -> 12.1,
  *                                  ETC2 22.1 -> 15.0, RGBA32 14.9 -> 13.1; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
- *   BU_LAUNCH_AUTO (default)       chosen PER CALL: shared when the launch goes to one of the context's own streams and another of them has
- *                                  work that has not completed (enqueued there within the last 20 us of host time, else one hipStreamQuery per
- *                                  stream ever used), exclusive otherwise -- a lone slice, and every launch on a stream of the caller's own, which
- *                                  the library cannot see beside.  The first launch of a pipeline goes out exclusive, the rest shared.
+ *   BU_LAUNCH_AUTO (default)       chosen PER CALL by how many OTHER streams of the context have work that has not completed (enqueued there within
+ *                                  the last 40 us of host time; if none was, one hipStreamQuery per stream ever used): none -> exclusive (a lone slice:
+ *                                  8.4 us; also every launch on a stream of the caller's own, which the library cannot see beside); three or more ->
+ *                                  shared (5.5-5.7); one or two -> the shared kernels on one-tile workgroups dealt by the hardware (BC7 / ASTC: 6.1 / 5.7
+ *                                  us per slice with two / three in flight, where exclusive gives 6.85 / 6.3 and shared 6.95 / 6.1).  The first launches
+ *                                  of a pipeline go out in the shapes of a shallower one, the rest shared.
  * Figures: profiles/r05_ab_bc7_two_launches_in_flight.txt, r05_ab_wave_priorities_with_launches_in_flight.txt, r05_ab_etc_shared_shapes_x_streams.txt,
  * r06_auto_policy_matrix.txt.  Small launches (at most one 1024-block tile per CU) are the same under all three. */
 typedef enum bu_launch_policy { BU_LAUNCH_EXCLUSIVE = 0, BU_LAUNCH_SHARED = 1, BU_LAUNCH_AUTO = 2 } bu_launch_policy;

@@ -141,6 +141,45 @@ def test_auto_policy_alone_and_in_flight_known_answers(golden, target):
     ctx.close()
 
 
+@pytest.mark.parametrize("target", ["bc7", "astc"])
+def test_auto_policy_two_streams_one_tile_workgroups_ragged_sizes(golden, target):
+    """with one or two other launches in flight the default policy takes the shared kernels on one-tile workgroups (BU_POLICY_SHARED_FEW): strips and rectangles,
+    ragged tails, sizes whose tiles exceed the grid (workgroups walk), the first-error index -- two and three streams round-robin"""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    t, bb = TB[target]
+    gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden[target]).cuda()
+    for n_streams in (2, 3):
+        for bpr, n in [(0, (1 << 20) + 12345), (1024, 1024 * 1056), (96, 96 * 11000), (2048, 2048 * 1040)]:
+            K = 6
+            idxs = [torch.from_numpy(synth.gold_indices(n, seed=1200 + k + n_streams)).cuda() for k in range(K)]
+            ins = [gu[i].contiguous() for i in idxs]
+            outs = [torch.zeros((n, bb), dtype=torch.uint8, device="cuda") for _ in range(K)]
+            status = torch.empty(1, dtype=torch.int64, device="cuda")
+            ctx.status_word_reset(status)
+            torch.cuda.synchronize()
+            for k in range(K):
+                ctx.transcode_device(t, ins[k], n, outs[k], blocks_per_row=bpr, block_index_base=k * n, d_status=status, stream=ctx.stream(k % n_streams))
+            ctx.synchronize()
+            ctx.status_word_check(int(status.item()))
+            for k in range(K):
+                assert torch.equal(outs[k], gt[idxs[k]]), (target, n_streams, bpr, k)
+            ins[4][n - 7, 0] = 69
+            ins[2][n // 3, 0] = 69
+            torch.cuda.synchronize()
+            for k in range(K):
+                ctx.transcode_device(t, ins[k], n, outs[k], blocks_per_row=bpr, block_index_base=k * n, d_status=status, stream=ctx.stream(k % n_streams))
+            ctx.synchronize()
+            with pytest.raises(BasisuError) as e:
+                ctx.status_word_check(int(status.item()))
+            assert e.value.first_bad_block == 2 * n + n // 3, (target, n_streams, bpr)
+            del ins, outs
+    ctx.close()
+
+
 # ---- bu_uastc_transcode_device_sync --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("target", ["bc7", "astc", "etc1", "etc2", "rgba"])
 def test_device_sync_tile_tickets_known_answers_and_lowest_error(golden, target):
