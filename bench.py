@@ -1141,13 +1141,14 @@ def run_atlas4096(env):
                               "note": "same atlas every launch (32 MiB working set sits in the 256 MiB Infinity Cache) -- NOT the headline"}
         # launches in flight x launch policy (the headline's cell among its neighbours; same window method, same rotation, 256 timed launches)
         try:
-            mat = {}
             pol_arg = {"exclusive": False, "shared": True, "auto": "auto"}
-            for pol in ("exclusive", "shared", "auto"):
-                mat[pol] = {}
-                for nfl in (1, 2, 3, 4):
-                    srow(64, nfl, pol_arg[pol])
-                    mat[pol][str(nfl)] = round(srow(256, nfl, pol_arg[pol]) * 1e6, 3)
+            mat = {pol: {} for pol in pol_arg}
+            for nfl in (1, 2, 3, 4):  # column by column, the three policies interleaved and the better of two windows kept: a drifting clock hits a column's cells alike
+                for rep in range(2):
+                    for pol in ("exclusive", "shared", "auto"):
+                        srow(64, nfl, pol_arg[pol])
+                        v_ = round(srow(256, nfl, pol_arg[pol]) * 1e6, 3)
+                        mat[pol][str(nfl)] = v_ if rep == 0 else min(mat[pol][str(nfl)], v_)
             torch.cuda.synchronize()
             extra["launches_in_flight_matrix"] = {"us_per_atlas": mat, "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
                                                   "auto_matches_the_better_row": all(mat["auto"][c] <= 1.03 * min(mat["exclusive"][c], mat["shared"][c]) for c in ("1", "4")),
