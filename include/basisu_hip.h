@@ -199,7 +199,9 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
  * pipeline).  The call merges the slices into runs as above, groups small runs into launches of about 2^20 blocks (one launch per group, the run
  * table in its kernel arguments), cuts the largest runs of a batch that would make fewer launches than streams into equal pieces (a 512-slice
  * texture array in one allocation becomes n_streams launches: 0.76-0.78 of the HBM roofline against 0.70 as one launch), and issues launch j on
- * the context's own stream j % n_streams (1..8; bu_context_stream) under the shared launch policy, whatever the context's policy is.
+ * the context's own stream j % n_streams (1..8; bu_context_stream; FOUR is the depth to use -- the chip runs four queues' dispatches side by side,
+ * and with five to eight streams BC7 / ASTC fall from 5.5 to 7-10 us per 2^20-block slice: profiles/r06_more_than_four_in_flight.txt) under the
+ * shared launch policy, whatever the context's policy is.
  * It only ENQUEUES: bu_context_synchronize(ctx), or synchronising those streams, waits for the results, and nothing the caller enqueued on
  * other streams is waited for -- inputs and the status word must be ready before the call (bu_status_word_reset + a synchronise).  The streams
  * need a hardware queue each; the library sees to that itself and reports it (bu_context_stream, bu_context_query_in_flight).  A batch of 64
