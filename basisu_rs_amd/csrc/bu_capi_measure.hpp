@@ -377,6 +377,15 @@ bu_status bu_time_last_window_enqueue(bu_context* ctx, float* out_ms, int* out_l
     return BU_OK;
 }
 
+// on == 0: every persistent launch of this context walks fixed shares of the tiles (what rounds 1-5 shipped); on != 0 (default): long walks draw their
+// tiles by ticket.  Measurement only -- the bench shows both forms of the 2^25-block launch in one process; results never depend on it.
+bu_status bu_time_set_tile_tickets(bu_context* ctx, int on)
+{
+    if (!ctx) return BU_ERR_ARGUMENT;
+    ctx->tickets_off.store(on == 0, std::memory_order_relaxed);
+    return BU_OK;
+}
+
 bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on)
 {
     if (!ctx) return BU_ERR_ARGUMENT;

@@ -82,7 +82,7 @@ bu_status bu_context_create(int device, bu_context** out_ctx)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tables), sizeof(BuTablesAll)) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipMalloc(reinterpret_cast<void**>(&ctx->d_status), 64) != hipSuccess) { st = BU_ERR_HIP; break; }  // (eight words; [0] serves the host-pointer entry points)
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), 9 * BU_TICKET_WORDS * 4) != hipSuccess || hipMemset(ctx->d_tickets, 0, 9 * BU_TICKET_WORDS * 4) != hipSuccess) { st = BU_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), (9 + BU_FOREIGN_TICKET_SETS) * BU_TICKET_WORDS * 4) != hipSuccess || hipMemset(ctx->d_tickets, 0, (9 + BU_FOREIGN_TICKET_SETS) * BU_TICKET_WORDS * 4) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), 64, hipHostMallocDefault) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->hd_status), ctx->h_status, 0) != hipSuccess) { st = BU_ERR_HIP; break; }
         if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { st = BU_ERR_HIP; break; }

@@ -4,6 +4,7 @@
 #pragma once
 
 // ================================================================================================
+constexpr int BU_FOREIGN_TICKET_SETS = 32;
 struct bu_context {
     int device = -1;
     int cu_count = 256;
@@ -21,7 +22,11 @@ struct bu_context {
     void* h_idx = nullptr;  // page-locked index buffer of the streamed ETC1S front door: the host decoder writes it, the kernels read it over PCIe
     size_t h_idx_cap = 0;
     unsigned long long* d_status = nullptr;
-    unsigned* d_tickets = nullptr;  // tile-ticket pairs of the persistent launches (kernel, `ticket`): one pair per own stream [0..7] and one for `stream` [8]
+    unsigned* d_tickets = nullptr;  // tile-ticket sets of the persistent launches (kernel, `ticket`): own streams [0..7], `stream` [8], then the caller's streams in order of first use
+    hipStream_t foreign_streams[32] = {};  // (bu_ticket_for, under ticket_lock)
+    int n_foreign_streams = 0;
+    std::mutex ticket_lock;
+    std::atomic<bool> tickets_off{false};  // bu_time_set_tile_tickets (measurement: the fixed walk beside the ticketed one in one process)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_start[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per-stream events of bu_time_uastc_launches_streams_window
     hipEvent_t ev_end[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

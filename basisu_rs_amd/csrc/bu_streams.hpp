@@ -215,21 +215,35 @@ int bu_auto_policy(bu_context* ctx, hipStream_t s)
     return busy == 0 ? BU_POLICY_EXCLUSIVE : (busy <= 2 ? BU_POLICY_SHARED_FEW : BU_POLICY_SHARED);
 }
 
-// The tile-ticket set a persistent launch on `s` draws its tiles from (kernel, `ticket`), or nullptr for the fixed walk.  A pair must never
-// serve two launches at once, and the kernel zeroes it when its last workgroup leaves: launches of ONE stream run one after the other, so every
-// stream the context owns has a pair of its own; a stream of the caller's has none (the library cannot know what else the caller runs on it
-// side by side through a graph), nor has a stream that is being captured (a graph may be replayed anywhere).
+// The tile-ticket set a persistent launch on `s` draws its tiles from (kernel, `ticket`), or nullptr for the fixed walk.  A set must never serve two
+// launches at once, and the kernel zeroes it when its last workgroup leaves.  Launches of ONE stream run one after the other -- that is what a stream is
+// -- so a set per stream is safe for any stream: the context's own streams and its internal one have fixed sets (0..8), a stream of the caller's gets
+// the next free one of BU_FOREIGN_TICKET_SETS on its first large launch (a small table under a lock: only launches of 16 or more tiles per workgroup
+// -- 90 us and up -- ever ask).  Excluded: hipStreamPerThread (one handle, a different stream on every host thread), a stream that is being captured
+// (a graph may be replayed on any stream, several times at once), and the caller's 33rd stream (fixed walk).
 unsigned* bu_ticket_for(bu_context* ctx, hipStream_t s)
 {
     static const bool off = [] { const char* e = getenv("BU_TILE_TICKETS"); return e && e[0] == '0'; }();  // diagnostic knob: 0 = fixed walk everywhere
-    if (off || !s || !ctx->d_tickets) return nullptr;
+    if (off || ctx->tickets_off.load(std::memory_order_relaxed) || !ctx->d_tickets || s == hipStreamPerThread) return nullptr;
     int slot = s == ctx->stream ? 8 : -1;
     for (int i = 0; i < 8 && slot < 0; i++)
-        if (ctx->extra_streams[i].load(std::memory_order_acquire) == s) slot = i;
+        if (s && ctx->extra_streams[i].load(std::memory_order_acquire) == s) slot = i;
+    if (slot < 0) {
+        std::lock_guard<std::mutex> g(ctx->ticket_lock);
+        for (int i = 0; i < ctx->n_foreign_streams && slot < 0; i++)
+            if (ctx->foreign_streams[i] == s) slot = 9 + i;
+        if (slot < 0 && ctx->n_foreign_streams < BU_FOREIGN_TICKET_SETS) {
+            ctx->foreign_streams[ctx->n_foreign_streams] = s;  // (the NULL stream is a stream like any other here: its launches run one after the other)
+            slot = 9 + ctx->n_foreign_streams++;
+        }
+    }
     if (slot < 0) return nullptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
-    return cap == hipStreamCaptureStatusNone ? ctx->d_tickets + BU_TICKET_WORDS * slot : nullptr;
+    if (s) {  // (the legacy NULL stream cannot be captured)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) return nullptr;
+    }
+    return ctx->d_tickets + BU_TICKET_WORDS * slot;
 }
 
 }  // namespace

@@ -1342,6 +1342,17 @@ def run_atlas4096(env):
                                                              ctypes.byref(ev), ctypes.byref(host), ctypes.byref(late)), "bu_time_uastc_launches_window")
                 return ev.value / 1e3 / launches
 
+            # the fixed walk first (every workgroup walks tiles b, b + grid, ...: what rounds 1-5 shipped), then -- the row itself -- the launch as the library
+            # issues it now: the workgroups draw their tiles by ticket, on the caller's stream like on any other
+            lib.bu_time_set_tile_tickets(ctx.handle, 0)
+            big_window(0, 2)
+            t_big = time.perf_counter()
+            while args.prewarm_ms > 0 and (time.perf_counter() - t_big) * 1e3 < 4 * args.prewarm_ms:
+                big_window(0, 8)
+            fixed_s = big_window(8, 40)
+            lib.bu_time_set_tile_tickets(ctx.handle, 1)
+            for t_ in big_out:
+                t_.zero_()
             big_window(0, 2)
             torch.cuda.synchronize()
             big_ok = bool(torch.equal(big_out[0], g_bc7[big_idx0]))
@@ -1352,10 +1363,12 @@ def run_atlas4096(env):
             extra["array512_one_launch"] = {"blocks": nbig, "us_per_launch": round(big_s * 1e6, 2), "mblocks_s": round(nbig / big_s / 1e6, 1),
                                             "gb_s": round(BYTES_PER_BLOCK * nbig / big_s / 1e9, 1), "frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / big_s / 1e9 / HBM_PEAK_GBS, 4),
                                             "verified": big_ok,
-                                            "note": "BASELINE config 5 on ONE GPU: 512 slices x 65 536 blocks contiguous, one launch per step, cold (two 1 GiB "
-                                                    "pairs rotated), 8 lead + 40 timed launches between events; `--config array512` is the sharded form"}
-            # ONE launch over the array on one of the context's OWN streams: the exclusive shape with tile tickets (workgroups draw their tiles from
-            # counters instead of walking fixed shares; `array512_one_launch` above runs on the caller's stream and keeps the fixed walk)
+                                            "fixed_walk_us_per_launch": round(fixed_s * 1e6, 2), "fixed_walk_frac_of_hbm_peak": round(BYTES_PER_BLOCK * nbig / fixed_s / 1e9 / HBM_PEAK_GBS, 4),
+                                            "note": "BASELINE config 5 on ONE GPU: 512 slices x 65 536 blocks contiguous, ONE launch per step on the caller's stream (bu_uastc_transcode_device), "
+                                                    "cold (two 1 GiB pairs rotated), 8 lead + 40 timed launches between events.  The persistent workgroups draw their tiles by ticket "
+                                                    "(round 6; fixed_walk_*: the same launch with every workgroup walking its fixed share, bu_time_set_tile_tickets(ctx, 0)); "
+                                                    "`--config array512` is the sharded form"}
+            # the same launch on one of the context's OWN streams (streams window helper), and the BLOCKING product call over the array on the host clock
             try:
                 ctx.set_launch_policy(False)  # (exclusive, as the row above; BU_LAUNCH_AUTO picks the same for a launch that is alone)
 

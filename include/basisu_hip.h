@@ -220,9 +220,10 @@ bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, 
  * BU_STATUS_WORD_CLEAR or the LOWEST (block_index_base + block) << 8 | status over the range -- bu_status_word_decode turns it into the
  * reference's error; ranks of a multi-process job reduce it with MIN before anyone raises (basisu_rs_amd/sharded.py).  The call takes the
  * context's lock (one blocking call per context at a time).  bu_array_transcode_sharded runs every device's range through the same code.
- * (Tile tickets are drawn from counters the CONTEXT owns, one set per stream of its own: bu_uastc_transcode_device on one of those streams --
- * bu_context_stream -- gets them too; a launch on a stream of the caller's keeps the fixed walk, since the library cannot know what else runs
- * beside it there.) */
+ * (Tile tickets are drawn from counters the CONTEXT owns, one set per STREAM -- launches of one stream run one after the other, so a set never
+ * serves two launches at once: the context's own streams have fixed sets, a stream of the caller's gets the next free one of 32 on its first large
+ * launch, so bu_uastc_transcode_device draws tickets on any stream.  Excluded: hipStreamPerThread, a stream that is being captured into a graph, and
+ * a context's 33rd caller stream -- those keep the fixed walk.) */
 bu_status bu_uastc_transcode_device_sync(bu_context* ctx, bu_target target, const void* d_in, size_t n_blocks, void* d_out,
                                          size_t blocks_per_row, uint64_t block_index_base, uint64_t* out_status_word);
 
@@ -447,6 +448,9 @@ bu_status bu_time_uastc_launches_streams(bu_context* ctx, bu_target target, cons
  * free) instead of from the calling thread alone -- how a caller with a thread per stream drives the context, and what keeps the host
  * from setting the pace when one enqueue costs more host time than a period (under rocprofv3 --kernel-trace: 6-8 us). */
 bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on);
+/* on == 0: the context's persistent launches walk fixed shares of the tiles (rounds 1-5); on != 0 (default): long walks draw their tiles by ticket
+ * (bu_uastc_transcode_device_sync).  Measurement only: bench.py shows both forms of the 2^25-block launch in one process; results never depend on it. */
+bu_status bu_time_set_tile_tickets(bu_context* ctx, int on);
 /* the per-stream events of the context's LAST streams window, ms from the head of that call: out_start_ms[i] / out_end_ms[i] (8 floats each)
  * = stream i's start event (behind its last lead launch) / end event (behind its last timed launch), -1 for a stream without timed launches.
  * Streams running in step start and end within a few periods of each other; a stream that shares a hardware queue falls behind, and the

@@ -253,6 +253,60 @@ def test_device_sync_against_the_oracle_on_random_blocks(oracle):
     ctx.close()
 
 
+def test_tile_tickets_on_the_callers_streams(golden):
+    """a ticket set per STREAM: launches of 2^24 blocks on torch's NULL stream, on two side streams at the same time (each its own set), back to back on one, and on 40
+    different streams in turn (the context has 32 sets for streams of the caller's: the rest walk fixed shares) -- same bytes as the known answers every time; a launch
+    captured into a graph (no tickets: a graph may be replayed anywhere) replays correctly beside a ticketed launch on another stream"""
+    import torch
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    n, bpr = 1 << 24, 1024
+    gu, gb = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden["bc7"]).cuda()
+    idx = torch.randint(0, 608, (n,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(31))
+    d_in = gu[idx].contiguous()
+    want = gb[idx]
+    outs = [torch.zeros((n, 16), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    ctx.transcode_device(_lib.BC7, d_in, n, outs[0], blocks_per_row=bpr)  # torch's current stream: the NULL stream
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], want)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    ctx.transcode_device(_lib.BC7, d_in, n, outs[0], blocks_per_row=bpr, stream=s1)
+    ctx.transcode_device(_lib.BC7, d_in, n, outs[1], blocks_per_row=bpr, stream=s2)
+    ctx.transcode_device(_lib.BC7, d_in, n, outs[2], blocks_per_row=bpr, stream=s1)  # back to back behind the first
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
+    many = [torch.cuda.Stream() for _ in range(40)]
+    for k, st in enumerate(many):
+        o = outs[k % 3]
+        o.zero_()
+        torch.cuda.synchronize()
+        ctx.transcode_device(_lib.BC7, d_in, n, o, blocks_per_row=bpr, stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(o, want), k
+    # a captured launch (fixed walk) replayed on s2 while a ticketed launch runs on s1
+    g = torch.cuda.CUDAGraph()
+    outs[1].zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s2):
+        ctx.transcode_device(_lib.BC7, d_in, n, outs[1], blocks_per_row=bpr, stream=s2)
+    outs[0].zero_()
+    outs[1].zero_()
+    torch.cuda.synchronize()
+    ctx.transcode_device(_lib.BC7, d_in, n, outs[0], blocks_per_row=bpr, stream=s1)
+    with torch.cuda.stream(s2):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+    ctx.close()
+
+
 # ---- bu_array_transcode_sharded with ranges that draw tickets ---------------------------------------------------------------------------
 def _ptr_array(vals):
     return (ctypes.c_void_p * len(vals))(*vals)
