@@ -28,7 +28,7 @@ SYMBOLS = [
     "bu_comm_unique_id", "bu_comm_create", "bu_comm_destroy", "bu_comm_query", "bu_allgather_inplace",
     "bu_ipc_export", "bu_ipc_open", "bu_ipc_close", "bu_allgather_peer", "bu_array_transcode_sharded",
     "bu_device_alloc", "bu_device_free", "bu_memcpy",
-    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_window", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_uastc_launches_streams_window", "bu_time_set_enqueue_threads", "bu_time_set_tile_tickets", "bu_time_last_window_streams", "bu_time_last_window_enqueue", "bu_time_mark_streams", "bu_time_marks_elapsed", "bu_time_etc1s_launches_streams_window", "bu_time_copy_launches", "bu_time_block_api",
+    "bu_copy_ceiling_device", "bu_time_uastc_launches", "bu_time_uastc_launches_window", "bu_time_uastc_launches_each", "bu_time_uastc_launches_streams", "bu_time_uastc_launches_streams_window", "bu_time_set_enqueue_threads", "bu_time_set_tile_tickets", "bu_time_auto_policy_counts", "bu_time_last_window_streams", "bu_time_last_window_enqueue", "bu_time_mark_streams", "bu_time_marks_elapsed", "bu_time_etc1s_launches_streams_window", "bu_time_copy_launches", "bu_time_block_api",
 ]
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
@@ -202,6 +202,8 @@ def load():
     lib.bu_time_set_enqueue_threads.restype = c.c_int
     lib.bu_time_set_tile_tickets.argtypes = [vp, c.c_int]
     lib.bu_time_set_tile_tickets.restype = c.c_int
+    lib.bu_time_auto_policy_counts.argtypes = [vp, c.POINTER(c.c_ulonglong)]
+    lib.bu_time_auto_policy_counts.restype = c.c_int
     lib.bu_time_last_window_streams.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_float), c.POINTER(c.c_int)]
     lib.bu_time_last_window_streams.restype = c.c_int
     lib.bu_time_last_window_enqueue.argtypes = [vp, c.POINTER(c.c_float), c.POINTER(c.c_int)]

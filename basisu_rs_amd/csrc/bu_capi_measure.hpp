@@ -377,6 +377,15 @@ bu_status bu_time_last_window_enqueue(bu_context* ctx, float* out_ms, int* out_l
     return BU_OK;
 }
 
+// what BU_LAUNCH_AUTO has chosen for this context's large launches since it was created: out[0] exclusive (no other own stream busy), out[1] the shared
+// kernels on one-tile workgroups (one or two busy), out[2] the shared shape (three or more)
+bu_status bu_time_auto_policy_counts(bu_context* ctx, unsigned long long out[3])
+{
+    if (!ctx || !out) return BU_ERR_ARGUMENT;
+    for (int i = 0; i < 3; i++) out[i] = ctx->auto_picks[i].load(std::memory_order_relaxed);
+    return BU_OK;
+}
+
 // on == 0: every persistent launch of this context walks fixed shares of the tiles (what rounds 1-5 shipped); on != 0 (default): long walks draw their
 // tiles by ticket.  Measurement only -- the bench shows both forms of the 2^25-block launch in one process; results never depend on it.
 bu_status bu_time_set_tile_tickets(bu_context* ctx, int on)

@@ -26,6 +26,7 @@ struct bu_context {
     hipStream_t foreign_streams[32] = {};  // (bu_ticket_for, under ticket_lock)
     int n_foreign_streams = 0;
     std::mutex ticket_lock;
+    std::atomic<unsigned long long> auto_picks[3] = {{0}, {0}, {0}};  // what BU_LAUNCH_AUTO chose so far: exclusive, one-tile shared, shared (bu_time_auto_policy_counts)
     std::atomic<bool> tickets_off{false};  // bu_time_set_tile_tickets (measurement: the fixed walk beside the ticketed one in one process)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_start[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // per-stream events of bu_time_uastc_launches_streams_window

@@ -212,6 +212,7 @@ int bu_auto_policy(bu_context* ctx, hipStream_t s)
         }
     }
     ctx->last_big_enqueue_ns[me].store(now, std::memory_order_relaxed);
+    ctx->auto_picks[busy == 0 ? 0 : (busy <= 2 ? 1 : 2)].fetch_add(1, std::memory_order_relaxed);
     return busy == 0 ? BU_POLICY_EXCLUSIVE : (busy <= 2 ? BU_POLICY_SHARED_FEW : BU_POLICY_SHARED);
 }
 

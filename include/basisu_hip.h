@@ -451,6 +451,8 @@ bu_status bu_time_set_enqueue_threads(bu_context* ctx, int on);
 /* on == 0: the context's persistent launches walk fixed shares of the tiles (rounds 1-5); on != 0 (default): long walks draw their tiles by ticket
  * (bu_uastc_transcode_device_sync).  Measurement only: bench.py shows both forms of the 2^25-block launch in one process; results never depend on it. */
 bu_status bu_time_set_tile_tickets(bu_context* ctx, int on);
+/* what BU_LAUNCH_AUTO has chosen for this context's large launches so far: out[0] exclusive, out[1] the shared kernels on one-tile workgroups, out[2] shared */
+bu_status bu_time_auto_policy_counts(bu_context* ctx, unsigned long long out[3]);
 /* the per-stream events of the context's LAST streams window, ms from the head of that call: out_start_ms[i] / out_end_ms[i] (8 floats each)
  * = stream i's start event (behind its last lead launch) / end event (behind its last timed launch), -1 for a stream without timed launches.
  * Streams running in step start and end within a few periods of each other; a stream that shares a hardware queue falls behind, and the

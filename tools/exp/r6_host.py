@@ -220,3 +220,23 @@ if "one" in what:
     torch.cuda.synchronize()
     print("verified:", bool(torch.equal(outs[0], g_b[idx0])))
     ctx.close()
+
+if "picks" in what:
+    # what BU_LAUNCH_AUTO picks with 1..4 launches in flight, window shapes of bench.py's matrix (lead 64, 256 timed, tail = in flight)
+    ctx = Context(0)
+    lib = ctx._lib
+    nbuf = 64
+    idxs, ins, outs = atlases(nbuf)
+    PA = ctypes.c_void_p * nbuf
+    ip, op = PA(*[t.data_ptr() for t in ins]), PA(*[t.data_ptr() for t in outs])
+    torch.cuda.synchronize()
+    ctx.set_launch_policy("auto")
+    for nfl in (1, 2, 3, 4, 4, 4):
+        c0 = (ctypes.c_ulonglong * 3)(); lib.bu_time_auto_policy_counts(ctx.handle, c0)
+        ev, host = ctypes.c_float(0), ctypes.c_float(0)
+        assert lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, ip, op, nbuf, 0, NB, 1024, 64, 256, nfl if nfl > 1 else 0, nfl, None, ctypes.byref(ev), ctypes.byref(host), None, None) == 0
+        c1 = (ctypes.c_ulonglong * 3)(); lib.bu_time_auto_policy_counts(ctx.handle, c1)
+        ms_, k_ = ctypes.c_float(0), ctypes.c_int(0)
+        lib.bu_time_last_window_enqueue(ctx.handle, ctypes.byref(ms_), ctypes.byref(k_))
+        print("S%d: %.2f us per atlas; picks exclusive / one-tile / shared = %s; host enqueue %.2f us per launch" % (nfl, max(ev.value, host.value) * 1e3 / 256, [int(c1[i] - c0[i]) for i in range(3)], ms_.value * 1e3 / max(k_.value, 1)))
+    ctx.close()
