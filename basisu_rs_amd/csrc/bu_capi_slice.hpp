@@ -258,10 +258,13 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
             constexpr bool PERSIST = T == BU_TGT_BC7 || T == BU_TGT_ASTC || T == BU_TGT_RGBA;
             const size_t cap = (size_t)ctx->cu_count * (PERSIST ? (T == BU_TGT_RGBA ? (half ? 1 : 2) : (half ? 2 : 4)) : 7);  // (beyond seven workgroups per CU they walk the tiles, as bu_launch_uastc)
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
+            // tile tickets for the long walks of a persistent grid that has the chip to itself, as bu_go_big (a batch of 64 slices of 2^20 blocks in
+            // separate allocations: 64 tiles per workgroup)
+            unsigned* const ticket = (PERSIST && !half && n_tiles >= BU_TICKET_MIN_WALK * (size_t)grid) ? bu_ticket_for(ctx, s) : nullptr;
             if (one_per_cu)
-                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
+                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, (unsigned*)nullptr);
             else
-                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables);
+                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, ticket);
         };
         switch (target) {
         case BU_TARGET_ASTC: go(std::integral_constant<int, BU_TGT_ASTC>()); break;

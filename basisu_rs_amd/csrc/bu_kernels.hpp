@@ -566,10 +566,11 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 // whatever run it belongs to -- are loaded while the current tile is transcoded, as in the one-slice kernel.
 template <int TARGET, int WGS, int BPT, bool PREFETCH = false>
 __global__ __launch_bounds__(WGS, 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
-                                                             const BuTablesAll* __restrict__ tables)
+                                                             const BuTablesAll* __restrict__ tables, unsigned* __restrict__ ticket)
 {
     static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table);
+    static_assert(sizeof(BuRunTable) + 40 <= 4096, "the run table and the other arguments share the 4 KiB of kernel arguments");
+    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table, ticket);
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into

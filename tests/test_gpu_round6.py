@@ -307,6 +307,52 @@ def test_tile_tickets_on_the_callers_streams(golden):
     ctx.close()
 
 
+@pytest.mark.parametrize("target", ["bc7", "rgba"])
+def test_batch_device_long_walk_draws_tickets(golden, target):
+    """bu_uastc_transcode_batch_device over 20 (RGBA32: 10) slices of about 2^20 blocks in separate allocations, ragged: ONE persistent launch whose workgroups walk
+    the tiles of all runs -- 16 and more tiles per workgroup, so they draw them by ticket; known answers, twice back to back on one stream, and the lowest
+    failing block of the batch"""
+    import torch
+
+    from basisu_rs_amd import BasisuError
+
+    from basisu_rs_amd import Context
+
+    ctx = Context(0)
+    lib = ctx._lib
+    t, bb = TB[target]
+    bpr = 1024
+    n_s = 10 if target == "rgba" else 20
+    sizes = [bpr * (1024 + 3 * k) for k in range(n_s)]
+    gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden[target]).cuda()
+    idxs = [torch.randint(0, 608, (n,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(77 + k)) for k, n in enumerate(sizes)]
+    ins = [gu[i].contiguous() for i in idxs]
+    outs = [torch.zeros((n // bpr * 4, bpr * 16) if target == "rgba" else (n, bb), dtype=torch.uint8, device="cuda") for n in sizes]
+    status = torch.empty(1, dtype=torch.int64, device="cuda")
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+    a = (n_s, VP(*[x.data_ptr() for x in ins]), SZ(*sizes), VP(*[x.data_ptr() for x in outs]))
+    s = torch.cuda.Stream()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    for rep in range(2):
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, a[0], a[1], a[2], a[3], bpr, None, ctypes.c_void_p(status.data_ptr()), sp) == 0
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()))
+    for k, n in enumerate(sizes):
+        got = outs[k].view(n // bpr, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64) if target == "rgba" else outs[k]
+        assert torch.equal(got, gt[idxs[k]]), (target, k)
+    ins[7][sizes[7] - 1, 0] = 69
+    ins[3][5, 0] = 69
+    torch.cuda.synchronize()
+    assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, a[0], a[1], a[2], a[3], bpr, None, ctypes.c_void_p(status.data_ptr()), sp) == 0
+    torch.cuda.synchronize()
+    with pytest.raises(BasisuError) as e:
+        ctx.status_word_check(int(status.item()))
+    assert e.value.first_bad_block == sum(sizes[:3]) + 5
+    ctx.close()
+
+
 # ---- bu_array_transcode_sharded with ranges that draw tickets ---------------------------------------------------------------------------
 def _ptr_array(vals):
     return (ctypes.c_void_p * len(vals))(*vals)

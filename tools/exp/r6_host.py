@@ -240,3 +240,32 @@ if "picks" in what:
         lib.bu_time_last_window_enqueue(ctx.handle, ctypes.byref(ms_), ctypes.byref(k_))
         print("S%d: %.2f us per atlas; picks exclusive / one-tile / shared = %s; host enqueue %.2f us per launch" % (nfl, max(ev.value, host.value) * 1e3 / 256, [int(c1[i] - c0[i]) for i in range(3)], ms_.value * 1e3 / max(k_.value, 1)))
     ctx.close()
+
+if "multi" in what:
+    # ONE call of bu_uastc_transcode_batch_device over N slices of 2^20 blocks in separate allocations (a persistent grid walks all runs' tiles), tickets off / on
+    ctx = Context(0)
+    lib = ctx._lib
+    nbuf = 64
+    idxs, ins, outs = atlases(nbuf)
+    s = torch.cuda.Stream()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    ctx.set_launch_policy(False)
+    for n in (8, 16, 32, 64):
+        VP, SZ = ctypes.c_void_p * n, ctypes.c_size_t * n
+        a_in, a_n, a_out = VP(*[ins[k].data_ptr() for k in range(n)]), SZ(*([NB] * n)), VP(*[outs[k].data_ptr() for k in range(n)])
+        res = []
+        for tk in (0, 1, 0, 1):
+            lib.bu_time_set_tile_tickets(ctx.handle, tk)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, n, a_in, a_n, a_out, 1024, None, None, sp) == 0
+            reps = max(4, 256 // n)
+            e0.record(s)
+            for _ in range(reps):
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, n, a_in, a_n, a_out, 1024, None, None, sp) == 0
+            e1.record(s)
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) * 1e3 / reps / n)
+        ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(n))
+        print("%2d slices per call: fixed walk %.2f %.2f   tickets %.2f %.2f us per slice   verified %s" % (n, res[0], res[2], res[1], res[3], ok))
+    ctx.close()
