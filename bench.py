@@ -1159,7 +1159,7 @@ def run_atlas4096(env):
             torch.cuda.synchronize()
             extra["launches_in_flight_matrix"] = {"us_per_atlas": mat, "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
                                                   "auto_picks_exclusive_onetile_shared": auto_picks,
-                                                  "auto_matches_the_better_row": all(mat["auto"][c] <= 1.05 * min(mat["exclusive"][c], mat["shared"][c]) for c in ("1", "2", "3", "4"))  # (cells repeat within 3 %),
+                                                  "auto_matches_the_better_row": all(mat["auto"][c] <= 1.05 * min(mat["exclusive"][c], mat["shared"][c]) for c in ("1", "2", "3", "4")),  # (cells repeat within 3 %)
                                                   "note": "UASTC->BC7, 2^20 blocks per launch, step i on context stream i %% n; rows = launch policy (auto = BU_LAUNCH_AUTO, the default: chosen "
                                                           "per call -- exclusive for a launch that is alone, shared once another of the context's streams has work in flight), columns = launches in flight; "
                                                           "every one of the %d rotated outputs compared with the known answers afterwards" % nbuf}
