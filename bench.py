@@ -1879,6 +1879,17 @@ def run_atlas4096(env):
             extra["valu_issue"] = {"wave_instructions_per_launch": int(tr[2]), "achieved_g_per_s": round(rate, 1), "peak_g_per_s": round(peak, 1),
                                    "frac": round(rate / peak, 3), "source": tr[1] + " (SQ_INSTS_VALU of the committed counter pass -- read from that file, NOT measured in this run)"}
     extra["one_launch_at_a_time"] = one_row
+    a1_ = extra.get("array512_one_launch")
+    if a1_ and a1_.get("verified"):
+        # the headline's workload in ONE launch: 32 atlases of 4096^2 contiguous in memory ARE the 2^25-block array of config 5 -- a figure that needs no pipeline,
+        # no streams and no period: one kernel's duration (this run: HIP events around 40 launches; rocprofv3's own average from the committed passes over the same launch)
+        line["roofline"]["one_launch_of_32_contiguous_atlases"] = {
+            "us_per_atlas": round(a1_["us_per_launch"] / 32, 3), "frac": a1_["frac_of_hbm_peak"],
+            "us_per_atlas_by_rocprofv3_kernel_avg": round(a1_["kernel_avg_ns"] / 32e3, 3) if a1_.get("kernel_avg_ns") else None,
+            "frac_by_rocprofv3_kernel_avg": a1_.get("frac_by_rocprofv3_kernel_avg"), "profile": a1_.get("profile"),
+            "fixed_walk_us_per_atlas": round(a1_["fixed_walk_us_per_launch"] / 32, 3) if a1_.get("fixed_walk_us_per_launch") else None,
+            "note": "extra.array512_one_launch read per atlas: bu_uastc_transcode_device over 2^25 contiguous blocks on the caller's stream, one launch at a time; the persistent "
+                    "workgroups draw their tiles by ticket (round 6)"}
     line["extra"] = extra
     allgather = None
     if use_dist:
