@@ -420,10 +420,27 @@ def main():
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world > 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # BENCH_FORCE_DIST with one rank: this process is its own rendezvous.  A port somebody handed us (or the default) may have been taken in the meantime
+            # (a test picks a free one, closes it, and starts us a second later): on "address already in use" take a fresh one and try again
+            import socket
+            for attempt in range(6):
+                if attempt or "MASTER_PORT" not in os.environ:
+                    s_ = socket.socket()
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+                    s_.close()
+                try:
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                    break
+                except Exception as e:  # noqa: BLE001 -- DistNetworkError is not importable on every torch
+                    if attempt == 5 or "EADDRINUSE" not in repr(e) and "address already in use" not in repr(e):
+                        raise
         # the communicator's first collectives (connection setup, tens of ms) happen here, far from the timed region
         dist.barrier()
         dist.barrier()
