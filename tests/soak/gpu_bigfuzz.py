@@ -8,7 +8,7 @@ import numpy as np
 from basisu_rs_amd import Context, _lib, synth, BasisuError
 from oracle.pyoracle import Oracle
 ctx = Context(0); o = Oracle()
-ctx.set_launch_policy(os.environ.get("FUZZ_POLICY") == "shared")
+ctx.set_launch_policy({"shared": True, "auto": "auto"}.get(os.environ.get("FUZZ_POLICY"), False))  # FUZZ_POLICY=shared | auto | (exclusive)
 FMT = {"astc": _lib.ASTC, "bc7": _lib.BC7, "etc1": _lib.ETC1, "etc2": _lib.ETC2}
 t0 = time.time(); total = 0
 SEED0 = int(os.environ.get("FUZZ_SEED0", 0))

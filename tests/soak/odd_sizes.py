@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from basisu_rs_amd import Context, _lib, synth
 from oracle.pyoracle import Oracle
 ctx = Context(0); o = Oracle()
-ctx.set_launch_policy(os.environ.get("FUZZ_POLICY") == "shared")  # FUZZ_POLICY=shared: the half-CU shapes (fixed 1024- / 2048-block tiles, ragged tails)
+ctx.set_launch_policy({"shared": True, "auto": "auto"}.get(os.environ.get("FUZZ_POLICY"), False))  # FUZZ_POLICY=shared | auto | (exclusive)  # FUZZ_POLICY=shared: the half-CU shapes (fixed 1024- / 2048-block tiles, ragged tails)
 g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
 for n in (262145, 300001, 524289, 786433, 851968, 1000000, 1234567, 1572865, 3000001, 5000003):
     idx = synth.gold_indices(n, seed=n)
