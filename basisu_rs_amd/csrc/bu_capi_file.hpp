@@ -713,14 +713,13 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                     if (piece_bytes < ((size_t)4 << 20)) piece_bytes = (size_t)4 << 20;
                     if (piece_bytes > run_piece_bytes) piece_bytes = run_piece_bytes;
                 }
-                // The same pieces with the output in DEVICE memory (pageable `out`), from a run of 2^22 blocks (64 MiB) on: piece i's upload and its
-                // launch share a stream, four streams carry the pieces round-robin under the shared launch policy, so that a piece's transcode lies
-                // under the next pieces' uploads and the launches of different pieces run side by side (the pipeline of the slice-level batch call,
-                // fed over PCIe); the streams are joined on the host in front of the status download.
-                const bool big_run = run_bytes / 16 >= ((size_t)1 << 22);
-                if (target != BU_READ_RGBA && (direct_out || big_run) && piece_bytes && run_bytes >= 2 * piece_bytes) {
+                // (Round 6 tried the same pieces for a PAGEABLE output too -- four streams, upload and launch of a piece on one stream, shared launch shapes -- from
+                // runs of 64 MiB on: 2.64 against 2.52 ms for a 64 MiB file, 5.17 against 4.97 for 128 MiB, profiles/r06_read_to_pieces_pageable_output.txt.  The call is
+                // two PCIe copies long and the kernels are 1 % of it; with a pageable output the run stays one upload, one launch -- which draws its tiles by
+                // ticket from 2^24 blocks on -- and one download.)
+                if (target != BU_READ_RGBA && direct_out && piece_bytes && run_bytes >= 2 * piece_bytes) {
                     pieced = true;
-                    const int n_ps = direct_out ? 2 : 4;  // streams that carry pieces: the context's internal one and n_ps - 1 of its own
+                    constexpr int n_ps = 2;  // streams that carry pieces: the context's internal one and one of its own
                     {
                         const bu_status sst = bu_ctx_streams(ctx, n_ps - 1);
                         if (sst) return sst;
@@ -740,7 +739,7 @@ static bu_status bu_read_to_impl(bu_context* ctx, bu_read_target target, const u
                         BU_HIP(ctx, hipMemcpyAsync(d_in + in_off[k] + done, file + s.file_ofs + done, nbytes, hipMemcpyHostToDevice, ps));
                         crc_enqueue(d_in + in_off[k] + done, (size_t)s.file_ofs + done, nbytes, ps);
                         st = bu_launch_uastc(ctx, pbt, d_in + in_off[k] + done, nbytes / 16, d_out + im.offset + (done / 16) * obytes, 1, done / 16, d_status + k, ps,
-                                             direct_out ? BU_ZEROCOPY_GRID : 0, direct_out ? BU_POLICY_EXCLUSIVE : BU_POLICY_SHARED);
+                                             BU_ZEROCOPY_GRID);
                         if (st) return st;
                     }
                 } else {
