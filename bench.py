@@ -147,6 +147,24 @@ def pmc_child():
     torch.cuda.synchronize()
     rounds = max(1, int(os.environ.get("BENCH_PMC_ROUNDS", "1")))
     streams = max(1, int(os.environ.get("BENCH_PMC_STREAMS", "1")))
+    if os.environ.get("BENCH_PMC_ARRAY") == "1":
+        # 32 atlases contiguous in memory = the 2^25-block array of config 5, ONE launch each, one at a time on this process's NULL stream (exclusive shape, tile
+        # tickets): rocprofv3's per-kernel duration of these launches is a reading of the headline's workload that needs no pipeline and no period
+        del outs
+        big = [torch.cat(ins[:16] + ins[:16]).contiguous(), torch.cat(ins[8:24] + ins[8:24]).contiguous()]
+        del ins
+        bout = [torch.empty((32 * N_BLOCKS, 16), dtype=torch.uint8, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        ctx.set_launch_policy("auto")
+        lib = _lib.load()
+        P2 = ctypes.c_void_p * 2
+        ms = ctypes.c_float(0)
+        st = lib.bu_time_uastc_launches(ctx.handle, _lib.BC7, P2(*[t.data_ptr() for t in big]), P2(*[t.data_ptr() for t in bout]), 2, 0, 32 * N_BLOCKS, NBX,
+                                        int(os.environ.get("BENCH_PMC_ARRAY_LAUNCHES", "480")), None, None, ctypes.byref(ms))
+        assert st == 0
+        torch.cuda.synchronize()
+        ctx.close()
+        return
     if rounds == 1:
         for k in range(24):
             ctx.transcode_device(_lib.BC7, ins[k], N_BLOCKS, outs[k], blocks_per_row=NBX)
@@ -255,6 +273,25 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
                                    "(end_to_end: end-to-end; steady_period: end-to-end over the stretches of >= 64 completions without a host-side pause, i.e. no gap above 3 x the median); avg_kernels_running = sum of spans / wall time" % in_flight}
         except Exception as e:  # the trace pass is a cross-check: without it the counter passes still run
             trace = {"error": "%s: %s" % (type(e).__name__, e)}
+        # ---- kernel trace of ONE launch over 32 contiguous atlases (2^25 blocks), one at a time: the per-kernel duration rocprofv3 itself reports ----
+        try:
+            out = os.path.join(work, "array")
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            rc, err = _run_child(cmd, dict(env, BENCH_PMC_ARRAY="1"), timeout_s)
+            durs = []
+            for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if is_bc7(row["Kernel_Name"]):
+                        durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+            durs = [d_ for _, d_ in sorted(durs) if d_ > 100000]  # (the 2^25-block launches; anything else of this kernel in the child is a 2^20-block launch)
+            durs = durs[len(durs) // 2:]  # (these launches take ~100 ms to settle the clocks)
+            if rc == 0 and len(durs) >= 16 and isinstance(trace, dict):
+                trace["array32"] = {"launches": len(durs), "kernel_avg_ns": round(sum(durs) / len(durs), 1), "kernel_median_ns": float(np.median(durs)), "kernel_min_ns": min(durs),
+                                    "source": "child rocprofv3 --kernel-trace pass over `bench.py --pmc-child` with BENCH_PMC_ARRAY=1: 480 launches of bu_uastc_transcode_device over "
+                                              "2^25 contiguous blocks (32 atlases of 4096^2), one at a time on the NULL stream, two 1 GiB pairs rotated, the last half counted"}
+        except Exception as e:
+            if isinstance(trace, dict):
+                trace["array32"] = {"error": "%s: %s" % (type(e).__name__, e)}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
@@ -1897,6 +1934,7 @@ def run_atlas4096(env):
                                    "frac": round(rate / peak, 3), "source": tr[1] + " (SQ_INSTS_VALU of the committed counter pass -- read from that file, NOT measured in this run)"}
     extra["one_launch_at_a_time"] = one_row
     a1_ = extra.get("array512_one_launch")
+    a32_ = (env.live_traffic[2] or {}).get("array32") if len(env.live_traffic) > 2 and isinstance(env.live_traffic[2], dict) else None
     if a1_ and a1_.get("verified"):
         # the headline's workload in ONE launch: 32 atlases of 4096^2 contiguous in memory ARE the 2^25-block array of config 5 -- a figure that needs no pipeline,
         # no streams and no period: one kernel's duration (this run: HIP events around 40 launches; rocprofv3's own average from the committed passes over the same launch)
@@ -1905,6 +1943,9 @@ def run_atlas4096(env):
             "us_per_atlas_by_rocprofv3_kernel_avg": round(a1_["kernel_avg_ns"] / 32e3, 3) if a1_.get("kernel_avg_ns") else None,
             "frac_by_rocprofv3_kernel_avg": a1_.get("frac_by_rocprofv3_kernel_avg"), "profile": a1_.get("profile"),
             "fixed_walk_us_per_atlas": round(a1_["fixed_walk_us_per_launch"] / 32, 3) if a1_.get("fixed_walk_us_per_launch") else None,
+            "rocprofv3_this_run": a32_,
+            "us_per_atlas_by_rocprofv3_kernel_avg_this_run": round(a32_["kernel_avg_ns"] / 32e3, 3) if a32_ and a32_.get("kernel_avg_ns") else None,
+            "frac_by_rocprofv3_kernel_avg_this_run": round(BYTES_PER_BLOCK * 32 * N_BLOCKS / a32_["kernel_avg_ns"] / HBM_PEAK_GBS, 4) if a32_ and a32_.get("kernel_avg_ns") else None,
             "note": "extra.array512_one_launch read per atlas: bu_uastc_transcode_device over 2^25 contiguous blocks on the caller's stream, one launch at a time; the persistent "
                     "workgroups draw their tiles by ticket (round 6)"}
     line["extra"] = extra
