@@ -223,11 +223,27 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
     for (size_t r0 = 0; r0 < n_runs;) {
         BuRunTable tb;
         size_t k = 0, n_tiles = 0;
+        bool all_whole = true;  // every run of this launch is tiled as whole rectangles: the kernel variant without per-lane validity tests
         for (; r0 + k < n_runs && k < BU_MULTI_RUNS; k++) {
             const BuRun& r = runs[r0 + k];
             const size_t t = (r.n + 1023) / 1024;
             if (n_tiles + t >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
-            tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, 0u};
+            // BC7 / ASTC: a run that is whole 64 x 16-block rectangles of a power-of-two grid is tiled that way -- the caller's blocks_per_row if it is one, else
+            // a virtual pitch (bu_launch_uastc has the story: 16 segments of 1 KiB at >= 4 KiB pitch load faster than 16 KiB in a row; multi-run launch over 32
+            // slices of 2^20 blocks 6.0 -> 5.6 us per slice)
+            uint32_t vshift = BU_RUN_STRIPS;
+            if (target == BU_TARGET_BC7 || target == BU_TARGET_ASTC) {
+                const size_t real = (blocks_per_row >= 128 && (blocks_per_row & (blocks_per_row - 1)) == 0 && blocks_per_row <= ((size_t)1 << 20)) ? blocks_per_row : 0;
+                for (const size_t v : {real, (size_t)1024, (size_t)2048, (size_t)512, (size_t)256}) {
+                    if (v && r.n % (16 * v) == 0) {
+                        vshift = 0;
+                        while (((size_t)BU_RECT_W << vshift) < v) vshift++;
+                        break;
+                    }
+                }
+            }
+            all_whole = all_whole && vshift != BU_RUN_STRIPS;
+            tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, vshift};
             tb.first_tile[k] = (uint32_t)n_tiles;
             n_tiles += t;
         }
@@ -238,7 +254,7 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
             continue;
         }
         for (size_t i = k; i < BU_MULTI_RUNS + 32; i++) tb.first_tile[i] = 0xFFFFFFFFu;
-        for (size_t i = k; i < BU_MULTI_RUNS; i++) tb.run[i] = BuRunDesc{nullptr, nullptr, 0, 0u, 0u};
+        for (size_t i = k; i < BU_MULTI_RUNS; i++) tb.run[i] = BuRunDesc{nullptr, nullptr, 0, 0u, BU_RUN_STRIPS};
         // Shapes, as the plain launcher picks them by size (bu_context.hpp): at most one tile per CU 1024 threads on it; beyond that 512 x 2.
         // BC7 / ASTC / RGBA32 batches of more tiles than fit the chip at once run as a PERSISTENT grid (four / four / two workgroups per CU)
         // whose workgroups walk the tiles of all runs with the next tile's loads in flight -- a batch of large slices in separate
@@ -263,6 +279,9 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
             unsigned* const ticket = (PERSIST && !half && n_tiles >= BU_TICKET_MIN_WALK * (size_t)grid) ? bu_ticket_for(ctx, s) : nullptr;
             if (one_per_cu)
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, (unsigned*)nullptr);
+            else if (PERSIST && all_whole && (T == BU_TGT_BC7 || T == BU_TGT_ASTC))
+                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST, (T == BU_TGT_BC7 || T == BU_TGT_ASTC)>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row,
+                                   stw, ctx->d_tables, ticket);
             else
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, ticket);
         };

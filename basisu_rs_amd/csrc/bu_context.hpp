@@ -310,6 +310,21 @@ bu_status bu_launch_uastc(bu_context* ctx, bu_target target, const void* d_in, s
         // (one tile per row, blocks_per_row == 64: the strip IS the rectangle)
         p.rect_rows = grid_cap == 0 && bpr >= 2 * RW && bpr % RW == 0 && bpr < ((size_t)1 << 21);
         p.rect_quantum = n_blocks <= piece ? 0 : piece;
+        // A VIRTUAL pitch for BC7 / ASTC when the caller gave no usable block grid (blocks_per_row 0, or no multiple of 64): for a block-linear target the
+        // grid never changes a byte, it only decides which 1024 blocks form a tile -- and a tile that is 16 segments of 1 KiB at a pitch of 4 KiB or more
+        // loads and stores measurably faster than 16 KiB in a row (its 16 segments sit on 16 different HBM channel groups; the workgroup waits for ALL of its
+        // tile at barrier 1): strips 8.94 / 5.77 / 187.5 us against 8.45 / 5.56 / 177.7 for a lone 2^20-block launch / four in flight / one 2^25-block launch
+        // (profiles/r06_tile_pitch_sweep.txt).  Needs whole tiles: the slice a multiple of 16 x pitch blocks.  (A real grid is kept whatever its pitch:
+        // on texture-like content rectangles of the IMAGE keep regions of one mode whole, which is worth more.)
+        if (!p.rect_rows && grid_cap == 0 && (target == BU_TARGET_BC7 || target == BU_TARGET_ASTC)) {
+            for (const size_t v : {(size_t)1024, (size_t)2048, (size_t)512, (size_t)256}) {
+                if (n_blocks % (16 * v) == 0) {
+                    p.bpr = bpr = v;
+                    p.rect_rows = true;
+                    break;
+                }
+            }
+        }
         p.rect_magic = p.rect_rows ? (unsigned)((((unsigned long long)1 << 32) + bpr / RW - 1) / (bpr / RW)) : 0u;  // ceil(2^32 / tiles per row)
         for (size_t done = 0; done < n_blocks; done += piece) {
             p.nb = n_blocks - done < piece ? n_blocks - done : piece;

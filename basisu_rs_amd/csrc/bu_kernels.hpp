@@ -185,9 +185,11 @@ struct BuRunDesc {
     void* out;        // its output
     uint64_t base;    // block-index base of the run (status words)
     uint32_t n;       // blocks in the run
-    uint32_t pad;
+    uint32_t vshift;  // BU_RUN_STRIPS: tiles are strips of 1024 consecutive blocks; else the run is whole 64 x 16-block rectangles of a (virtual) grid
+                      // 64 << vshift blocks wide (bu_launch_runs: a power of two, the run a multiple of 16 rows of it)
 };
 constexpr unsigned BU_MULTI_RUNS = 96;
+constexpr uint32_t BU_RUN_STRIPS = 0xFFFFFFFFu;
 struct BuRunTable {
     BuRunDesc run[BU_MULTI_RUNS];
     uint32_t first_tile[BU_MULTI_RUNS + 32];  // ascending; entries past the last run hold 0xFFFFFFFF (128 entries: two 64-lane loads)
@@ -197,11 +199,13 @@ static_assert(sizeof(BuRunDesc) == 32 && sizeof(BuRunTable) <= 3968, "the run ta
 struct BuTileDesc {
     const uint4* in;
     void* out;
-    uint32_t first;
+    uint32_t first;   // strips: the tile's first block inside its run; rectangles: (16 * tile row) * width + 64 * tile column, the block index of the tile's corner
     uint32_t n;
     uint64_t base;
+    uint32_t width;   // rectangles: blocks per row of the run's (virtual) grid; 0: strips
 };
-enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2 };
+enum { BU_LAYOUT_STRIP = 0, BU_LAYOUT_RECT = 1, BU_LAYOUT_MULTI = 2,
+       BU_LAYOUT_MULTI_WHOLE = 3 };  // MULTI with every run tiled as whole rectangles (BuRunDesc::vshift): no lane ever lacks a block, and the validity tests fold away as in RECT
 // one set of tile tickets (kernel, `ticket`): eight counters BU_TICKET_STRIDE words apart, then the count of workgroups that have left
 constexpr unsigned BU_TICKET_STRIDE = 32, BU_TICKET_DONE = 8 * BU_TICKET_STRIDE, BU_TICKET_WORDS = 9 * BU_TICKET_STRIDE;
 // WGS threads per workgroup, BPT blocks per thread: tile = WGS * BPT blocks.  PREFETCH: a workgroup that walks several tiles
@@ -235,7 +239,8 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // lives IN row 0 of that output tile: a lane reads its block from slot s and later overwrites exactly slot s with
     // the block's first pixel row, so no other lane's input is ever clobbered -- 64 KiB instead of 80 per 1024 blocks,
     // which is what lets two workgroups share a CU.
-    constexpr bool RECT = LAYOUT == BU_LAYOUT_RECT, MULTI = LAYOUT == BU_LAYOUT_MULTI;
+    constexpr bool RECT = LAYOUT == BU_LAYOUT_RECT, MULTI = LAYOUT == BU_LAYOUT_MULTI || LAYOUT == BU_LAYOUT_MULTI_WHOLE;
+    constexpr bool WHOLE = RECT || LAYOUT == BU_LAYOUT_MULTI_WHOLE;  // every tile of the launch holds BU_TILE blocks
     constexpr bool BU_ALIAS = TARGET == BU_TGT_RGBA;
     // two RGBA32 workgroups must fit the 160 KiB of a CU: output tile + table blob + status bytes + counters / chunk list
     static_assert(!BU_ALIAS || bu_lds_table_bytes(TARGET) + 4 * BU_TILE * 16 + BU_TILE + 1536 <= 80 * 1024,
@@ -279,7 +284,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     };
     // RECT launches hold whole tiles only: every lane of every tile has a block (keys are 0..19, never the "no block" 31), and the
     // validity tests below fold away
-    auto has_block = [&](uint32_t k) { return RECT || k < 20u; };
+    auto has_block = [&](uint32_t k) { return WHOLE || k < 20u; };
     unsigned tile = blockIdx.x;
     // Tile tickets (`ticket` != nullptr): a persistent workgroup's FIRST tile is its block index; every further tile is the next number off a
     // counter in device memory instead of tile + gridDim.x -- workgroups that run ahead (a cheaper mode mix, a luckier HBM channel, a CU they
@@ -300,7 +305,19 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     // MULTI: the current tile's descriptor (wave-uniform: scalar loads); every other layout addresses the one slice of the launch
     // `td` = the descriptor of the tile being sorted / transcoded / written back; `tl` = the descriptor of the tile whose blocks are being
     // LOADED (the same tile, or with PREFETCH the next one: its loads are in flight while `td`'s tile is transcoded)
-    BuTileDesc td = {in, out, 0u, 0u, base}, tl = td;
+    BuTileDesc td = {in, out, 0u, 0u, base, 0u}, tl = td;
+    // MULTI, persistent grid: the run table is copied to LDS once per workgroup (3.9 KiB) and every later look-up reads it there.  From the kernel
+    // arguments a look-up is two vector loads, a ballot and dependent scalar loads -- a microsecond of round trips between the scatter and the prefetch
+    // loads of EVERY tile, with the workgroup waiting at barrier (2) behind it (8 % of a multi-run launch over 2^20-block slices)
+    constexpr bool RUNS_IN_LDS = MULTI && PREFETCH;
+    __shared__ uint4 s_runs[RUNS_IN_LDS ? sizeof(BuRunTable) / 16 : 1];  // (16 bytes in every other instantiation)
+    const BuRunTable* R = runs;  // the table the look-ups read: the kernel arguments until the copy is complete (the first barrier), LDS from then on
+    if constexpr (RUNS_IN_LDS) {
+        static_assert(sizeof(BuRunTable) % 16 == 0, "copied in 16-byte pieces");
+        for (unsigned i = tid; i < sizeof(BuRunTable) / 16; i += WGS) s_runs[i] = reinterpret_cast<const uint4*>(runs)[i];
+    }
+    auto uni32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    auto uni64 = [&](uint64_t x) { return (uint64_t)uni32((uint32_t)x) | ((uint64_t)uni32((uint32_t)(x >> 32)) << 32); };
     auto desc_of = [&](unsigned t, BuTileDesc& d) {
         if constexpr (MULTI) {
             if (t < n_tiles) {
@@ -308,22 +325,35 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
                 uint32_t r = 0;
 #pragma unroll
                 for (unsigned c = 0; c < BU_MULTI_RUNS + 32; c += 64) {
-                    const uint32_t cnt = (uint32_t)__popcll(__ballot(runs->first_tile[c + lane] <= t));
+                    const uint32_t cnt = (uint32_t)__popcll(__ballot(R->first_tile[c + lane] <= t));
                     if (cnt) r = c + cnt - 1u;
                 }
                 r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-                const BuRunDesc rd = runs->run[r];
-                const uint32_t first = (t - runs->first_tile[r]) * (uint32_t)BU_TILE, left = rd.n - first;
-                d = BuTileDesc{rd.in, rd.out, first, left < (uint32_t)BU_TILE ? left : (uint32_t)BU_TILE, rd.base};
+                // (the record comes back in vector registers -- an LDS read --, but every lane read the same one: made scalar here, so that the tile's addresses
+                //  are an SGPR base and a VGPR offset like the one-slice kernel's, not 64-bit vector arithmetic per load and store)
+                const BuRunDesc rv = R->run[r];
+                const BuRunDesc rd = {reinterpret_cast<const uint4*>(uni64(reinterpret_cast<uint64_t>(rv.in))), reinterpret_cast<void*>(uni64(reinterpret_cast<uint64_t>(rv.out))),
+                                      uni64(rv.base), uni32(rv.n), uni32(rv.vshift)};
+                const uint32_t lt = t - uni32(R->first_tile[r]);  // the tile's number inside its run
+                if (rd.vshift != BU_RUN_STRIPS) {
+                    // a 64 x 16-block rectangle of the run's grid (tiles per row a power of two): 16 segments of 1 KiB at the grid's pitch instead of 16 KiB in a row
+                    const uint32_t ty = lt >> rd.vshift, tx = lt & ((1u << rd.vshift) - 1u), width = (uint32_t)BU_RECT_W << rd.vshift;
+                    d = BuTileDesc{rd.in, rd.out, (uint32_t)(BU_TILE / BU_RECT_W) * ty * width + (uint32_t)BU_RECT_W * tx, (uint32_t)BU_TILE, rd.base, width};
+                } else {
+                    const uint32_t first = lt * (uint32_t)BU_TILE, left = rd.n - first;
+                    d = BuTileDesc{rd.in, rd.out, first, left < (uint32_t)BU_TILE ? left : (uint32_t)BU_TILE, rd.base, 0u};
+                }
             }
         }
     };
     desc_of(tile, td);
     tl = td;
     // block l of tile t (whose descriptor is `tl`): where it is loaded from, whether it exists
-    auto blk_src = [&](unsigned t, unsigned l) { return MULTI ? tl.in + (tl.first + l) : in + gidx(t, l); };
+    // MULTI: block l of the tile described by d, as an index inside d's run (strips: consecutive; rectangles: row l / 64, column l % 64 of the tile)
+    auto run_idx = [&](const BuTileDesc& d, unsigned l) { return d.first + ((WHOLE || d.width) ? (l / BU_RECT_W) * d.width + (l % BU_RECT_W) : l); };
+    auto blk_src = [&](unsigned t, unsigned l) { return MULTI ? tl.in + run_idx(tl, l) : in + gidx(t, l); };
     auto blk_valid = [&](unsigned t, unsigned l) {
-        if constexpr (MULTI) return t < n_tiles && l < tl.n;
+        if constexpr (MULTI) return t < n_tiles && (WHOLE || l < tl.n);
         else return RECT ? t < n_tiles : (t < n_tiles && gidx(t, l) < n_blocks && in_tile(l));
     };
     // Table staging.  The staged 16-byte pieces of the LDS image are numbered 0..TVT-1: BC7's own tables, then the target's one or
@@ -370,6 +400,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
     if (tid < 64) (&cnt[0][0])[tid] = 0;
     if (tid < 2) next_chunk[tid] = 0;
     __syncthreads();
+    if constexpr (RUNS_IN_LDS) R = reinterpret_cast<const BuRunTable*>(s_runs);
     unsigned par = 0;
     unsigned next_of_loop = 0;
     for (; tile < n_tiles; tile = next_of_loop, par ^= 1u) {
@@ -384,7 +415,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
         bool uniform = true;
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
-            const bool valid = RECT || (MULTI ? (unsigned)(j * BU_WG) + tid < td.n : (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid)));  // (RECT: whole tiles only)
+            const bool valid = WHOLE || (MULTI ? (unsigned)(j * BU_WG) + tid < td.n : (tbase + j * BU_WG + tid < n_blocks && in_tile(j * BU_WG + tid)));  // (RECT: whole tiles only)
             key[j] = valid ? T.key_lut[TARGET][v[j].x & 127u] : 31u;
             uniform = uniform && (__ballot(key[j] == (uint32_t)__builtin_amdgcn_readfirstlane(key[j])) == ~0ull) && has_block(key[j]);
         }
@@ -493,7 +524,7 @@ __device__ __forceinline__ void bu_uastc_sorted_body(const uint4* __restrict__ i
 #pragma unroll
         for (int j = 0; j < BU_BPT; j++) {
             if (has_block(key[j])) {
-                const unsigned idx = MULTI ? td.first + j * BU_WG + tid : gidx(tile, j * BU_WG + tid);  // (MULTI: inside the tile's slice)
+                const unsigned idx = MULTI ? run_idx(td, j * BU_WG + tid) : gidx(tile, j * BU_WG + tid);  // (MULTI: inside the tile's slice)
                 void* const out = td.out;                  // (the launch's `out` unless MULTI)
                 const unsigned long long base = td.base;
                 if constexpr (INBLOCK) {
@@ -557,20 +588,21 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
                                                                 const BuTablesAll* __restrict__ tables, unsigned cus, unsigned tile_rt,
                                                                 unsigned* __restrict__ ticket)
 {
-    static_assert(LAYOUT != BU_LAYOUT_MULTI, "several runs per launch: bu_uastc_multi_kernel");
+    static_assert(LAYOUT != BU_LAYOUT_MULTI && LAYOUT != BU_LAYOUT_MULTI_WHOLE, "several runs per launch: bu_uastc_multi_kernel");
     bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, LAYOUT>(in, out, n_blocks, bpr, base, status, tables, cus, tile_rt, nullptr, ticket);
 }
 
 // several runs in one launch (layout MULTI): n_tiles 1024-block tiles over the runs of `table` (a kernel argument, by value).
 // PREFETCH: the launch is a persistent grid whose workgroups walk many tiles (batches of large slices): the next tile's blocks -- of
 // whatever run it belongs to -- are loaded while the current tile is transcoded, as in the one-slice kernel.
-template <int TARGET, int WGS, int BPT, bool PREFETCH = false>
+// WHOLE: every run of the table is tiled as whole rectangles (the host checked: BuRunDesc::vshift of all of them)
+template <int TARGET, int WGS, int BPT, bool PREFETCH = false, bool WHOLE = false>
 __global__ __launch_bounds__(WGS, 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
                                                              const BuTablesAll* __restrict__ tables, unsigned* __restrict__ ticket)
 {
     static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");
     static_assert(sizeof(BuRunTable) + 40 <= 4096, "the run table and the other arguments share the 4 KiB of kernel arguments");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table, ticket);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, WHOLE ? BU_LAYOUT_MULTI_WHOLE : BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table, ticket);
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into

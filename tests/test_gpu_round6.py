@@ -353,6 +353,73 @@ def test_batch_device_long_walk_draws_tickets(golden, target):
     ctx.close()
 
 
+@pytest.mark.parametrize("target", ["bc7", "astc"])
+def test_virtual_pitch_tiles_without_a_block_grid(golden, target):
+    """BC7 / ASTC without a usable blocks_per_row (0, or no multiple of 64): slices that are whole multiples of 16 x {1024, 2048, 512, 256} blocks are tiled as 64 x 16-block
+    rectangles of a VIRTUAL grid (faster loads and stores; never a different byte) -- small and large launches, both policies' shapes, lowest failing block -- and the same
+    inside ONE multi-run launch: every run whole (the kernel variant without validity tests), and whole and ragged runs mixed"""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    lib = ctx._lib
+    t, bb = TB[target]
+    gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden[target]).cuda()
+    for bpr, n in [(0, 1 << 20), (0, 3 * 16384), (0, 5 * 4096), (0, 7 * 8192), (100, 2 * 32768), (0, (1 << 21) + 16384), (0, 1 << 24)]:
+        idx = torch.from_numpy(synth.gold_indices(n, seed=n & 0xFFFF)).cuda()
+        d_in = gu[idx].contiguous()
+        for shared in (False, True):
+            ctx.set_launch_policy(shared)
+            d_out = torch.zeros((n, bb), dtype=torch.uint8, device="cuda")
+            status = torch.empty(1, dtype=torch.int64, device="cuda")
+            ctx.status_word_reset(status)
+            torch.cuda.synchronize()
+            ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr, block_index_base=5, d_status=status)
+            torch.cuda.synchronize()
+            ctx.status_word_check(int(status.item()))
+            assert torch.equal(d_out, gt[idx]), (target, bpr, n, shared)
+        bad = n // 3 + 1
+        d_in[bad, 0] = 69
+        d_in[n - 1, 0] = 69
+        torch.cuda.synchronize()
+        ctx.transcode_device(t, d_in, n, d_out, blocks_per_row=bpr, block_index_base=5, d_status=status)
+        torch.cuda.synchronize()
+        with pytest.raises(BasisuError) as e:
+            ctx.status_word_check(int(status.item()))
+        assert e.value.first_bad_block == 5 + bad and not d_out[bad].any()
+        del d_in, d_out
+    ctx.set_launch_policy("auto")
+    # one multi-run launch: (a) every run whole, (b) whole and ragged runs mixed; separate allocations
+    for sizes in ([1 << 20, 3 << 18, 1 << 20, 5 << 18, 1 << 20, 1 << 19], [1 << 20, (1 << 20) + 1024, 3 << 18, 300000, 1 << 20, 77 * 1024]):
+        n_s = len(sizes)
+        idxs = [torch.randint(0, 608, (n,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(500 + k)) for k, n in enumerate(sizes)]
+        ins = [gu[i].contiguous() for i in idxs]
+        outs = [torch.zeros((n, bb), dtype=torch.uint8, device="cuda") for n in sizes]
+        status = torch.empty(1, dtype=torch.int64, device="cuda")
+        ctx.status_word_reset(status)
+        torch.cuda.synchronize()
+        VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+        a = (n_s, VP(*[x.data_ptr() for x in ins]), SZ(*sizes), VP(*[x.data_ptr() for x in outs]))
+        for bpr in (0, 1024):
+            for o in outs:
+                o.zero_()
+            assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, a[0], a[1], a[2], a[3], bpr, None, ctypes.c_void_p(status.data_ptr()), None) == 0
+            torch.cuda.synchronize()
+            ctx.status_word_check(int(status.item()))
+            for k in range(n_s):
+                assert torch.equal(outs[k], gt[idxs[k]]), (target, sizes, bpr, k)
+        ins[4][sizes[4] - 1, 0] = 69
+        ins[1][12345, 0] = 69
+        torch.cuda.synchronize()
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, a[0], a[1], a[2], a[3], 0, None, ctypes.c_void_p(status.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        with pytest.raises(BasisuError) as e:
+            ctx.status_word_check(int(status.item()))
+        assert e.value.first_bad_block == sizes[0] + 12345
+    ctx.close()
+
+
 # ---- bu_array_transcode_sharded with ranges that draw tickets ---------------------------------------------------------------------------
 def _ptr_array(vals):
     return (ctypes.c_void_p * len(vals))(*vals)

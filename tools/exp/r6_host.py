@@ -269,3 +269,58 @@ if "multi" in what:
         ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(n))
         print("%2d slices per call: fixed walk %.2f %.2f   tickets %.2f %.2f us per slice   verified %s" % (n, res[0], res[2], res[1], res[3], ok))
     ctx.close()
+
+if "multi2" in what:
+    # 32 atlases per launch: (a) contiguous in one allocation -- the plain persistent launch (bu_uastc_transcode_device), (b) in 32 separate allocations -- ONE multi-run launch
+    # (bu_uastc_transcode_batch_device); exclusive policy, tickets on; events around 24 launches after a long warm-up, alternating
+    ctx = Context(0)
+    lib = ctx._lib
+    ctx.set_launch_policy(False)
+    n = 32
+    idxs, ins, outs = atlases(64)
+    cat_in = [torch.cat(ins[:32]).contiguous(), torch.cat(ins[32:]).contiguous()]
+    cat_out = [torch.zeros((32 * NB, 16), dtype=torch.uint8, device=dev) for _ in range(2)]
+    s = torch.cuda.Stream()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    VP, SZ = ctypes.c_void_p * n, ctypes.c_size_t * n
+    sets = [(VP(*[ins[h * 32 + k].data_ptr() for k in range(n)]), SZ(*([NB] * n)), VP(*[outs[h * 32 + k].data_ptr() for k in range(n)])) for h in range(2)]
+
+    def contiguous(k):
+        assert lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(cat_in[k % 2].data_ptr()), 32 * NB, ctypes.c_void_p(cat_out[k % 2].data_ptr()), 1024, 0, None, sp) == 0
+
+    def separate(k):
+        a = sets[k % 2]
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, n, a[0], a[1], a[2], 1024, None, None, sp) == 0
+
+    def timed(fn, reps=24):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(8):
+            fn(k)
+        e0.record(s)
+        for k in range(reps):
+            fn(k)
+        e1.record(s)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps / n
+
+    # (c) the multi-run launch over the CONTIGUOUS buffers: 32 slices that would merge, kept apart by gaps in the block numbering -- the kernel's share of the difference
+    U64 = ctypes.c_uint64 * n
+    gaps = U64(*[k * 2 * NB for k in range(n)])
+    csets = [(VP(*[cat_in[h].data_ptr() + k * NB * 16 for k in range(n)]), SZ(*([NB] * n)), VP(*[cat_out[h].data_ptr() + k * NB * 16 for k in range(n)])) for h in range(2)]
+
+    def separate_runs_contiguous_memory(k):
+        a = csets[k % 2]
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, n, a[0], a[1], a[2], 1024, gaps, None, sp) == 0
+
+    def contiguous_strips(k):  # the plain launch without a block grid: tiles are strips of 1024 consecutive blocks, as in the multi-run kernel
+        assert lib.bu_uastc_transcode_device(ctx.handle, _lib.BC7, ctypes.c_void_p(cat_in[k % 2].data_ptr()), 32 * NB, ctypes.c_void_p(cat_out[k % 2].data_ptr()), 0, 0, None, sp) == 0
+
+    for _ in range(40):
+        contiguous(_)
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        print("round %d: contiguous %.3f us per atlas (strips: %.3f)   32 separate allocations, one launch %.3f   32 runs in contiguous memory, one launch %.3f" % (
+            rnd, timed(contiguous), timed(contiguous_strips), timed(separate), timed(separate_runs_contiguous_memory)))
+    ok = all(bool(torch.equal(outs[k], g_b[idxs[k]])) for k in range(64)) and bool(torch.equal(cat_out[0][:NB], g_b[idxs[0]]))
+    print("verified:", ok)
+    ctx.close()
