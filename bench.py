@@ -1267,6 +1267,33 @@ def run_atlas4096(env):
                                                              "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
                                                              "note": "one call of bu_uastc_transcode_batch_device per eight 2^20-block slices in separate allocations = ONE launch over 2^23 blocks, "
                                                                      "calls back to back on one stream, exclusive policy; every rotated output compared afterwards"}
+            # ... and ALL the headline's atlases (separate allocations) through one call = ONE launch on the caller's stream: a persistent grid over 64 runs of whole
+            # rectangular tiles, drawing its tiles by ticket -- the stream-ordered way to the pipeline's rate, and one kernel for a profiler to time
+            if nbuf <= 96:
+                VPn, SZn = ctypes.c_void_p * nbuf, ctypes.c_size_t * nbuf
+                ball = (VPn(*[in_ptrs[j] for j in range(nbuf)]), SZn(*([N_BLOCKS] * nbuf)), VPn(*[out_ptrs[j] for j in range(nbuf)]))
+                for o_ in outs:
+                    o_.zero_()
+
+                def all_atlases():
+                    assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, nbuf, ball[0], ball[1], ball[2], NBX, None, None, sp) == 0
+
+                t_b = time.perf_counter()
+                while (time.perf_counter() - t_b) * 1e3 < max(args.prewarm_ms, 1.0) * 2:
+                    all_atlases()
+                    torch.cuda.synchronize()
+                e0.record(stream)
+                for k in range(12):
+                    all_atlases()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ball_s = e0.elapsed_time(e1) / 1e3 / (12 * nbuf)
+                extra["batch_all_atlases_one_launch"] = {"atlases_per_launch": nbuf, "us_per_atlas": round(ball_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / ball_s / 1e6, 1),
+                                                         "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / ball_s / 1e9 / HBM_PEAK_GBS, 4),
+                                                         "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
+                                                         "note": "ONE call of bu_uastc_transcode_batch_device over the headline's %d atlases in their separate allocations = one launch "
+                                                                 "on the caller's stream (run table in the kernel arguments, copied to LDS; every run tiled as 64 x 16-block rectangles; "
+                                                                 "tiles drawn by ticket), 12 calls back to back between events" % nbuf}
             # the same loop as ONE call of the pipelined entry point: bu_uastc_transcode_batch_in_flight issues the slices round-robin on the context's
             # four streams under the shared policy and returns; bu_context_synchronize waits.  512 slices per call (the 64 atlases eight times over),
             # host clock around call + wait -- the pipeline's fill and drain and the final wake-up are inside
