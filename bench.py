@@ -50,6 +50,7 @@ NBX = NBY = 1024  # 4096x4096 px
 N_BLOCKS = NBX * NBY
 BYTES_PER_BLOCK = 32  # 16 read + 16 written
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ATLASES_PER_STEP = 64  # --method batch: one step = ONE launch over this many 4096x4096 atlases in separate allocations (at most BU_MULTI_RUNS = 96 runs per launch)
 ETC1S_UNPINNED = "unpinned: the reference holds no ETC1S / BasisLZ vectors (tests/corpus_tests.rs:54-73 are #[ignore]d, the corpus absent); checked against the oracle's reading of the source"
 
 
@@ -139,12 +140,25 @@ def pmc_child():
     dev = torch.device("cuda", 0)
     gu = torch.from_numpy(g["uastc"]).to(dev)
     ins, outs = [], []
-    for k in range(24):
+    n_atl = ATLASES_PER_STEP if os.environ.get("BENCH_PMC_BATCH") == "1" else 24
+    for k in range(n_atl):
         gen = torch.Generator(device=dev)
         gen.manual_seed(k + 1)
         ins.append(gu[torch.randint(0, 608, (N_BLOCKS,), device=dev, generator=gen)].contiguous())
         outs.append(torch.empty((N_BLOCKS, 16), dtype=torch.uint8, device=dev))
     torch.cuda.synchronize()
+    if os.environ.get("BENCH_PMC_BATCH") == "1":
+        # the headline's step: ONE launch (bu_uastc_transcode_batch_device on the NULL stream) over ATLASES_PER_STEP atlases in separate allocations; the counter
+        # passes run 4 such launches, the trace pass BENCH_PMC_ROUNDS of them back to back
+        lib = _lib.load()
+        ctx.set_launch_policy("auto")
+        VPn, SZn = ctypes.c_void_p * n_atl, ctypes.c_size_t * n_atl
+        a_in, a_n, a_out = VPn(*[t.data_ptr() for t in ins]), SZn(*([N_BLOCKS] * n_atl)), VPn(*[t.data_ptr() for t in outs])
+        for _ in range(max(4, int(os.environ.get("BENCH_PMC_ROUNDS", "4")))):
+            assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, n_atl, a_in, a_n, a_out, NBX, None, None, None) == 0
+        torch.cuda.synchronize()
+        ctx.close()
+        return
     rounds = max(1, int(os.environ.get("BENCH_PMC_ROUNDS", "1")))
     streams = max(1, int(os.environ.get("BENCH_PMC_STREAMS", "1")))
     if os.environ.get("BENCH_PMC_ARRAY") == "1":
@@ -199,7 +213,7 @@ def _run_child(cmd, env, timeout_s):
         raise
 
 
-def live_traffic(in_flight=1, policy="shared", timeout_s=90):
+def live_traffic(in_flight=1, policy="shared", timeout_s=90, batch=False):
     """HBM bytes per launch of the BC7 kernel MEASURED IN THIS RUN: two child rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE,
     then WRITE_SIZE: separate passes, nothing but --kernel-trace beside --pmc, the program directly after `--`) over
     `bench.py --pmc-child`, run before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE count KiB; gfx950 reports half of
@@ -292,18 +306,40 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
         except Exception as e:
             if isinstance(trace, dict):
                 trace["array32"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # ---- the headline's step (--method batch): ONE launch over ATLASES_PER_STEP atlases -- rocprofv3's own per-kernel duration, then its counters below ----
+        is_multi = lambda name: "bu_uastc_multi_kernel<1," in name.replace("(int)", "")
+        if batch:
+            try:
+                out = os.path.join(work, "batch_trace")
+                cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
+                rc, err = _run_child(cmd, dict(env, BENCH_PMC_BATCH="1", BENCH_PMC_ROUNDS="240"), timeout_s)
+                durs = []
+                for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if is_multi(row["Kernel_Name"]):
+                            durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+                durs = [d_ for _, d_ in sorted(durs)]
+                durs = durs[len(durs) // 2:]  # (the clocks settle on the load they are given: ~40 ms)
+                if rc == 0 and len(durs) >= 16 and isinstance(trace, dict):
+                    trace["batch"] = {"launches": len(durs), "atlases_per_launch": ATLASES_PER_STEP, "kernel_avg_ns": round(sum(durs) / len(durs), 1),
+                                      "kernel_median_ns": float(np.median(durs)), "kernel_min_ns": min(durs), "kernel_max_ns": max(durs),
+                                      "source": "child rocprofv3 --kernel-trace pass over `bench.py --pmc-child` with BENCH_PMC_BATCH=1: 240 launches of bu_uastc_transcode_batch_device over "
+                                                "%d atlases of 4096^2 in separate allocations, back to back on the NULL stream, the last half counted" % ATLASES_PER_STEP}
+            except Exception as e:
+                if isinstance(trace, dict):
+                    trace["batch"] = {"error": "%s: %s" % (type(e).__name__, e)}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"]
-            rc, err = _run_child(cmd, env, timeout_s)
+            rc, err = _run_child(cmd, dict(env, BENCH_PMC_BATCH="1") if batch else env, timeout_s)
             if rc != 0:
                 return None, "rocprofv3 --pmc %s exited with %d: %s" % (counter, rc, err.decode(errors="replace")[-200:]), trace
             got = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] == counter and is_bc7(row["Kernel_Name"]):
+                    if row["Counter_Name"] == counter and (is_multi(row["Kernel_Name"]) if batch else is_bc7(row["Kernel_Name"])):
                         got.append(float(row["Counter_Value"]))
-            if len(got) < 8:
+            if len(got) < (4 if batch else 8):
                 return None, "rocprofv3 --pmc %s reported %d launches of the BC7 kernel" % (counter, len(got)), trace
             vals[counter] = sum(got) / len(got)
             vals[counter + "_n"] = len(got)
@@ -313,8 +349,9 @@ def live_traffic(in_flight=1, policy="shared", timeout_s=90):
         shutil.rmtree(work, ignore_errors=True)
     nbytes = int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
     return nbytes, ("measured in this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over `bench.py --pmc-child` "
-                    "(%d + %d launches of this kernel on cold atlases; (2 x FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 read correction of "
-                    "MI355X_MICROARCH.md; %.0f s with the trace pass)" % (vals["FETCH_SIZE_n"], vals["WRITE_SIZE_n"], time.time() - t0)), trace
+                    "(%d + %d launches of %s; (2 x FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 read correction of "
+                    "MI355X_MICROARCH.md; %.0f s with the trace passes)" % (vals["FETCH_SIZE_n"], vals["WRITE_SIZE_n"],
+                                                                         ("the headline's launch over %d cold atlases" % ATLASES_PER_STEP) if batch else "this kernel on cold atlases", time.time() - t0)), trace
 
 
 def cpu_baseline(golden, idx, budget_s=12.0):
@@ -383,6 +420,11 @@ def main():
     ap.add_argument("--config", choices=("atlas4096", "array512"), default="atlas4096")
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--method", choices=("batch", "pipeline"), default="batch",
+                    help="what a step of --config atlas4096 is.  batch (default): ONE launch -- one call of bu_uastc_transcode_batch_device on the caller's stream -- over "
+                         "%d atlases of 4096x4096 in separate allocations (a persistent grid over all their tiles, drawn by ticket): a kernel whose duration HIP events and "
+                         "rocprofv3 agree on.  pipeline: one launch per atlas, --in-flight of them in flight on the context's streams (rounds 5's headline; always measured and "
+                         "reported under `one_launch_per_atlas_in_flight`)" % ATLASES_PER_STEP)
     ap.add_argument("--nbuf", type=int, default=64, help="distinct atlas buffers rotated through (cold cache)")
     ap.add_argument("--prewarm-ms", type=float, default=40.0,
                     help="untimed launches BEFORE the W warm-up steps until this many milliseconds have passed: the GPU needs ~20 ms of "
@@ -435,7 +477,7 @@ def main():
     assert not torch.cuda.is_initialized()
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "atlas4096" and not args.headline_only and not args.no_live_traffic
             and os.environ.get("BENCH_FORCE_DIST") != "1"):
-        live = live_traffic(args.in_flight, args.policy)
+        live = live_traffic(args.in_flight, args.policy, batch=args.method == "batch")
 
     # stdout carries exactly ONE line, the JSON result of rank 0: libraries print banners there (RCCL's version block lands
     # in the C stdio buffer and is flushed at exit, i.e. BEHIND a Python print when stdout is a pipe), so file descriptor 1
@@ -736,6 +778,131 @@ class ProductWindow:
             self.streams = {"start_us": [round(a_[i] * 1e3, 1) for i in range(n_.value)], "end_us": [round(b_[i] * 1e3, 1) for i in range(n_.value)]}
         self.ctx.synchronize()  # (the tail)
         return ev.value, strict.value, host.value
+
+
+def batch_headline(env, line, in_ptrs, out_ptrs, nbuf, outs, idxs, status):
+    """--method batch: the headline with one step = ONE launch over ATLASES_PER_STEP atlases.  One call of bu_uastc_transcode_batch_device on the caller's stream (torch's
+    NULL stream) hands the library the atlases' separate allocations; they go out as ONE kernel -- a persistent grid that walks the 64 Ki tiles of all runs, every run tiled as
+    64 x 16-block rectangles, the tiles drawn by ticket -- whose duration is the step.  A kernel's duration is what HIP events, the host clock and rocprofv3 all measure the
+    same way: no streams, no period, no hardware queues.  W warm-up steps, barrier + synchronize, lead steps + EXACTLY K timed steps enqueued back to back with an event on
+    either side, barrier + synchronize; --repeats windows, the median reported, MAX over ranks.  Rewrites the line's top-level figures; what the pipeline measured moves to
+    line["one_launch_per_atlas_in_flight"]."""
+    torch, dist, lib, ctx, args = env.torch, env.dist, env.lib, env.ctx, env.args
+    world, rank, dev = env.world, env.rank, env.dev
+    A = min(nbuf, ATLASES_PER_STEP)
+    VPn, SZn = ctypes.c_void_p * A, ctypes.c_size_t * A
+    sets = []
+    for r_ in range(max(1, nbuf // A)):  # (nbuf = 64: one set -- every step touches all 2 GiB of the rotation, eight times the Infinity Cache)
+        sets.append((VPn(*[in_ptrs[r_ * A + j] for j in range(A)]), SZn(*([N_BLOCKS] * A)), VPn(*[out_ptrs[r_ * A + j] for j in range(A)])))
+    stp = ctypes.c_void_p(status.data_ptr())
+    sp = env.sp
+    ctx.set_launch_policy("auto")
+    n_step = [0]
+
+    def step(stream_ptr=None):
+        a_ = sets[n_step[0] % len(sets)]
+        n_step[0] += 1
+        check(env, lib.bu_uastc_transcode_batch_device(ctx.handle, env._lib.BC7, A, a_[0], a_[1], a_[2], NBX, None, stp, stream_ptr or sp), "bu_uastc_transcode_batch_device")
+
+    # correctness gate through this very path: every atlas of the step against the known answers
+    for k in range(A):
+        outs[k].zero_()
+    ctx.status_word_reset(status)
+    torch.cuda.synchronize()
+    step()
+    torch.cuda.synchronize()
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    for k in range(A):
+        if not torch.equal(outs[k], env.g_bc7[idxs[k]]):
+            raise SystemExit("bench: BC7 output of atlas %d (batch step) differs from the known-answer vectors" % k)
+    t_pre, prewarm_steps = time.perf_counter(), 0
+    while args.prewarm_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        prewarm_steps += 4
+    for _ in range(max(0, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    busy_barrier(env, lambda i, ssp: step(ssp), 8)  # (N > 1: the ranks meet while ~3 ms of untimed steps keep the GPU busy)
+    lead = 8
+    wins = []
+    for _ in range(max(1, args.repeats)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _l in range(lead):
+            step()
+        e0.record(env.stream)
+        for _k in range(args.steps):
+            step()
+        e1.record(env.stream)
+        late = e0.query()
+        while not e0.query():
+            pass
+        t0 = time.perf_counter()
+        while not e1.query():
+            pass
+        host_ms = (time.perf_counter() - t0) * 1e3
+        ev_ms = e0.elapsed_time(e1)
+        wins.append((max(ev_ms, 0.0 if late else host_ms), ev_ms, host_ms, bool(late)))
+    torch.cuda.synchronize()
+    if env.use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([w[0] / 1e3 for w in wins] + [w[1] / 1e3 for w in wins], dtype=torch.float64, device=dev)
+    if env.use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    R_ = len(wins)
+    dts, evs = [float(x) for x in t[:R_]], [float(x) for x in t[R_:]]
+    m_ = sorted(range(R_), key=lambda i: dts[i])[R_ // 2]
+    dt, ev = dts[m_], evs[m_]
+    ctx.status_word_check(int(status.item()) & 0xFFFFFFFFFFFFFFFF)
+    K = args.steps
+    step_s = ev / K
+    achieved = BYTES_PER_BLOCK * A * N_BLOCKS / step_s / 1e9
+    old_roof = line["roofline"]
+    line["one_launch_per_atlas_in_flight"] = {
+        "value": line["value"], "unit": line["unit"], "us_per_atlas": round(line["ms_per_step"] * 1e3, 3), "launches_in_flight": line["config"].get("launches_in_flight"),
+        "launch_policy": line["config"].get("launch_policy"), "workload": line["config"]["workload"], "timed_region": line["config"].pop("timed_region", None),
+        "roofline": {k_: v_ for k_, v_ in old_roof.items() if k_ not in ("one_launch_of_32_contiguous_atlases",)},
+        "note": "rounds 5's headline, measured in this run by its own method: one launch per atlas, step i on context stream i % in_flight, K timed launches between per-stream events "
+                "(window = last lead launch complete -> last timed launch complete); a pipeline's throughput is a PERIOD, which rocprofv3 does not report"}
+    live = env.live_traffic
+    tr = live[2] if len(live) > 2 and isinstance(live[2], dict) else None
+    rp = (tr or {}).get("batch")
+    line["value"] = round(world * K * A * N_BLOCKS / dt / 1e6, 1)
+    line["ms_per_step"] = round(dt / K * 1e3, 6)
+    line["config"]["method"] = "batch"
+    line["config"]["workload"] = ("UASTC->BC7, %d atlases of 4096x4096 px (1 048 576 blocks each, separate allocations) per GPU per step, ONE launch per step: one call of "
+                                  "bu_uastc_transcode_batch_device on the caller's stream = one persistent grid over the %d tiles of all runs (rectangular 64 x 16-block tiles, "
+                                  "drawn by ticket); A-gold atlases (block i = reference known-answer block h(i) mod 608, uniform mix of the 19 modes), %d distinct atlases rotated "
+                                  "(every step touches %.1f GiB: cold cache)" % (A, A * 1024, nbuf, A * N_BLOCKS * 32 / 2 ** 30))
+    line["config"]["atlases_per_step"] = A
+    line["config"]["blocks_per_step_per_gpu"] = A * N_BLOCKS
+    line["config"]["us_per_atlas"] = round(dt / K / A * 1e6, 4)
+    line["config"]["gb_s_in"] = round(line["value"] * 16 / 1e3, 1)
+    line["config"]["prewarm"] = {"steps": prewarm_steps, "ms": args.prewarm_ms, "note": "untimed steps ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}
+    line["config"]["timed_region"] = {
+        "lead_steps": lead, "repeats": R_, "window_reported": "median", "windows_ms_per_step": [round(x / K * 1e3, 5) for x in dts], "event_ms": round(wins[m_][1], 6),
+        "host_ms": round(wins[m_][2], 6), "host_started_late": wins[m_][3],
+        "note": "barrier + synchronize, then -- enqueued back to back on one stream, no host synchronisation in between -- %d untimed lead steps, an event, EXACTLY K timed steps, an event; "
+                "host clock from the first event seen complete to the second; value uses max(host, event) of the median window, MAX over ranks.  One step = one kernel: its "
+                "duration is the step" % lead}
+    line["roofline"] = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": live[0] if live[0] is not None else None,
+        "traffic_source": live[1] if live[0] is not None else "not measured in this run (%s); committed passes of this launch: profiles/r06_*pmc*batch*" % live[1],
+        "traffic_over_algorithmic": round(live[0] / (BYTES_PER_BLOCK * A * N_BLOCKS), 4) if live[0] else None,
+        "kernel": "bu_uastc_multi_kernel<BC7, 512 threads x 2 blocks, persistent, whole rectangular tiles> over %d runs" % A,
+        "us_per_launch": round(step_s * 1e6, 3), "us_per_atlas": round(step_s / A * 1e6, 4), "bytes_per_launch": BYTES_PER_BLOCK * A * N_BLOCKS, "atlases_per_launch": A,
+        "rocprofv3_this_run": rp,
+        "us_per_launch_by_rocprofv3_kernel_avg": round(rp["kernel_avg_ns"] / 1e3, 3) if rp and rp.get("kernel_avg_ns") else None,
+        "frac_by_rocprofv3_kernel_avg": round(BYTES_PER_BLOCK * A * N_BLOCKS / rp["kernel_avg_ns"] / HBM_PEAK_GBS, 4) if rp and rp.get("kernel_avg_ns") else None,
+        "one_launch_of_32_contiguous_atlases": old_roof.get("one_launch_of_32_contiguous_atlases"),
+        "note": "achieved = algorithmic bytes per launch (32 B x 2^20 blocks x %d atlases) / the launch's average duration = HIP events around the K timed launches / K; "
+                "rocprofv3_this_run: the same launch's per-kernel duration from a child `rocprofv3 --kernel-trace` pass of this run (240 launches, the last half counted); "
+                "traffic: child --pmc FETCH_SIZE / WRITE_SIZE passes over the same launch, (2 x FETCH + WRITE) KiB (the gfx950 read correction).  The three clocks agree because "
+                "the step is ONE kernel; `one_launch_per_atlas_in_flight` has round 5's pipeline, measured in this run too" % A}
+    return line
 
 
 def run_array512(env):
@@ -1999,6 +2166,13 @@ def run_atlas4096(env):
 
     if allgather:
         line["allgather"] = allgather
+    if args.method == "batch":
+        try:
+            line = batch_headline(env, line, in_ptrs, out_ptrs, nbuf, outs, idxs, status)
+        except SystemExit:
+            raise
+        except Exception as e:  # the pipeline's line stands, and says why
+            line["config"]["method"] = "pipeline (the batch step failed: %r)" % (e,)
     if world == 1 and rank == 0 and not args.no_cpu and not args.headline_only:
         line["cpu_baseline"] = cpu_baseline(golden, idx0)
     return line

@@ -343,7 +343,7 @@ def test_bench_dist_branch_checks_that_its_streams_are_in_step(queues):
     env.pop("GPU_MAX_HW_QUEUES", None)
     if queues:
         env["GPU_MAX_HW_QUEUES"] = queues
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--headline-only", "--no-cpu", "--steps", "20", "--warmup", "5"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--method", "pipeline", "--headline-only", "--no-cpu", "--steps", "20", "--warmup", "5"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])

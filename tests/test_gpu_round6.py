@@ -517,3 +517,26 @@ def test_read_to_bc7_large_file(ctx, golden):
     with pytest.raises(BasisuError) as e:
         bu.read_to_bc7(f, ctx)
     assert e.value.status == _lib.ERR_INVALID_MODE
+
+
+def test_bench_default_method_is_one_launch_per_64_atlases():
+    """bench.py's default line (--method batch): a step is ONE launch over 64 atlases in separate allocations through bu_uastc_transcode_batch_device; the line's value, ms_per_step and
+    roofline belong to that kernel (HIP events), round 5's pipeline is measured beside it, and with BENCH_FORCE_DIST the N > 1 branch runs the same steps"""
+    import socket
+
+    for force_dist in (False, True):
+        env = dict(os.environ)
+        if force_dist:
+            env["BENCH_FORCE_DIST"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--headline-only", "--no-cpu", "--no-live-traffic", "--steps", "6", "--warmup", "2"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["config"]["method"] == "batch" and line["config"]["atlases_per_step"] == 64 and line["steps"] == 6
+        us_atlas = line["ms_per_step"] * 1e3 / 64
+        assert 4.8 < us_atlas < 7.5, us_atlas
+        assert abs(line["value"] - 64 * (1 << 20) / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]
+        roof = line["roofline"]
+        assert roof["atlases_per_launch"] == 64 and 0.55 < roof["frac"] < 0.9 and roof["bytes_per_launch"] == 64 * 32 << 20
+        pipe = line["one_launch_per_atlas_in_flight"]
+        assert 4.8 < pipe["us_per_atlas"] < 9.0 and pipe["roofline"]["bound"] == "hbm"

@@ -37,6 +37,16 @@ if not only or "rgba" in only:
     ms = ctypes.c_float(0)
     assert lib.bu_time_uastc_launches(ctx.handle, _lib.RGBA32, A8(*[x.data_ptr() for x in ins[:8]]), A8(*[x.data_ptr() for x in ro]), 8, 0, N, 1024, NBUF * REPS, None, sp, ctypes.byref(ms)) == 0
     torch.cuda.synchronize(); del ro
+if not only or "batch" in only:
+    # the headline's step (bench.py --method batch): ONE launch over all NBUF atlases in their separate allocations (bu_uastc_transcode_batch_device: the multi-run kernel,
+    # whole rectangular tiles, tickets), a few launches back to back
+    VPn, SZn = ctypes.c_void_p * NBUF, ctypes.c_size_t * NBUF
+    a_in, a_n, a_out = VPn(*[x.data_ptr() for x in ins]), SZn(*([N] * NBUF)), VPn(*[x.data_ptr() for x in outs])
+    ctx.set_launch_policy("auto")
+    for _ in range(4 * REPS):
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.BC7, NBUF, a_in, a_n, a_out, 1024, None, None, sp) == 0
+    torch.cuda.synchronize()
+    ctx.set_launch_policy(False)
 if "array512" in only:  # (its own rocprofv3 passes: the persistent grid is the 2^20-block launch's, the summaries could not tell them apart)
     # BASELINE config 5's kernel: the 512-slice array (2^25 blocks, 512 MiB in + 512 MiB out) in ONE launch, two pairs rotated
     nbig = 1 << 25

@@ -9,4 +9,5 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | 
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err; cut -c1-300 $O/bench_steps20.json
 timeout 600 python bench.py --steps 512 --warmup 64 --no-cpu > $O/bench_steps512.json 2> $O/bench_steps512.err; cut -c1-200 $O/bench_steps512.json
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --config array512 --steps 20 --warmup 3 > $O/bench_array512_forced_dist_one_rank.json 2> $O/bench_array512.err; cut -c1-300 $O/bench_array512_forced_dist_one_rank.json
+timeout 600 python bench.py --method pipeline --steps 20 --warmup 5 --no-cpu --no-live-traffic > $O/bench_steps20_method_pipeline.json 2> $O/bench_steps20_method_pipeline.err; cut -c1-200 $O/bench_steps20_method_pipeline.json
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu > $O/bench_atlas4096_forced_dist_one_rank.json 2> $O/bench_atlas4096_dist.err; cut -c1-200 $O/bench_atlas4096_forced_dist_one_rank.json

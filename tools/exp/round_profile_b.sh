@@ -11,10 +11,12 @@ find $O/prof -name "*kernel_stats*.csv" | head -1 | while read f; do cp "$f" $O/
 # what the same trace says about the pipeline: span of a dispatch, completion period UNDER THE PROFILER (its own cost per dispatch is 6-8 us:
 # profiles/r05_rocprofv3_dispatch_floor_*), dispatches running, hardware queues
 find $O/prof -name "*kernel_trace.csv" | head -1 | while read f; do python3 tools/exp/trace_periods.py "$f" "sorted_kernel<1, 256" 1 > $O/rocprofv3_headline_trace_summary.txt; done
+# the headline's own kernel (round 6, --method batch): one launch over 64 atlases -- span of a dispatch = the step
+find $O/prof -name "*kernel_trace.csv" | head -1 | while read f; do python3 tools/exp/trace_periods.py "$f" "multi_kernel<1" 1 > $O/rocprofv3_headline_batch_kernel_summary.txt; done
 rm -rf $O/prof
 # the same with one enqueue thread per stream (bu_time_set_enqueue_threads): the profiler's 6-8 us of host time per enqueue no longer set the pace.  The
 # streams are then fed out of step, so bench.py's own figure in this mode is the strict bracket; the profiler's clock over the steady stretches is the evidence
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 bench.py --headline-only --steps 512 --warmup 64 --enqueue-threads 1 > $O/bench_profiled_enqueue_threads.json 2> $O/bench_profiled_enqueue_threads.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 bench.py --method pipeline --headline-only --steps 512 --warmup 64 --enqueue-threads 1 > $O/bench_profiled_enqueue_threads.json 2> $O/bench_profiled_enqueue_threads.err
 find $O/prof -name "*kernel_trace.csv" | head -1 | while read f; do python3 tools/exp/trace_periods.py "$f" "sorted_kernel<1, 256" 1 > $O/rocprofv3_headline_trace_summary_enqueue_threads.txt; done
 rm -rf $O/prof
 # BASELINE config 5 with four launches in flight: at 2^23 blocks per launch the profiler's cost is small beside the period, its clock and the events agree
