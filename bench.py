@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: UASTC -> BC7 at 4096x4096 (1 048 576 blocks per step) on N MI355X.
+"""Headline benchmark: UASTC -> BC7 at 4096x4096 (64 atlases of 1 048 576 blocks per step) on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W [--config atlas4096|array512]
   N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run the ranks come from the environment
@@ -7,30 +7,32 @@
   `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before it touches any GPU, relays the
   child's output and exits with its code.
 
-  --config atlas4096 (default, the headline metric): weak scaling, every rank transcodes its own 4096x4096 atlas per step.
+  --config atlas4096 (default, the headline metric): weak scaling, every rank transcodes its own 64 atlases of 4096x4096 per step (one launch).
   --config array512  (BASELINE config 5): strong scaling, ONE texture array of 512 slices x 65 536 blocks per step, rank r
                      owns slices [r*512/N, (r+1)*512/N); value = all 33.5 M blocks / max-over-ranks time of the transcode;
                      the all-gather that reassembles the array on every rank is timed separately (RCCL in place, and
                      direct peer pulls) and never folded into `value`.
 
-A step = one launch of the UASTC->BC7 kernel over one 4096x4096 synthetic atlas already resident in
-HBM.  Atlases rotate through NBUF distinct input/output buffer pairs (>= 1 GiB each way) so neither L2
-nor the 256 MiB Infinity Cache can serve a launch (cold-cache protocol).
-Step i is issued on context stream i % IN_FLIGHT (--in-flight, default 4) under the shared launch policy
-(bu_context_set_launch_policy): launches queued on one stream never overlap, and one launch over an atlas
-waits ~3.4 us for HBM with the ALUs idle and then computes with HBM idle; independent atlases on several
-streams use both at once.  `value` = K x 2^20 blocks / the time in which the K timed launches COMPLETE in a
-full pipeline (lead launches in front, one tail launch per stream behind); beside it the
-line carries the strict bracket around the same K steps and the one-launch-at-a-time figure of rounds 1-4.
-GPU_MAX_HW_QUEUES=8 (16 beside an RCCL communicator) is set before HIP initialises (a stream needs a hardware queue of its own to overlap).
-Every rank owns its own atlases (weak scaling: in the texture-array reading of the config each rank
-holds 16 slices of 1024x1024 px); the transcode needs no data-path collective.  The all-gather that
+A step (--method batch, the default since round 6) = ONE launch over 64 synthetic atlases of 4096x4096 (1 048 576 blocks each) already resident in HBM in
+their 64 separate allocations: one call of bu_uastc_transcode_batch_device on the caller's stream hands the library the slice table, and the
+library issues ONE kernel -- a persistent grid that walks the 65 536 tiles of all runs, every run tiled as 64 x 16-block rectangles, the tiles
+drawn by ticket.  A kernel's duration is what HIP events, the host clock and rocprofv3 measure alike: `value` = K x 64 x 2^20 blocks / the time of
+the K timed launches (lead launches in front, an event on either side, no host synchronisation in between; median of --repeats windows), and the
+line carries the same launch's per-kernel average from a child `rocprofv3 --kernel-trace` pass of the same run (they agree to a fraction of a
+percent) and its HBM traffic from child --pmc passes.  Every step touches 2 GiB in + out (cold for L2 and the 256 MiB Infinity Cache).
+Round 5's headline -- one launch per ATLAS, step i on context stream i % IN_FLIGHT under the shared launch policy, throughput counted as the
+pipeline's completion period -- is still measured in every run, by its own method, and reported under `one_launch_per_atlas_in_flight`
+(`--method pipeline` makes it the headline again): launches queued on one stream never overlap, and one launch over an atlas waits ~3.4 us for
+HBM with the ALUs idle and then computes with HBM idle; independent atlases on several streams use both at once.  The pipeline needs a hardware
+queue per stream (the library sees to that itself since round 6; GPU_MAX_HW_QUEUES=8, 16 beside an RCCL communicator, is still set here so that
+ordinary streams are kept).
+Every rank owns its own atlases (weak scaling); the transcode needs no data-path collective.  The all-gather that
 reassembles the array is timed separately and reported under "allgather" -- never folded into `value`.
 
 Prints ONE JSON line (rank 0): metric/value per the driver contract plus
-  roofline      algorithmic bytes (32 B/block x blocks per launch) / launch-to-launch period measured with
-                hipEvents on the launch streams over the timed region, against the 8 TB/s HBM peak; one launch's
-                own span and the HBM traffic from this run's child rocprofv3 passes
+  roofline      algorithmic bytes (32 B/block x 64 x 2^20 blocks per launch) / the launch's average duration measured with
+                HIP events around the timed launches, against the 8 TB/s HBM peak; rocprofv3's own average for the same
+                launch and its HBM traffic from this run's child rocprofv3 passes
   cpu_baseline  the oracle (C restatement of the reference CPU path, kind "port") timed on this box's
                 host cores on a bounded sample of the same atlas
 """
