@@ -818,11 +818,11 @@ def batch_headline(env, line, in_ptrs, out_ptrs, nbuf, outs, idxs, status):
         if not torch.equal(outs[k], env.g_bc7[idxs[k]]):
             raise SystemExit("bench: BC7 output of atlas %d (batch step) differs from the known-answer vectors" % k)
     t_pre, prewarm_steps = time.perf_counter(), 0
-    while args.prewarm_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(4):
+    while args.prewarm_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < 4 * args.prewarm_ms:  # (launches of this size take ~100 ms to settle the clocks, as config 5's)
+        for _ in range(8):
             step()
         torch.cuda.synchronize()
-        prewarm_steps += 4
+        prewarm_steps += 8
     for _ in range(max(0, args.warmup)):
         step()
     torch.cuda.synchronize()
@@ -882,7 +882,7 @@ def batch_headline(env, line, in_ptrs, out_ptrs, nbuf, outs, idxs, status):
     line["config"]["blocks_per_step_per_gpu"] = A * N_BLOCKS
     line["config"]["us_per_atlas"] = round(dt / K / A * 1e6, 4)
     line["config"]["gb_s_in"] = round(line["value"] * 16 / 1e3, 1)
-    line["config"]["prewarm"] = {"steps": prewarm_steps, "ms": args.prewarm_ms, "note": "untimed steps ahead of the W warm-up steps (clock ramp); --prewarm-ms 0 disables"}
+    line["config"]["prewarm"] = {"steps": prewarm_steps, "ms": 4 * args.prewarm_ms, "note": "untimed steps ahead of the W warm-up steps (clock ramp: 4 x --prewarm-ms for launches of this size); --prewarm-ms 0 disables"}
     line["config"]["timed_region"] = {
         "lead_steps": lead, "repeats": R_, "window_reported": "median", "windows_ms_per_step": [round(x / K * 1e3, 5) for x in dts], "event_ms": round(wins[m_][1], 6),
         "host_ms": round(wins[m_][2], 6), "host_started_late": wins[m_][3],
