@@ -1,7 +1,7 @@
 """soak checker (run by hand on the GPU box, not collected by pytest): launches that draw their tiles by TICKET (round 6: exclusive BC7 / ASTC / RGBA32 launches of 16 or
 more tiles per workgroup on one of the context's own streams) against the oracle -- random valid, high-contrast and RAW blocks (statuses: lowest failing block),
 ragged sizes, launches back to back on one stream (the counters reset themselves), two streams side by side (each has its own counter set), the blocking
-entry point.  TICKET_SEEDS rounds (default 3)."""
+entry point, and the multi-run launch of the batch entry point (24 slices in separate allocations: whole-rectangle and mixed runs).  TICKET_SEEDS rounds (default 3)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -73,5 +73,44 @@ for seed in range(int(os.environ.get("TICKET_SEEDS", 3))):
         assert torch.equal(got[ok_rows], torch.from_numpy(w_raw.reshape(-1, bb)).cuda()[ok_rows]), (seed, name)
         assert not got[~ok_rows].any()
         total += n
+    # the multi-run launch (bu_uastc_transcode_batch_device; the headline's kernel): 24 slices of 2^20 blocks in SEPARATE allocations -- every run whole rectangles (the
+    # variant without validity tests), tiles by ticket -- then the same with three ragged slices among them (generic variant, strips and rectangles mixed), and raw blocks
+    import ctypes
+    lib = ctx._lib
+    for ragged in (False, True):
+        sizes = [1 << 20] * 24
+        if ragged:
+            sizes[3], sizes[11], sizes[20] = (1 << 20) + 1024 * 7, (1 << 19) + 333, 16384 * 5
+        for name in ("bc7", "astc"):
+            t, bb = FMT[name]
+            w_, st_ = o.batch(name, base)
+            want = torch.from_numpy(w_.reshape(n1, bb)).cuda()
+            offs = [int(rng.integers(0, n1 - sz)) // 1024 * 1024 for sz in sizes]
+            ins = [d_base[of: of + sz].clone() for of, sz in zip(offs, sizes)]
+            outs = [torch.zeros((sz, bb), dtype=torch.uint8, device="cuda") for sz in sizes]
+            n_s = len(sizes)
+            VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+            a = (n_s, VP(*[x.data_ptr() for x in ins]), SZ(*sizes), VP(*[x.data_ptr() for x in outs]))
+            status = torch.empty(1, dtype=torch.int64, device="cuda")
+            ctx.status_word_reset(status)
+            torch.cuda.synchronize()
+            ctx.set_launch_policy("auto")
+            for rep in range(2):
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, a[0], a[1], a[2], a[3], 1024, None, ctypes.c_void_p(status.data_ptr()), None) == 0
+            torch.cuda.synchronize()
+            ctx.status_word_check(int(status.item()))
+            for k in range(n_s):
+                assert torch.equal(outs[k], want[offs[k]: offs[k] + sizes[k]]), (seed, name, ragged, k)
+            total += 2 * sum(sizes)
+            # raw blocks in slice 9: the lowest failing block of the batch
+            ins[9][1000: 1000 + (1 << 16)] = torch.from_numpy(raw[: 1 << 16]).cuda()
+            first9 = int(np.argmax(st_raw[: 1 << 16] != 0))
+            torch.cuda.synchronize()
+            assert lib.bu_uastc_transcode_batch_device(ctx.handle, t, a[0], a[1], a[2], a[3], 1024, None, ctypes.c_void_p(status.data_ptr()), None) == 0
+            torch.cuda.synchronize()
+            word = int(status.item()) & 0xFFFFFFFFFFFFFFFF
+            assert word >> 8 == sum(sizes[:9]) + 1000 + first9 and (word & 0xFF) == int(st_raw[first9]), (seed, name, ragged)
+            ctx.set_launch_policy(False)
+            del ins, outs
     print("seed %d ok: %d Mi blocks so far, %.0f s" % (seed, total >> 20, time.time() - t0), flush=True)
 print("TICKET SOAK OK: %d Mi block transcodes against the oracle, statuses included, %.0f s" % (total >> 20, time.time() - t0))
