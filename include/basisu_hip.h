@@ -187,9 +187,13 @@ bu_status bu_uastc_transcode_device(bu_context* ctx, bu_target target, const voi
  * copied or freed behind the call; longer batches go out as one launch per 96 runs) -- 64 slices of 65 536 blocks in separate
  * allocations take ~46 us call + synchronize where 64 launches take 290 us on one stream and 230-260 us on two to eight: a loop
  * of launches is bound by the host's ~4 us per launch, not by the GPU.  A batch of LARGE slices at unrelated addresses (BC7, ASTC, RGBA32)
- * is one launch of a persistent grid that walks all the runs' tiles with the next tile's loads in flight: eight 2^20-block slices in
- * separate allocations ~6.4 us each where eight launches one after another take 8.4.  Small batches (a 1-slice "batch") cost what
- * bu_uastc_transcode_device costs.  RGBA32: every slice uses the same blocks_per_row. */
+ * is one launch of a persistent grid that walks all the runs' tiles with the next tile's loads in flight.  Since round 6 that launch is as
+ * fast as a pipeline of launches and is what bench.py's headline times: the run table is copied to LDS once per workgroup, every BC7 / ASTC
+ * run that is whole 64 x 16-block rectangles of a power-of-two grid (blocks_per_row if it is one, else a virtual pitch) is tiled that way,
+ * and from 16 tiles per workgroup on the workgroups draw their tiles by ticket -- SIXTY-FOUR 4096 x 4096 slices in 64 separate allocations:
+ * ONE launch, 351-357 us = 5.5-5.6 us per slice = 0.75-0.765 of the HBM roofline, by HIP events and by rocprofv3's kernel average alike
+ * (eight slices: 7.3 us each -- short walks keep their fixed shares; one slice: what bu_uastc_transcode_device costs).
+ * RGBA32: every slice uses the same blocks_per_row. */
 bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, size_t n_slices, const void* const* d_in,
                                           const size_t* n_blocks, void* const* d_out, size_t blocks_per_row,
                                           const uint64_t* index_base, uint64_t* d_status, void* stream);
