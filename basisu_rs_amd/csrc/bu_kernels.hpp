@@ -153,7 +153,9 @@ __global__ __launch_bounds__(BU_WG) void bu_uastc_kernel(const uint4* __restrict
 // Environment knobs read by the host code (diagnostics, not configuration): BU_TRACE (phase times of bu_read_to on stderr, and
 // for the streamed ETC1S front door when every work item started and ended), BU_RUN_PIECE_MIB (piece size of the two-stream upload
 // pipeline, 0 = off), BU_ETC1S_ONE_LAUNCH (ETC1S files: decode everything, then one launch -- the round-3 path),
-// BU_ETC1S_ONE_THREAD (streamed ETC1S front door: every slice's symbol loop on one thread).
+// BU_ETC1S_ONE_THREAD (streamed ETC1S front door: every slice's symbol loop on one thread); round 6: BU_STREAM_MODE=plain | cumask (how the context's own
+// streams are created: never / always with CU masks instead of by the hardware-queue check, bu_streams.hpp), BU_ENQUEUE_THREADS=0 (the pipelined batch call
+// enqueues from the calling thread alone), BU_TILE_TICKETS=0 (every persistent launch walks fixed shares of the tiles).
 // inclusive add-scan over lanes 0..31 (and 32..63) with DPP row shifts: 5 VALU, no LDS round trips
 __device__ __forceinline__ uint32_t bu_scan32(uint32_t v)
 {
