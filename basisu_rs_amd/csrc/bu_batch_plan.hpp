@@ -44,8 +44,13 @@ inline void bu_merge_runs(size_t n_slices, const void* const* d_in, const size_t
 }
 
 // The launches of bu_uastc_transcode_batch_in_flight.
-// 1. Consecutive runs are grouped into launches of about 2^20 blocks (below that a launch is bound by the host's ~4 us): a group is closed
-//    when it holds 2^20 blocks or `max_runs` runs, a run of 2^20 blocks or more is a group of its own.
+// 1. Consecutive runs are grouped into launches of up to `group_blocks` blocks: a group is closed when it holds that many blocks or `max_runs` runs,
+//    a run of `group_blocks` or more is a group of its own.  Below 2^20 blocks a launch is bound by the host's ~4 us.  BC7 / ASTC group up to 2^23 blocks --
+//    their multi-run kernel (a persistent grid over the tiles of all runs, bu_launch_runs) runs a group at the rate of the plain launches or better, with
+//    one enqueue per group: 64 / 512 slices of 65 536 blocks in separate allocations 36-48 / 226-303 us -> 30-31 / 197-204 per batch, 128 of 262 144
+//    227-248 -> 190, 64 atlases of 2^20 blocks 388-392 -> 373-377 on the host's clock with a single enqueueing thread (groups of 2^20 / 2^22 / 2^23 blocks, queue
+//    pool and CU-mask streams: tools/exp/group_size.sh, group_size_few.sh).  ETC1 / ETC2 / RGBA32 keep 2^20: the ETC multi-run kernel is 10 % behind
+//    their plain launches in flight (64 atlases 797 -> 886 / 973 -> 1122 us if grouped, tools/exp/group_size_targets.sh).
 // 2. With more than one stream, a single-run group of more than 2^23 blocks is cut into equal pieces of at most 2^23: launches of 2^22-2^23 blocks
 //    are what a pipeline of four runs best on (per 2^25-block array, four in flight: 2^20-block launches 179 us, 2^22 175, 2^23 175-176, 2^25
 //    178-184 -- a launch's 512 persistent workgroups walk fixed shares, and the longer the walk the longer its uneven tail;
@@ -54,19 +59,21 @@ inline void bu_merge_runs(size_t n_slices, const void* const* d_in, const size_t
 //    blocks.  Pieces end on tile boundaries: 1024 blocks, and with a pitch 16 block rows of it (the rectangular tiles of the kernels; RGBA32
 //    needs whole block rows) -- lcm(16 * blocks_per_row, 1024).
 // Every block of every run is in exactly one launch, in order; pieces carry their share of the run's block numbering.
-inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, size_t blocks_per_row, size_t block_bytes, size_t max_runs,
+inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, size_t blocks_per_row, size_t block_bytes, size_t max_runs, size_t group_blocks,
                               std::vector<BuLaunchGroup>& groups, std::vector<BuRun>& pieces)
 {
     constexpr size_t GROUP_BLOCKS = (size_t)1 << 20, MAX_LAUNCH_BLOCKS = (size_t)1 << 23;
+    if (group_blocks < GROUP_BLOCKS) group_blocks = GROUP_BLOCKS;
+    if (group_blocks > MAX_LAUNCH_BLOCKS) group_blocks = MAX_LAUNCH_BLOCKS;
     groups.clear();
     pieces.clear();
     for (size_t i = 0; i < runs.size();) {
         BuLaunchGroup g{i, 0, 0};
-        while (i < runs.size() && g.count < max_runs && (g.count == 0 || g.blocks + runs[i].n <= GROUP_BLOCKS)) {
+        while (i < runs.size() && g.count < max_runs && (g.count == 0 || g.blocks + runs[i].n <= group_blocks)) {
             g.blocks += runs[i].n;
             g.count++;
             i++;
-            if (g.blocks >= GROUP_BLOCKS) break;
+            if (g.blocks >= group_blocks) break;
         }
         groups.push_back(g);
     }
@@ -116,7 +123,9 @@ inline void bu_plan_in_flight(const std::vector<BuRun>& runs, int n_streams, siz
             continue;
         }
         const BuRun r = runs[g.first];
-        const size_t per = ((r.n + want[k] - 1) / want[k] + align - 1) / align * align;
+        size_t per = ((r.n + want[k] - 1) / want[k] + align - 1) / align * align;
+        // (rounding a piece up to the alignment must not carry it past 2^23 again: one piece more then)
+        for (size_t w = want[k] + 1; want[k] > 1 && per > MAX_LAUNCH_BLOCKS && align < MAX_LAUNCH_BLOCKS / 2 && r.n > MAX_LAUNCH_BLOCKS; w++) per = ((r.n + w - 1) / w + align - 1) / align * align;
         for (size_t done = 0; done < r.n; done += per) {
             const size_t n = r.n - done < per ? r.n - done : per;
             pieces.push_back(BuRun{r.in + done * 16, r.out + done * block_bytes, n, r.base + done});

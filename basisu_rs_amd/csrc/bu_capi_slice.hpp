@@ -259,20 +259,23 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         // BC7 / ASTC / RGBA32 batches of more tiles than fit the chip at once run as a PERSISTENT grid (four / four / two workgroups per CU)
         // whose workgroups walk the tiles of all runs with the next tile's loads in flight -- a batch of large slices in separate
         // allocations is then one long launch that overlaps its own loads and compute (two 2^20-block slices 7.9 us each, eight 6.4, against
-        // 8.4 for plain launches one after another and 9.2-10.2 through the round-4 table kernel without the prefetch); ETC1 / ETC2 keep
-        // the one-tile-at-a-time shape (their large shape sorts 4096-block tiles, the table numbers 1024-block ones).
+        // 8.4 for plain launches one after another and 9.2-10.2 through the round-4 table kernel without the prefetch).  ETC1 / ETC2 walk the same way with
+        // TWO workgroups per CU (97 / 119 VGPRs: 16 waves are what fits): 64 slices of 2^20 blocks in separate allocations 15.4 / 19.4 -> 13.8 / 17.5 us per
+        // slice against one-tile workgroups dealt by the dispatcher (tools/exp/etc_multi_persist.sh; their plain large shape sorts 4096-block tiles, the
+        // table numbers 1024-block ones: 13.4 / 17.1 when the slices are adjacent and merge into one run).
         const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
         // Launch policy of a grouped launch.  Under the shared policy (launches of other streams run beside this one: bu_uastc_transcode_batch_in_flight
         // with groups of small runs) the PERSISTENT grid is capped at half of every CU -- two workgroups of 512 threads for BC7 / ASTC (16 of the 32 wave
-        // slots, 56 of the 160 KiB), one for RGBA32 -- so that two such launches fit side by side; the one-tile-per-CU shape and the ETC shape are the same
-        // under both policies (a tile's 1024 threads cannot be halved; the ETC tiles are resident one at a time anyway).
+        // slots, 56 of the 160 KiB), one for RGBA32 -- so that two such launches fit side by side (ETC1 / ETC2: one of the two that fit; 64 slices of
+        // 65 536 blocks on four streams 66.3 / 80.2 -> 65.0 / 78.0 us, tools/exp/etc_small_slices.sh); the one-tile-per-CU shape is the same under both
+        // policies (a tile's 1024 threads cannot be halved).
         int pol = policy < 0 ? ctx->launch_policy.load(std::memory_order_relaxed) : policy;
         if (pol == BU_POLICY_AUTO) pol = one_per_cu ? (int)BU_POLICY_EXCLUSIVE : bu_auto_policy(ctx, s);
         const bool half = pol == BU_POLICY_SHARED || pol == BU_POLICY_SHARED_FEW;
         auto go = [&](auto tgt) {
             constexpr int T = decltype(tgt)::value;
-            constexpr bool PERSIST = T == BU_TGT_BC7 || T == BU_TGT_ASTC || T == BU_TGT_RGBA;
-            const size_t cap = (size_t)ctx->cu_count * (PERSIST ? (T == BU_TGT_RGBA ? (half ? 1 : 2) : (half ? 2 : 4)) : 7);  // (beyond seven workgroups per CU they walk the tiles, as bu_launch_uastc)
+            constexpr bool PERSIST = true, ETC = T == BU_TGT_ETC1 || T == BU_TGT_ETC2;
+            const size_t cap = (size_t)ctx->cu_count * (T == BU_TGT_RGBA ? (half ? 1 : 2) : ETC ? (half ? 1 : 2) : (half ? 2 : 4));
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
             // tile tickets for the long walks of a persistent grid that has the chip to itself, as bu_go_big (a batch of 64 slices of 2^20 blocks in
             // separate allocations: 64 tiles per workgroup)
@@ -445,10 +448,12 @@ bu_status bu_uastc_transcode_batch_in_flight(bu_context* ctx, bu_target target, 
     const bool persist_target = target == BU_TARGET_BC7 || target == BU_TARGET_ASTC || target == BU_TARGET_RGBA32;
     if (n_streams > 1 && effective < n_streams && effective <= 2 && persist_target)
         return bu_launch_runs(ctx, target, runs.data(), runs.size(), blocks_per_row, d_status, ctx->extra_streams[0].load(std::memory_order_acquire), BU_POLICY_EXCLUSIVE);
-    // launches of about 2^20 blocks or more; a batch with fewer launches than streams has its largest runs cut (bu_batch_plan.hpp)
+    // launches of 2^20 .. 2^23 blocks (BC7 / ASTC: runs grouped up to 2^23 into multi-run launches; else up to 2^20); a batch with fewer launches than streams has
+    // its largest runs cut (bu_batch_plan.hpp)
     std::vector<BuRun> extra;
     std::vector<BuLaunchGroup> groups;
-    bu_plan_in_flight(runs, n_streams, blocks_per_row, bu_target_block_bytes(target), (size_t)BU_MULTI_RUNS, groups, extra);
+    const size_t group_blocks = (target == BU_TARGET_BC7 || target == BU_TARGET_ASTC) ? (size_t)1 << 23 : (size_t)1 << 20;
+    bu_plan_in_flight(runs, n_streams, blocks_per_row, bu_target_block_bytes(target), (size_t)BU_MULTI_RUNS, group_blocks, groups, extra);
     // launch j on stream j % n_streams, shared policy (a single launch gets the exclusive shape: nothing runs beside it)
     const int policy = groups.size() > 1 && n_streams > 1 ? BU_POLICY_SHARED : BU_POLICY_EXCLUSIVE;
     return bu_issue_in_flight(ctx, target, runs, extra, groups, blocks_per_row, d_status, n_streams, policy);

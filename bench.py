@@ -1463,8 +1463,8 @@ def run_atlas4096(env):
                                                          "note": "ONE call of bu_uastc_transcode_batch_device over the headline's %d atlases in their separate allocations = one launch "
                                                                  "on the caller's stream (run table in the kernel arguments, copied to LDS; every run tiled as 64 x 16-block rectangles; "
                                                                  "tiles drawn by ticket), 12 calls back to back between events" % nbuf}
-            # the same loop as ONE call of the pipelined entry point: bu_uastc_transcode_batch_in_flight issues the slices round-robin on the context's
-            # four streams under the shared policy and returns; bu_context_synchronize waits.  512 slices per call (the 64 atlases eight times over),
+            # the same loop as ONE call of the pipelined entry point: bu_uastc_transcode_batch_in_flight issues the slices -- eight atlases per multi-run launch --
+            # round-robin on the context's four streams under the shared policy and returns; bu_context_synchronize waits.  512 slices per call (the 64 atlases eight times over),
             # host clock around call + wait -- the pipeline's fill and drain and the final wake-up are inside
             nsl = 8 * nbuf
             VPs, SZs = ctypes.c_void_p * nsl, ctypes.c_size_t * nsl
@@ -1487,23 +1487,23 @@ def run_atlas4096(env):
                 "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / fl_s / 1e9 / HBM_PEAK_GBS, 4),
                 "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
                 "note": "ONE call of bu_uastc_transcode_batch_in_flight over 512 slices of 2^20 blocks in separate allocations (the 64 atlases eight times over) on four "
-                        "context streams + bu_context_synchronize, host clock around both (median of five calls): the headline's pipeline as an entry point, its fill, "
-                        "drain and the final wake-up included"}
+                        "context streams (64 multi-run launches of eight atlases each) + bu_context_synchronize, host clock around both (median of five calls): the "
+                        "headline's pipeline as an entry point, its fill, drain and the final wake-up included"}
             # ... and the headline's window itself around that entry point: [call over 2048 lead atlases][start marks][call over K timed atlases][end marks]
             # [call over 8 tail atlases], the context's timing-only events between the calls (ProductWindow) -- every launch of the window planned, shaped and
             # enqueued by the call a user makes (from 256 launches per call on: by one enqueue thread per stream)
             pwh = ProductWindow(env, _lib.BC7, list(in_ptrs), list(out_ptrs), N_BLOCKS, NBX, status.data_ptr(), 4)
             k_pw = max(args.steps, 256)
             pwh.window(0, 256)
-            pw_h = sorted(pwh.window(2048, k_pw) for _ in range(3))[1]
+            pw_h = sorted(pwh.window(2048, k_pw, 64) for _ in range(3))[1]  # (the call groups eight atlases per launch: a tail of eight launches)
             pw_hs = max(pw_h[0], pw_h[2]) / 1e3 / k_pw
             torch.cuda.synchronize()
             extra["headline_through_product_api"] = {
                 "us_per_atlas": round(pw_hs * 1e6, 3), "mblocks_s": round(N_BLOCKS / pw_hs / 1e6, 1), "frac_of_hbm_peak": round(BYTES_PER_BLOCK * N_BLOCKS / pw_hs / 1e9 / HBM_PEAK_GBS, 4),
                 "timed_atlases": k_pw, "us_per_atlas_strict_bracket": round(pw_h[1] / k_pw * 1e3, 3), "streams": pwh.streams,
                 "verified": all(bool(torch.equal(outs[k], g_bc7[idxs[k]])) for k in range(nbuf)),
-                "note": "the headline's timed window with bu_uastc_transcode_batch_in_flight doing the launches: one call carries the timed atlases (one slice = one launch each, "
-                        "launch i on context stream i % 4, shared shapes), 2048 lead atlases in the call in front, 8 tail atlases in the call behind, timing-only events of "
+                "note": "the headline's timed window with bu_uastc_transcode_batch_in_flight doing the launches: one call carries the timed atlases (grouped by the call's planner into multi-run launches of "
+                        "eight atlases = 2^23 blocks, launch i on context stream i % 4, shared shapes), 2048 lead atlases in the call in front, 64 tail atlases in the call behind, timing-only events of "
                         "the context between the calls (bu_time_mark_streams / bu_time_marks_elapsed): last lead launch complete -> last timed launch complete; median of "
                         "three windows; max(event, host) clock"}
         except Exception as e:  # secondary rows must never break the headline line
@@ -1819,11 +1819,34 @@ def run_atlas4096(env):
             sramp(4, True, target=tcode)
             t4 = srow(256, 4, True, target=tcode)
             ok4 = t_ok()
+            # ... and the headline's method for this target: ONE bu_uastc_transcode_batch_device launch over all the atlases in their separate allocations
+            tb_s, okb = None, None
+            if nbuf <= 96:
+                VPn, SZn = ctypes.c_void_p * nbuf, ctypes.c_size_t * nbuf
+                tb_a = (VPn(*[in_ptrs[j] for j in range(nbuf)]), SZn(*([N_BLOCKS] * nbuf)), VPn(*[out_ptrs[j] for j in range(nbuf)]))
+                for o_ in outs:
+                    o_.zero_()
+                tb_t0 = time.perf_counter()  # (clocks: the same long lead-in as the BC7 row's)
+                while (time.perf_counter() - tb_t0) * 1e3 < max(args.prewarm_ms, 1.0) * 2:
+                    assert lib.bu_uastc_transcode_batch_device(ctx.handle, tcode, nbuf, tb_a[0], tb_a[1], tb_a[2], NBX, None, None, sp) == 0
+                    torch.cuda.synchronize()
+                tb_e0, tb_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                tb_e0.record(stream)
+                for _ in range(8):
+                    assert lib.bu_uastc_transcode_batch_device(ctx.handle, tcode, nbuf, tb_a[0], tb_a[1], tb_a[2], NBX, None, None, sp) == 0
+                tb_e1.record(stream)
+                torch.cuda.synchronize()
+                tb_s = tb_e0.elapsed_time(tb_e1) / 1e3 / (8 * nbuf)
+                okb = t_ok()
             extra["uastc_to_" + tname] = {"gb_s": round(bpb * N_BLOCKS / ts / 1e9, 1), "us_per_launch": round(ts * 1e6, 3),
                                           "mblocks_s": round(N_BLOCKS / ts / 1e6, 1), "bytes_per_block": bpb, "frac_of_hbm_peak": round(bpb * N_BLOCKS / ts / 1e9 / HBM_PEAK_GBS, 4),
                                           "verified": ok1,
                                           "in_flight_4_shared": {"us_per_atlas": round(t4 * 1e6, 3), "mblocks_s": round(N_BLOCKS / t4 / 1e6, 1), "gb_s": round(bpb * N_BLOCKS / t4 / 1e9, 1),
                                                                  "frac_of_hbm_peak": round(bpb * N_BLOCKS / t4 / 1e9 / HBM_PEAK_GBS, 4), "verified": ok4}}
+            if tb_s is not None:
+                extra["uastc_to_" + tname]["all_atlases_one_launch"] = {"atlases_per_launch": nbuf, "us_per_atlas": round(tb_s * 1e6, 3), "mblocks_s": round(N_BLOCKS / tb_s / 1e6, 1),
+                                                                        "gb_s": round(bpb * N_BLOCKS / tb_s / 1e9, 1),
+                                                                        "frac_of_hbm_peak": round(bpb * N_BLOCKS / tb_s / 1e9 / HBM_PEAK_GBS, 4), "verified": okb}
             del g_t
         # config 4 shape: ETC1S 2048x2048 (512x512 blocks), 4096-entry endpoint / 8192-entry selector codebooks
         try:

@@ -48,8 +48,8 @@ size_t bu_emul_tables_size(void) { return sizeof(BuTablesAll); }
 // (launch, in, out, n_blocks, index base), one per run or piece, in launch order; returns the number of rows (or the number needed
 // if `cap` is too small) and the number of launches in *out_launches
 size_t bu_emul_plan_in_flight(size_t n_slices, const uint64_t* in_addr, const size_t* n_blocks, const uint64_t* out_addr, size_t block_bytes,
-                              const uint64_t* index_base, int n_streams, size_t blocks_per_row, size_t max_runs, uint64_t* rows, size_t cap,
-                              size_t* out_launches)
+                              const uint64_t* index_base, int n_streams, size_t blocks_per_row, size_t max_runs, size_t group_blocks, uint64_t* rows,
+                              size_t cap, size_t* out_launches)
 {
     std::vector<const void*> in(n_slices);
     std::vector<void*> out(n_slices);
@@ -60,7 +60,7 @@ size_t bu_emul_plan_in_flight(size_t n_slices, const uint64_t* in_addr, const si
     std::vector<BuRun> runs, pieces;
     bu_merge_runs(n_slices, in.data(), n_blocks, out.data(), block_bytes, index_base, runs);
     std::vector<BuLaunchGroup> groups;
-    bu_plan_in_flight(runs, n_streams, blocks_per_row, block_bytes, max_runs, groups, pieces);
+    bu_plan_in_flight(runs, n_streams, blocks_per_row, block_bytes, max_runs, group_blocks, groups, pieces);
     size_t n = 0;
     for (size_t j = 0; j < groups.size(); j++)
         for (size_t k = 0; k < groups[j].count; k++, n++) {

@@ -17,11 +17,11 @@ def plan():
     subprocess.run(["make", "-C", os.path.dirname(EMUL), "libbu_emul.so"], check=True, capture_output=True)
     lib = ctypes.CDLL(EMUL)
     U64P, SZP = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_size_t)
-    lib.bu_emul_plan_in_flight.argtypes = [ctypes.c_size_t, U64P, SZP, U64P, ctypes.c_size_t, U64P, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, U64P,
+    lib.bu_emul_plan_in_flight.argtypes = [ctypes.c_size_t, U64P, SZP, U64P, ctypes.c_size_t, U64P, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, U64P,
                                            ctypes.c_size_t, SZP]
     lib.bu_emul_plan_in_flight.restype = ctypes.c_size_t
 
-    def run(in_addr, n_blocks, out_addr, bb, base, n_streams, bpr, max_runs=96):
+    def run(in_addr, n_blocks, out_addr, bb, base, n_streams, bpr, max_runs=96, group_blocks=1 << 20):
         n = len(n_blocks)
         A = (ctypes.c_uint64 * n)(*in_addr)
         O = (ctypes.c_uint64 * n)(*out_addr)
@@ -30,7 +30,7 @@ def plan():
         cap = n + 64
         rows = (ctypes.c_uint64 * (5 * cap))()
         nl = ctypes.c_size_t(0)
-        got = lib.bu_emul_plan_in_flight(n, A, N, O, bb, B, n_streams, bpr, max_runs, rows, cap, ctypes.byref(nl))
+        got = lib.bu_emul_plan_in_flight(n, A, N, O, bb, B, n_streams, bpr, max_runs, group_blocks, rows, cap, ctypes.byref(nl))
         assert got <= cap
         return np.array(list(rows[:5 * got]), dtype=np.uint64).reshape(got, 5), nl.value
 
@@ -69,6 +69,30 @@ def test_large_slices_one_launch_each_small_ones_grouped(plan):
     # launches: big | big+5 | four small ones together (262 144 blocks, then the next run would pass 2^20) | big
     assert launches == 4
     assert [int(x) for x in rows[:, 0]] == [0, 1, 2, 2, 2, 2, 3]
+
+
+def test_bc7_astc_group_up_to_2_23_blocks_per_launch(plan):
+    """the BC7 / ASTC plan (group_blocks = 2^23): 64 atlases of 2^20 blocks in separate allocations are eight launches of eight runs, 512 slices of
+    65 536 blocks six launches of at most 96 runs; a run of 2^23 blocks or more stays alone and one beyond that is cut"""
+    def table(n, per):
+        return [0x1000_0000 + i * 0x4000_0000 for i in range(n)], [0x9000_0000_00 + i * 0x4000_0000 for i in range(n)]
+    a, o = table(64, 1 << 20)
+    rows, launches = plan(a, [1 << 20] * 64, o, 16, None, 4, 1024, group_blocks=1 << 23)
+    _check_cover(rows, a, [1 << 20] * 64, o, 16, None)
+    assert launches == 8 and [int(x) for x in rows[:, 0]] == [k // 8 for k in range(64)]
+    a, o = table(512, 65536)
+    rows, launches = plan(a, [65536] * 512, o, 16, None, 4, 256, group_blocks=1 << 23)
+    _check_cover(rows, a, [65536] * 512, o, 16, None)
+    assert launches == 6 and [int((rows[:, 0] == j).sum()) for j in range(6)] == [96] * 5 + [32]
+    sizes = [1 << 20, 1 << 23, 3 << 20, (1 << 23) + 1024, 5]
+    a, o = table(len(sizes), 0)
+    rows, launches = plan(a, sizes, o, 16, None, 4, 0, group_blocks=1 << 23)
+    _check_cover(rows, a, sizes, o, 16, None)
+    # 2^20 alone (the next run would pass 2^23) | 2^23 | 3 Mi alone (as before) | two pieces of the long run | the last 5 blocks
+    assert launches == 6 and [int(r[3]) for r in rows] == [1 << 20, 1 << 23, 3 << 20, (1 << 22) + 1024, 1 << 22, 5]
+    # the same table at the other targets' 2^20: the small runs group, everything else goes alone
+    rows20, launches20 = plan(a, sizes, o, 16, None, 4, 0)
+    assert launches20 == 6
 
 
 def test_contiguous_array_is_cut_into_pieces_of_at_most_2_23_blocks_and_one_per_stream_at_least(plan):
@@ -125,13 +149,14 @@ def test_random_slice_tables_cover_every_block_once(plan):
             base = None
             # (gaps in the numbering cannot be expressed without index_base: remove them from the expectation by construction)
         streams = int(rng.integers(1, 9))
-        rows, launches = plan(in_addr, sizes, out_addr, bb, base, streams, bpr, max_runs=int(rng.choice([4, 96])))
+        grp = int(rng.choice([1 << 20, 1 << 22, 1 << 23]))
+        rows, launches = plan(in_addr, sizes, out_addr, bb, base, streams, bpr, max_runs=int(rng.choice([4, 96])), group_blocks=grp)
         _check_cover(rows, in_addr, sizes, out_addr, bb, base)
         per_launch = {}
         for r in rows:
             per_launch.setdefault(int(r[0]), []).append(int(r[3]))
         assert sorted(per_launch) == list(range(launches))
         for j, ns in per_launch.items():
-            # a launch of several runs stops growing at 2^20 blocks: without its last run it is below
-            assert len(ns) == 1 or sum(ns[:-1]) < (1 << 20), (case, j, ns)
+            # a launch of several runs holds at most `group_blocks` blocks
+            assert len(ns) == 1 or sum(ns) <= grp, (case, j, ns)
             assert streams == 1 or len(ns) > 1 or ns[0] <= (1 << 23), (case, j, ns)

@@ -369,7 +369,7 @@ def test_bench_dist_branch_checks_that_its_streams_are_in_step(queues):
 
 def test_probe_streams_sees_queue_sharing():
     """bu_context_probe_streams: a child process started with GPU_MAX_HW_QUEUES=8 finds every one of the context's four streams on its own hardware
-    queue (1) and keeps ordinary streams; with GPU_MAX_HW_QUEUES=2 four ordinary streams cannot have two queues to themselves -- BU_STREAM_MODE=plain
+    queue (1), normally as ordinary streams; with GPU_MAX_HW_QUEUES=2 four ordinary streams cannot have two queues to themselves -- BU_STREAM_MODE=plain
     shows it (>= 2) -- and the library's own answer (round 6) is CU-mask streams, each on a queue of its own (1); argument checks"""
     import subprocess
 
@@ -385,7 +385,9 @@ def test_probe_streams_sees_queue_sharing():
         assert r.returncode == 0, r.stderr[-2000:]
         f = r.stdout.split("SHARING")[1].split()[:4]
         got[(q, mode)] = [int(f[0]), int(f[1]), int(f[2]), f[3]]
-    assert got[("8", None)] == [1, 1, 4, "pool"], got
+    # (eight queues normally leave the four ordinary streams one each -- "pool" --, but which queue a stream lands on is the runtime's business and other
+    #  streams of the process count too: when the probe finds two together the library's answer is CU-mask streams here as well.  Four in flight either way.)
+    assert got[("8", None)][:3] == [1, 1, 4] and got[("8", None)][3] in ("pool", "cu_mask"), got
     assert got[("2", None)] == [1, 1, 4, "cu_mask"], got
     assert got[("2", "plain")][0] >= 2 and got[("2", "plain")][1] == 1 and got[("2", "plain")][2] <= 2 and got[("2", "plain")][3] == "pool", got
     from basisu_rs_amd import Context
