@@ -3,6 +3,6 @@
 # and one per CU under the shared policy (lib_etchalf1)
 cd $GRAFT_REPO_ROOT/tools/exp
 for t in etc1 etc2; do for l in lib_exbase.so lib_etcnow.so lib_etchalf1.so; do
-  python3 small_slices.py $l $t 2>&1 | grep -v amdgpu.ids
+  python3 slices_in_flight_ab.py $l $t 2>&1 | grep -v amdgpu.ids
 done; done
-python3 small_slices.py lib_etcnow.so bc7 2>&1 | grep -v amdgpu.ids
+python3 slices_in_flight_ab.py lib_etcnow.so bc7 2>&1 | grep -v amdgpu.ids

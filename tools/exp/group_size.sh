@@ -6,7 +6,7 @@ for q in "" 8; do
   if [ -n "$q" ]; then export GPU_MAX_HW_QUEUES=$q; else unset GPU_MAX_HW_QUEUES; fi
   for shape in "64 65536" "512 65536" "128 262144" "64 1048576"; do
     for l in lib_grp20.so lib_grp22.so lib_grp23.so lib_grp23all.so; do
-      python3 small_slices.py $l bc7 $shape 2>&1 | grep -v amdgpu.ids
+      python3 slices_in_flight_ab.py $l bc7 $shape 2>&1 | grep -v amdgpu.ids
     done
   done
 done

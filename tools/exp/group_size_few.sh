@@ -3,6 +3,6 @@
 cd $GRAFT_REPO_ROOT/tools/exp
 for shape in "4 1048576" "8 1048576" "16 1048576" "32 1048576"; do
   for l in lib_grp20.so lib_grp22all.so lib_grp23all.so; do
-    python3 small_slices.py $l bc7 $shape 2>&1 | grep -v amdgpu.ids
+    python3 slices_in_flight_ab.py $l bc7 $shape 2>&1 | grep -v amdgpu.ids
   done
 done

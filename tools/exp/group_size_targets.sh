@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT/tools/exp
 for t in astc etc1 etc2; do
   for shape in "64 65536" "512 65536" "64 1048576"; do
     for l in lib_grp20.so lib_grp23.so lib_grp23all.so; do
-      python3 small_slices.py $l $t $shape 2>&1 | grep -v amdgpu.ids
+      python3 slices_in_flight_ab.py $l $t $shape 2>&1 | grep -v amdgpu.ids
     done
   done
 done
