@@ -200,8 +200,9 @@ bu_status bu_uastc_transcode_batch_device(bu_context* ctx, bu_target target, siz
 /* The same loop over independent slices at the rate of a PIPELINE of launches -- what bench.py's headline measures, as one call.
  * Launches queued on one stream never overlap, and a launch over a slice waits for HBM with the ALUs idle and then computes with HBM idle;
  * launches on several streams fill each other's gaps (UASTC -> BC7 over 4096 x 4096 slices: 8.4 us per slice one at a time, 5.6-6.0 us in a
- * pipeline).  The call merges the slices into runs as above, groups small runs into launches of about 2^20 blocks (one launch per group, the run
- * table in its kernel arguments), cuts the largest runs of a batch that would make fewer launches than streams into equal pieces (a 512-slice
+ * pipeline).  The call merges the slices into runs as above, groups the runs into multi-run launches (one launch per group, the run table in its
+ * kernel arguments; BC7 / ASTC: up to 2^23 blocks per launch, so that eight 4096 x 4096 atlases in separate allocations are one enqueue; ETC1 / ETC2 /
+ * RGBA32: small runs up to 2^20 blocks, a larger run is a launch of its own -- profiles/r06_in_flight_group_size.txt), cuts runs of more than 2^23 blocks and the largest runs of a batch that would make fewer launches than streams into equal pieces (a 512-slice
  * texture array in one allocation becomes n_streams launches: 0.76-0.78 of the HBM roofline against 0.70 as one launch), and issues launch j on
  * the context's own stream j % n_streams (1..8; bu_context_stream; FOUR is the depth to use -- the chip runs four queues' dispatches side by side,
  * and with five to eight streams BC7 / ASTC fall from 5.5 to 7-10 us per 2^20-block slice: profiles/r06_more_than_four_in_flight.txt) under the
