@@ -265,8 +265,8 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         // table numbers 1024-block ones: 13.4 / 17.1 when the slices are adjacent and merge into one run).
         const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
         // Launch policy of a grouped launch.  Under the shared policy (launches of other streams run beside this one: bu_uastc_transcode_batch_in_flight
-        // with groups of small runs) the PERSISTENT grid is capped at half of every CU -- two workgroups of 512 threads for BC7 / ASTC (16 of the 32 wave
-        // slots, 56 of the 160 KiB), one for RGBA32 -- so that two such launches fit side by side (ETC1 / ETC2: one of the two that fit; 64 slices of
+        // with groups of small runs) the PERSISTENT grid is capped at about half of every CU -- two workgroups of 512 threads for BC7 / ASTC (16 of the 32 wave
+        // slots, 56 of the 160 KiB; four of 256 in the whole-tile shape below), one for RGBA32 -- so that two such launches fit side by side (ETC1 / ETC2: one of the two that fit; 64 slices of
         // 65 536 blocks on four streams 66.3 / 80.2 -> 65.0 / 78.0 us, tools/exp/etc_small_slices.sh); the one-tile-per-CU shape is the same under both
         // policies (a tile's 1024 threads cannot be halved).
         int pol = policy < 0 ? ctx->launch_policy.load(std::memory_order_relaxed) : policy;
@@ -275,17 +275,23 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         auto go = [&](auto tgt) {
             constexpr int T = decltype(tgt)::value;
             constexpr bool PERSIST = true, ETC = T == BU_TGT_ETC1 || T == BU_TGT_ETC2;
-            const size_t cap = (size_t)ctx->cu_count * (T == BU_TGT_RGBA ? (half ? 1 : 2) : ETC ? (half ? 1 : 2) : (half ? 2 : 4));
+            // BC7 / ASTC batches whose runs are all whole rectangular tiles (the variant without validity tests): 256 x 4, FIVE workgroups per CU (63 / 76 VGPRs, 31 / 27 KiB),
+            // four under the shared policy.  ASTC's 512 x 2 form of that variant sits at exactly 64 VGPRs -- the compiler gets there by serialising -- and ran 64 atlases in
+            // separate allocations at 5.95-6.0 us per atlas where the plain kernel does 5.5: 5.59-5.63 in this shape (64 / 512 slices of 65 536 blocks 32.8 / 243 -> 30.6 / 219 us);
+            // BC7 5.57-5.75 -> 5.52-5.57, 512 small slices 224 -> 215 (in flight 202 -> 191): profiles/r06_ab_multi_run_256x4.txt.  Everything else 512 x 2, four / two per CU.
+            constexpr bool WHOLE_T = T == BU_TGT_BC7 || T == BU_TGT_ASTC;
+            const bool whole = WHOLE_T && all_whole;
+            const size_t cap = (size_t)ctx->cu_count * (T == BU_TGT_RGBA ? (half ? 1 : 2) : ETC ? (half ? 1 : 2) : whole ? (half ? 4 : 5) : (half ? 2 : 4));
             const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
             // tile tickets for the long walks of a persistent grid that has the chip to itself, as bu_go_big (a batch of 64 slices of 2^20 blocks in
             // separate allocations: 64 tiles per workgroup)
             unsigned* const ticket = (PERSIST && !half && n_tiles >= BU_TICKET_MIN_WALK * (size_t)grid) ? bu_ticket_for(ctx, s) : nullptr;
             if (one_per_cu)
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, (unsigned*)nullptr);
-            else if (PERSIST && all_whole && (T == BU_TGT_BC7 || T == BU_TGT_ASTC))
-                hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST, (T == BU_TGT_BC7 || T == BU_TGT_ASTC)>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row,
-                                   stw, ctx->d_tables, ticket);
-            else
+            else if (whole) {
+                if constexpr (WHOLE_T)
+                    hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 256, 4, PERSIST, true>), dim3(grid), dim3(256), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, ticket);
+            } else
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 2, PERSIST>), dim3(grid), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, ticket);
         };
         switch (target) {

@@ -894,7 +894,7 @@ def batch_headline(env, line, in_ptrs, out_ptrs, nbuf, outs, idxs, status):
         "traffic": live[0] if live[0] is not None else None,
         "traffic_source": live[1] if live[0] is not None else "not measured in this run (%s); committed passes of this launch: profiles/r06_*pmc*batch*" % live[1],
         "traffic_over_algorithmic": round(live[0] / (BYTES_PER_BLOCK * A * N_BLOCKS), 4) if live[0] else None,
-        "kernel": "bu_uastc_multi_kernel<BC7, 512 threads x 2 blocks, persistent, whole rectangular tiles> over %d runs" % A,
+        "kernel": "bu_uastc_multi_kernel<BC7, 256 threads x 4 blocks, five workgroups per CU, persistent, whole rectangular tiles> over %d runs" % A,
         "us_per_launch": round(step_s * 1e6, 3), "us_per_atlas": round(step_s / A * 1e6, 4), "bytes_per_launch": BYTES_PER_BLOCK * A * N_BLOCKS, "atlases_per_launch": A,
         "rocprofv3_this_run": rp,
         "us_per_launch_by_rocprofv3_kernel_avg": round(rp["kernel_avg_ns"] / 1e3, 3) if rp and rp.get("kernel_avg_ns") else None,
