@@ -137,10 +137,13 @@ def test_streams_window_runs_every_launch_on_every_stream(golden, shared, stream
     A = vp * nbuf
     ev, host, fd, late = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
     lead, launches = 5, 19 - tail  # (neither a multiple of the stream counts: every stream carries lead and timed launches, unevenly)
-    st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 3, n, 1024,
-                                                   lead, launches, tail, streams, vp(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(fd), ctypes.byref(late))
-    assert st == 0, lib.bu_status_string(st)
-    torch.cuda.synchronize()
+    for attempt in range(3):  # (the host clock starts when the host SEES the start events done: a descheduled host thread shortens it -- try again then)
+        st = lib.bu_time_uastc_launches_streams_window(ctx.handle, _lib.BC7, A(*[x.data_ptr() for x in ins]), A(*[x.data_ptr() for x in outs]), nbuf, 3, n, 1024,
+                                                       lead, launches, tail, streams, vp(status.data_ptr()), ctypes.byref(ev), ctypes.byref(host), ctypes.byref(fd), ctypes.byref(late))
+        assert st == 0, lib.bu_status_string(st)
+        torch.cuda.synchronize()
+        if abs(host.value - ev.value) < 0.5 * ev.value + 0.05:
+            break
     want = torch.from_numpy(golden["bc7"]).cuda()
     for k in range(nbuf):  # 24 launches over 12 buffers from buffer 3 on: every buffer was written
         assert torch.equal(outs[k], want[torch.from_numpy(idxs[k]).cuda()]), k
