@@ -78,7 +78,7 @@ def test_in_flight_without_the_environment_variable():
     and 64 atlases through ONE call of the in-flight entry point come out right at the pipeline's rate -- or the call reports fewer effective streams"""
     r = _child({})
     assert r["ok"] and r["clear"], r
-    assert r["effective"] < 4 or r["us_per_atlas"] <= 6.2, r
+    assert r["effective"] < 4 or r["us_per_atlas"] <= 6.6, r
     if r["effective"] == 4:
         assert r["sharing_now"] == 1, r
     print("in flight without GPU_MAX_HW_QUEUES:", r)
