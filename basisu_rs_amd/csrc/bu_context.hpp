@@ -253,6 +253,10 @@ void bu_launch_sorted(const BuPiece& p, unsigned cu_count, int policy, unsigned 
         if (policy == BU_POLICY_SHARED_FEW && bu_big_from_one_tile_per_cu(TARGET))
             bu_go_big<TARGET, BuShape<SharedShape::WGS, SharedShape::BPT, SharedShape::MINW, SharedShape::PREFETCH, SharedShape::RECT, 4>>(p, cu_count, false);
         else if (policy == BU_POLICY_SHARED || policy == BU_POLICY_SHARED_FEW) bu_go_big<TARGET, SharedShape>(p, cu_count, false);
+        else if (TARGET == BU_TGT_ASTC && p.nb >= ((size_t)1 << 21))
+            // ASTC from 2^21 blocks on: 256 x 4, five per CU (79 VGPRs, 24 KiB) -- 2^21 / 2^22 / 2^23 / 2^25 blocks 15.2 / 28.3 / 53.6 / 183.3 -> 14.3 / 27.5 / 51.2 / 179.9 us,
+            // 2^24 level (97.5 / 98.0), a lone 2^20-block atlas 8.9 -> 9.9: profiles/r06_ab_astc_large_launch_256x4.txt.  (BC7 loses 0-5 % in that shape at every size.)
+            bu_go_big<TARGET, BuShape<256, 4, 1, true, true, 5>>(p, cu_count, true);
         else bu_go_big<TARGET, BuBigShape<TARGET, BU_POLICY_EXCLUSIVE>>(p, cu_count, true);
     } else {
         bu_go<TARGET, BuEtcMidShape>(p, (unsigned)tiles, cu_count, (unsigned)BU_HOST_TILE);
