@@ -8,9 +8,12 @@ bu_status bu_copy_ceiling_device(bu_context* ctx, const void* d_in, size_t n_blo
 {
     if (!ctx || (n_blocks && (!d_in || !d_out))) return BU_ERR_ARGUMENT;
     if (n_blocks == 0) return BU_OK;
-    const size_t per_wg = (size_t)BU_COPY_WG * BU_COPY_EPT;
-    hipLaunchKernelGGL(bu_copy_kernel, dim3((unsigned)((n_blocks + per_wg - 1) / per_wg)), dim3(BU_COPY_WG), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), n_blocks);
+    if (n_blocks >= ((size_t)1 << 22))
+        hipLaunchKernelGGL((bu_copy_kernel<1024, 1>), dim3((unsigned)((n_blocks + 1023) / 1024)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), n_blocks);
+    else
+        hipLaunchKernelGGL((bu_copy_kernel<256, 4>), dim3((unsigned)((n_blocks + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint4*>(d_in), static_cast<uint4*>(d_out), n_blocks);
     BU_HIP(ctx, hipGetLastError());
     return BU_OK;
 }

@@ -673,23 +673,23 @@ __global__ __launch_bounds__(64) void bu_sleep_kernel(unsigned long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
-// uint4 -> uint4 copy (measurement only): the practical ceiling any 16 B in / 16 B out kernel is compared with.  The shape is the
-// fastest of tools/exp/copy_shapes.hip at 2^20 blocks (profiles/r02_copy_shapes_32MiB.txt): 512 threads, four 16-byte elements per
-// thread issued back to back (all four loads in flight before the first store), nontemporal both ways, one pass per thread --
-// 6.06 us against 7.2 us for one element per thread (fewer, fatter waves shorten the launch ramp).
-constexpr int BU_COPY_WG = 512, BU_COPY_EPT = 4;
-__global__ __launch_bounds__(BU_COPY_WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+// uint4 -> uint4 copy (measurement only): the practical ceiling any 16 B in / 16 B out kernel is compared with -- one pass per thread, every load in flight before
+// the first store, nontemporal both ways.  The shape is the fastest of tools/exp/copy_big.hip at the size (profiles/r06_copy_ceiling_by_size.txt): 1024 threads x one
+// element from 2^22 elements on (2^25: 164.5 us = 6.5 TB/s = 0.82 of the data sheet; 256 x 4: 166, 512 x 4 -- this kernel until round 6 -- 173.6, plain loads and
+// stores 181), 256 x 4 below (2^20: 6.7 us against 7.0 / 7.1).
+template <int WG, int EPT>
+__global__ __launch_bounds__(WG) void bu_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
 {
-    const size_t base = (size_t)blockIdx.x * (BU_COPY_WG * BU_COPY_EPT) + threadIdx.x;
-    uint4 v[BU_COPY_EPT];
+    const size_t base = (size_t)blockIdx.x * (WG * EPT) + threadIdx.x;
+    uint4 v[EPT];
 #pragma unroll
-    for (int k = 0; k < BU_COPY_EPT; k++) {
-        const size_t i = base + (size_t)k * BU_COPY_WG;
+    for (int k = 0; k < EPT; k++) {
+        const size_t i = base + (size_t)k * WG;
         if (i < n) v[k] = bu_ld_stream(in + i);
     }
 #pragma unroll
-    for (int k = 0; k < BU_COPY_EPT; k++) {
-        const size_t i = base + (size_t)k * BU_COPY_WG;
+    for (int k = 0; k < EPT; k++) {
+        const size_t i = base + (size_t)k * WG;
         if (i < n) {
             bu_v4u r;
             r.x = v[k].x; r.y = v[k].y; r.z = v[k].z; r.w = v[k].w;

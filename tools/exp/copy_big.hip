@@ -1,0 +1,113 @@
+// EXPERIMENT: how fast can ANY traversal copy 512 MiB -> 512 MiB (BASELINE config 5's bytes) on this box, and does the transcoder's traversal -- a persistent grid walking
+// 1024-block tiles, strips or 64 x 16-block rectangles at a 1024-block pitch, next tile's loads in flight -- cost bandwidth by itself?
+// hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o tools/exp/copy_big tools/exp/copy_big.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <chrono>
+#include <cstdlib>
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+__device__ inline uint4 ldnt(const uint4* p) { v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p)); return make_uint4(t.x, t.y, t.z, t.w); }
+__device__ inline void stnt(uint4* p, uint4 v) { v4u t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(p)); }
+template <int EPT, bool NT>
+__global__ void oneshot(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+    uint4 v[EPT];
+    const size_t base = (size_t)blockIdx.x * blockDim.x * EPT + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) v[k] = NT ? ldnt(in + base + (size_t)k * blockDim.x) : in[base + (size_t)k * blockDim.x];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) { if (NT) stnt(out + base + (size_t)k * blockDim.x, v[k]); else out[base + (size_t)k * blockDim.x] = v[k]; }
+}
+// persistent: gridDim.x workgroups of WGS threads walk 1024-element tiles t = blockIdx.x, + gridDim.x, ...; RECT: tile = 64 x 16 elements of a grid 1024 wide
+template <int WGS, bool RECT, bool PF, bool NT>
+__global__ void persist(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles)
+{
+    constexpr int BPT = 1024 / WGS;
+    auto idx = [&](unsigned t, unsigned l) -> size_t {
+        if (RECT) { const unsigned ty = t >> 4, tx = t & 15u; return (size_t)(16u * ty + l / 64u) * 1024u + 64u * tx + (l % 64u); }
+        return (size_t)t * 1024u + l;
+    };
+    uint4 v[BPT], vn[BPT];
+    unsigned t = blockIdx.x;
+    if (t >= n_tiles) return;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = NT ? ldnt(in + idx(t, j * WGS + threadIdx.x)) : in[idx(t, j * WGS + threadIdx.x)];
+    for (; t < n_tiles; t += gridDim.x) {
+        const unsigned nt = t + gridDim.x;
+        if (PF && nt < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) vn[j] = NT ? ldnt(in + idx(nt, j * WGS + threadIdx.x)) : in[idx(nt, j * WGS + threadIdx.x)];
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; j++) { if (NT) stnt(out + idx(t, j * WGS + threadIdx.x), v[j]); else out[idx(t, j * WGS + threadIdx.x)] = v[j]; }
+        if (PF) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) v[j] = vn[j];
+        } else if (nt < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) v[j] = NT ? ldnt(in + idx(nt, j * WGS + threadIdx.x)) : in[idx(nt, j * WGS + threadIdx.x)];
+        }
+    }
+}
+// inputs as the benches have them: incompressible pseudo-random bytes (COPY_BIG_FILL=const keeps the memset pattern: data-dependent power is part of the answer)
+__global__ void fill_random(uint4* p, size_t n, unsigned seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; unsigned long long y = x * 0x94D049BB133111EBull; y ^= y >> 31;
+        p[i] = make_uint4((unsigned)x, (unsigned)(x >> 32), (unsigned)y, (unsigned)(y >> 32));
+    }
+}
+static std::vector<uint4*> g_in, g_out;
+static size_t N;
+static int g_reps = 8;
+template <class F> void run(const char* name, F launch)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto t0 = std::chrono::steady_clock::now();
+    int k = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.15) { launch(g_in[k % g_in.size()], g_out[k % g_in.size()]); k++; hipDeviceSynchronize(); }
+    float best = 1e9f, sum = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < g_reps; i++) launch(g_in[i % g_in.size()], g_out[i % g_in.size()]);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        ms /= g_reps; sum += ms; if (ms < best) best = ms;
+    }
+    printf("%-44s %8.2f us (avg %8.2f)  %6.3f TB/s  %.3f of 8 TB/s\n", name, best * 1e3, sum / 3 * 1e3, 32.0 * N / best / 1e9, 32.0 * N / best / 1e9 / 8);
+    if (hipGetLastError() != hipSuccess) printf("  ERROR\n");
+}
+int main()
+{
+    N = (size_t)1 << (getenv("COPY_BIG_LG") ? atoi(getenv("COPY_BIG_LG")) : 25);  // uint4 elements = UASTC blocks
+    const int pairs = getenv("COPY_BIG_PAIRS") ? atoi(getenv("COPY_BIG_PAIRS")) : 2;
+    for (int i = 0; i < pairs; i++) { uint4 *a, *b; hipMalloc(&a, N * 16); hipMalloc(&b, N * 16); hipMemset(a, i + 1, N * 16);
+        const char* f = getenv("COPY_BIG_FILL");
+        if (!f || f[0] != 'c') hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, a, N, 77u + i);
+        g_in.push_back(a); g_out.push_back(b); }
+    hipDeviceSynchronize();
+    printf("input: %s\n", (getenv("COPY_BIG_FILL") && getenv("COPY_BIG_FILL")[0] == 'c') ? "constant bytes" : "pseudo-random bytes");
+    const unsigned tiles = (unsigned)(N / 1024);
+    g_reps = (int)(((size_t)1 << 28) / N); if (g_reps < 8) g_reps = 8;
+    run("oneshot 256 x 4 plain", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot<4, false>), dim3(N / 1024), dim3(256), 0, 0, a, b, N); });
+    run("oneshot 256 x 4 nt", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot<4, true>), dim3(N / 1024), dim3(256), 0, 0, a, b, N); });
+    run("oneshot 512 x 2 nt", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot<2, true>), dim3(N / 1024), dim3(512), 0, 0, a, b, N); });
+    run("oneshot 1024 x 1 nt", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot<1, true>), dim3(N / 1024), dim3(1024), 0, 0, a, b, N); });
+    run("oneshot 512 x 4 nt (the library's shape)", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot<4, true>), dim3(N / 2048), dim3(512), 0, 0, a, b, N); });
+    run("oneshot 256 x 8 nt", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot<8, true>), dim3(N / 2048), dim3(256), 0, 0, a, b, N); });
+    for (int per_cu : {2, 4, 6, 8}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "persist 512x2 strips pf nt, %d per CU", per_cu);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<512, false, true, true>), dim3(256 * per_cu), dim3(512), 0, 0, a, b, tiles); });
+        snprintf(nm, sizeof nm, "persist 512x2 rect   pf nt, %d per CU", per_cu);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<512, true, true, true>), dim3(256 * per_cu), dim3(512), 0, 0, a, b, tiles); });
+    }
+    run("persist 512x2 rect nopf nt, 4 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<512, true, false, true>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
+    run("persist 512x2 rect pf plain, 4 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<512, true, true, false>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
+    run("persist 256x4 rect pf nt, 5 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<256, true, true, true>), dim3(1280), dim3(256), 0, 0, a, b, tiles); });
+    run("persist 256x4 rect pf nt, 8 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<256, true, true, true>), dim3(2048), dim3(256), 0, 0, a, b, tiles); });
+    run("persist 1024x1 rect pf nt, 2 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<1024, true, true, true>), dim3(512), dim3(1024), 0, 0, a, b, tiles); });
+    return 0;
+}
