@@ -1346,7 +1346,7 @@ def run_atlas4096(env):
         rot[0] += copy_n
         copy_s = ms.value / 1e3 / copy_n
         extra["copy_ceiling"] = {"gb_s": round(BYTES_PER_BLOCK * N_BLOCKS / copy_s / 1e9, 1), "us_per_launch": round(copy_s * 1e6, 3),
-                                 "note": "uint4->uint4 copy kernel in its fastest known one-launch shape (512 threads x 4 elements, nontemporal), same cold-cache rotation, one "
+                                 "note": "uint4->uint4 copy kernel in its fastest known one-launch shape at this size (256 threads x 4 elements, nontemporal; from 2^22 elements on 1024 x 1, which copies 512 MiB at 0.81 of the roofline: profiles/r06_copy_ceiling_by_size.txt), same cold-cache rotation, one "
                                          "launch at a time.  NOT a ceiling for launches in flight: this kernel gains nothing from company (in_flight rows), the transcoder's "
                                          "persistent workgroups stream faster (single-mode BC7 atlases, four in flight: 5.2 us = 6.4 TB/s)"}
         try:
