@@ -20,6 +20,79 @@ __global__ void oneshot(const uint4* __restrict__ in, uint4* __restrict__ out, s
     for (int k = 0; k < EPT; k++) { if (NT) stnt(out + base + (size_t)k * blockDim.x, v[k]); else out[base + (size_t)k * blockDim.x] = v[k]; }
 }
 // persistent: gridDim.x workgroups of WGS threads walk 1024-element tiles t = blockIdx.x, + gridDim.x, ...; RECT: tile = 64 x 16 elements of a grid 1024 wide
+template <int RW>
+__device__ inline size_t tile_idx(unsigned t, unsigned l)
+{
+    if (RW >= 1024) return (size_t)t * 1024u + l;
+    constexpr unsigned TPR = 1024u / RW, ROWS = 1024u / RW;  // tiles per row of the 1024-wide grid, rows per tile
+    const unsigned ty = t / TPR, tx = t % TPR;
+    return (size_t)(ROWS * ty + l / RW) * 1024u + RW * tx + (l % RW);
+}
+// one pass, one tile per workgroup, tiles RW wide
+template <int WGS, int RW>
+__global__ void oneshot_tile(const uint4* __restrict__ in, uint4* __restrict__ out)
+{
+    constexpr int BPT = 1024 / WGS;
+    uint4 v[BPT];
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(blockIdx.x, j * WGS + threadIdx.x));
+#pragma unroll
+    for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(blockIdx.x, j * WGS + threadIdx.x), v[j]);
+}
+// persistent, tiles drawn off ONE atomic counter (reset by the host between launches)
+template <int WGS, int RW>
+__global__ void persist_ticket(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles, unsigned* counter)
+{
+    constexpr int BPT = 1024 / WGS;
+    __shared__ unsigned s_t;
+    uint4 v[BPT], vn[BPT];
+    if (threadIdx.x == 0) s_t = atomicAdd(counter, 1u);
+    __syncthreads();
+    unsigned t = s_t;
+    if (t >= n_tiles) return;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(t, j * WGS + threadIdx.x));
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_t = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned nt = s_t;
+        if (nt < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) vn[j] = ldnt(in + tile_idx<RW>(nt, j * WGS + threadIdx.x));
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(t, j * WGS + threadIdx.x), v[j]);
+        if (nt >= n_tiles) break;
+#pragma unroll
+        for (int j = 0; j < BPT; j++) v[j] = vn[j];
+        t = nt;
+    }
+}
+// persistent fixed walk with a start-up delay per workgroup: SPREAD units of 64 x 16 clocks spread pseudo-randomly (or by residency generation) over the grid
+template <int WGS, int RW, int MODE>
+__global__ void persist_stagger(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles, unsigned spread)
+{
+    constexpr int BPT = 1024 / WGS;
+    unsigned d = MODE == 0 ? ((blockIdx.x * 2654435761u) >> 16) % (spread + 1u) : (blockIdx.x / 256u) * spread;
+    for (; d; d--) __builtin_amdgcn_s_sleep(16);
+    uint4 v[BPT], vn[BPT];
+    unsigned t = blockIdx.x;
+    if (t >= n_tiles) return;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(t, j * WGS + threadIdx.x));
+    for (; t < n_tiles; t += gridDim.x) {
+        const unsigned nt = t + gridDim.x;
+        if (nt < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) vn[j] = ldnt(in + tile_idx<RW>(nt, j * WGS + threadIdx.x));
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(t, j * WGS + threadIdx.x), v[j]);
+#pragma unroll
+        for (int j = 0; j < BPT; j++) v[j] = vn[j];
+    }
+}
 template <int WGS, bool RECT, bool PF, bool NT>
 __global__ void persist(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles)
 {
@@ -108,6 +181,31 @@ int main()
     run("persist 512x2 rect pf plain, 4 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<512, true, true, false>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
     run("persist 256x4 rect pf nt, 5 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<256, true, true, true>), dim3(1280), dim3(256), 0, 0, a, b, tiles); });
     run("persist 256x4 rect pf nt, 8 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<256, true, true, true>), dim3(2048), dim3(256), 0, 0, a, b, tiles); });
+    run("oneshot tile 512x2, 64-wide rectangles", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile<512, 64>), dim3(tiles), dim3(512), 0, 0, a, b); });
+    run("oneshot tile 512x2, 128-wide rectangles", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile<512, 128>), dim3(tiles), dim3(512), 0, 0, a, b); });
+    run("oneshot tile 512x2, 256-wide rectangles", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile<512, 256>), dim3(tiles), dim3(512), 0, 0, a, b); });
+    run("oneshot tile 512x2, strips", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile<512, 1024>), dim3(tiles), dim3(512), 0, 0, a, b); });
+    run("oneshot tile 256x4, 64-wide rectangles", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile<256, 64>), dim3(tiles), dim3(256), 0, 0, a, b); });
+    for (unsigned spread : {0u, 2u, 8u, 32u}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "persist 512x2 64-wide 4/CU, random delay <= %u x 0.43 us", spread);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_stagger<512, 64, 0>), dim3(1024), dim3(512), 0, 0, a, b, tiles, spread); });
+        snprintf(nm, sizeof nm, "persist 512x2 strips 4/CU, random delay <= %u x 0.43 us", spread);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_stagger<512, 1024, 0>), dim3(1024), dim3(512), 0, 0, a, b, tiles, spread); });
+    }
+    for (unsigned spread : {1u, 2u, 4u}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "persist 512x2 64-wide 4/CU, generation delay %u x 0.43 us", spread);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_stagger<512, 64, 1>), dim3(1024), dim3(512), 0, 0, a, b, tiles, spread); });
+    }
+    unsigned* counter; hipMalloc(&counter, 4);
+    auto tk = [&](auto kern, int wgs, int per_cu) { return [=](const uint4* a, uint4* b) { hipMemsetAsync(counter, 0, 4, 0); hipLaunchKernelGGL(kern, dim3(256 * per_cu), dim3(wgs), 0, 0, a, b, tiles, counter); }; };
+    run("persist ticket 512x2 64-wide, 4 per CU", tk(persist_ticket<512, 64>, 512, 4));
+    run("persist ticket 512x2 strips, 4 per CU", tk(persist_ticket<512, 1024>, 512, 4));
+    run("persist ticket 512x2 strips, 2 per CU", tk(persist_ticket<512, 1024>, 512, 2));
+    run("persist ticket 256x4 64-wide, 5 per CU", tk(persist_ticket<256, 64>, 256, 5));
+    run("persist ticket 256x4 strips, 5 per CU", tk(persist_ticket<256, 1024>, 256, 5));
+    run("persist ticket 512x2 256-wide, 4 per CU", tk(persist_ticket<512, 256>, 512, 4));
     run("persist 1024x1 rect pf nt, 2 per CU", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist<1024, true, true, true>), dim3(512), dim3(1024), 0, 0, a, b, tiles); });
     return 0;
 }
