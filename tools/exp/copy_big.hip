@@ -93,6 +93,60 @@ __global__ void persist_stagger(const uint4* __restrict__ in, uint4* __restrict_
         for (int j = 0; j < BPT; j++) v[j] = vn[j];
     }
 }
+// persistent, tiles drawn off EIGHT counters 128 B apart (counter c serves tiles 8 d + c), the draw for the tile after the next issued one tile ahead (the library's scheme)
+template <int WGS, int RW>
+__global__ void persist_ticket8(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles, unsigned* counters)
+{
+    constexpr int BPT = 1024 / WGS;
+    __shared__ unsigned s_t[2];
+    unsigned* const my = counters + (blockIdx.x & 7u) * 32u;
+    const unsigned c = blockIdx.x & 7u;
+    uint4 v[BPT], vn[BPT];
+    unsigned t = blockIdx.x;  // first tile: the workgroup's own number (the counters start at gridDim.x / 8)
+    unsigned draw = 0, par = 0;
+    if (threadIdx.x == 0) draw = atomicAdd(my, 1u);
+    if (t >= n_tiles) return;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(t, j * WGS + threadIdx.x));
+    for (;; par ^= 1u) {
+        if (threadIdx.x == 0) s_t[par] = (gridDim.x / 8u + draw) * 8u + c;
+        __syncthreads();
+        const unsigned nt = s_t[par];
+        if (threadIdx.x == 0 && nt < n_tiles) draw = atomicAdd(my, 1u);
+        if (nt < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) vn[j] = ldnt(in + tile_idx<RW>(nt, j * WGS + threadIdx.x));
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(t, j * WGS + threadIdx.x), v[j]);
+        if (nt >= n_tiles) break;
+#pragma unroll
+        for (int j = 0; j < BPT; j++) v[j] = vn[j];
+        t = nt;
+    }
+}
+// semi-persistent: gridDim.x = n_tiles / K workgroups, each walks K tiles (prefetch) and exits; CONTIG: tiles K w .. K w + K - 1, else w, w + G, w + 2 G, ...
+template <int WGS, int RW, bool CONTIG>
+__global__ void semi(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles, unsigned K)
+{
+    constexpr int BPT = 1024 / WGS;
+    uint4 v[BPT], vn[BPT];
+    const unsigned step = CONTIG ? 1u : gridDim.x;
+    unsigned t = CONTIG ? blockIdx.x * K : blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(t, j * WGS + threadIdx.x));
+    for (unsigned k = 0; k < K; k++, t += step) {
+        const unsigned nt = t + step;
+        if (k + 1 < K) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) vn[j] = ldnt(in + tile_idx<RW>(nt, j * WGS + threadIdx.x));
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(t, j * WGS + threadIdx.x), v[j]);
+#pragma unroll
+        for (int j = 0; j < BPT; j++) v[j] = vn[j];
+    }
+}
 template <int WGS, bool RECT, bool PF, bool NT>
 __global__ void persist(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles)
 {
@@ -198,6 +252,20 @@ int main()
         snprintf(nm, sizeof nm, "persist 512x2 64-wide 4/CU, generation delay %u x 0.43 us", spread);
         run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_stagger<512, 64, 1>), dim3(1024), dim3(512), 0, 0, a, b, tiles, spread); });
     }
+    for (unsigned K : {1u, 2u, 4u, 8u, 16u, 32u}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "semi 512x2 64-wide, %u tiles per WG, strided", K);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((semi<512, 64, false>), dim3(tiles / K), dim3(512), 0, 0, a, b, tiles, K); });
+        snprintf(nm, sizeof nm, "semi 512x2 64-wide, %u tiles per WG, contiguous", K);
+        run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((semi<512, 64, true>), dim3(tiles / K), dim3(512), 0, 0, a, b, tiles, K); });
+    }
+    unsigned* counters8; hipMalloc(&counters8, 8 * 128);
+    auto tk8 = [&](auto kern, int wgs, int per_cu) { return [=](const uint4* a, uint4* b) { hipMemsetAsync(counters8, 0, 8 * 128, 0); hipLaunchKernelGGL(kern, dim3(256 * per_cu), dim3(wgs), 0, 0, a, b, tiles, counters8); }; };
+    run("persist 8 tickets 512x2 64-wide, 4 per CU", tk8(persist_ticket8<512, 64>, 512, 4));
+    run("persist 8 tickets 512x2 strips, 4 per CU", tk8(persist_ticket8<512, 1024>, 512, 4));
+    run("persist 8 tickets 512x2 64-wide, 2 per CU", tk8(persist_ticket8<512, 64>, 512, 2));
+    run("persist 8 tickets 256x4 64-wide, 5 per CU", tk8(persist_ticket8<256, 64>, 256, 5));
+    run("persist 8 tickets 512x2 256-wide, 4 per CU", tk8(persist_ticket8<512, 256>, 512, 4));
     unsigned* counter; hipMalloc(&counter, 4);
     auto tk = [&](auto kern, int wgs, int per_cu) { return [=](const uint4* a, uint4* b) { hipMemsetAsync(counter, 0, 4, 0); hipLaunchKernelGGL(kern, dim3(256 * per_cu), dim3(wgs), 0, 0, a, b, tiles, counter); }; };
     run("persist ticket 512x2 64-wide, 4 per CU", tk(persist_ticket<512, 64>, 512, 4));
