@@ -28,6 +28,42 @@ __device__ inline size_t tile_idx(unsigned t, unsigned l)
     const unsigned ty = t / TPR, tx = t % TPR;
     return (size_t)(ROWS * ty + l / RW) * 1024u + RW * tx + (l % RW);
 }
+// XCD-aware renumbering: workgroup / walk index t (XCD = t % 8) -> tile whose ROW-in-a-group-of-eight is t % 8 and whose column (of 16) is (t / 8) % 16: an XCD then streams
+// whole 256 KiB tile rows instead of two 1 KiB-wide columns of every row
+__device__ inline unsigned xcd_rows(unsigned t) { return (t & ~0x7Fu) | ((t & 7u) << 4) | ((t >> 3) & 0xFu); }
+template <int WGS, int RW, bool XR>
+__global__ void oneshot_tile_x(const uint4* __restrict__ in, uint4* __restrict__ out)
+{
+    constexpr int BPT = 1024 / WGS;
+    const unsigned t = XR ? xcd_rows(blockIdx.x) : blockIdx.x;
+    uint4 v[BPT];
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(t, j * WGS + threadIdx.x));
+#pragma unroll
+    for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(t, j * WGS + threadIdx.x), v[j]);
+}
+template <int WGS, int RW, bool XR>
+__global__ void persist_x(const uint4* __restrict__ in, uint4* __restrict__ out, unsigned n_tiles)
+{
+    constexpr int BPT = 1024 / WGS;
+    uint4 v[BPT], vn[BPT];
+    unsigned w = blockIdx.x;
+    if (w >= n_tiles) return;
+    auto T = [&](unsigned x) { return XR ? xcd_rows(x) : x; };
+#pragma unroll
+    for (int j = 0; j < BPT; j++) v[j] = ldnt(in + tile_idx<RW>(T(w), j * WGS + threadIdx.x));
+    for (; w < n_tiles; w += gridDim.x) {
+        const unsigned nw = w + gridDim.x;
+        if (nw < n_tiles) {
+#pragma unroll
+            for (int j = 0; j < BPT; j++) vn[j] = ldnt(in + tile_idx<RW>(T(nw), j * WGS + threadIdx.x));
+        }
+#pragma unroll
+        for (int j = 0; j < BPT; j++) stnt(out + tile_idx<RW>(T(w), j * WGS + threadIdx.x), v[j]);
+#pragma unroll
+        for (int j = 0; j < BPT; j++) v[j] = vn[j];
+    }
+}
 // one pass, one tile per workgroup, tiles RW wide
 template <int WGS, int RW>
 __global__ void oneshot_tile(const uint4* __restrict__ in, uint4* __restrict__ out)
@@ -259,6 +295,12 @@ int main()
         snprintf(nm, sizeof nm, "semi 512x2 64-wide, %u tiles per WG, contiguous", K);
         run(nm, [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((semi<512, 64, true>), dim3(tiles / K), dim3(512), 0, 0, a, b, tiles, K); });
     }
+    run("oneshot tile 512x2 64-wide, as numbered", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile_x<512, 64, false>), dim3(tiles), dim3(512), 0, 0, a, b); });
+    run("oneshot tile 512x2 64-wide, XCD = tile row", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((oneshot_tile_x<512, 64, true>), dim3(tiles), dim3(512), 0, 0, a, b); });
+    run("persist 512x2 64-wide 4/CU, as numbered", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_x<512, 64, false>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
+    run("persist 512x2 64-wide 4/CU, XCD = tile row", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_x<512, 64, true>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
+    run("persist 512x2 strips 4/CU, as numbered", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_x<512, 1024, false>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
+    run("persist 512x2 strips 4/CU, XCD = 8-tile group", [&](const uint4* a, uint4* b) { hipLaunchKernelGGL((persist_x<512, 1024, true>), dim3(1024), dim3(512), 0, 0, a, b, tiles); });
     unsigned* counters8; hipMalloc(&counters8, 8 * 128);
     auto tk8 = [&](auto kern, int wgs, int per_cu) { return [=](const uint4* a, uint4* b) { hipMemsetAsync(counters8, 0, 8 * 128, 0); hipLaunchKernelGGL(kern, dim3(256 * per_cu), dim3(wgs), 0, 0, a, b, tiles, counters8); }; };
     run("persist 8 tickets 512x2 64-wide, 4 per CU", tk8(persist_ticket8<512, 64>, 512, 4));
