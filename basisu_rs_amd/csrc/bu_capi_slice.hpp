@@ -232,9 +232,11 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
             // a virtual pitch (bu_launch_uastc has the story: 16 segments of 1 KiB at >= 4 KiB pitch load faster than 16 KiB in a row; multi-run launch over 32
             // slices of 2^20 blocks 6.0 -> 5.6 us per slice)
             uint32_t vshift = BU_RUN_STRIPS;
-            if (target == BU_TARGET_BC7 || target == BU_TARGET_ASTC) {
+            if (target == BU_TARGET_BC7 || target == BU_TARGET_ASTC || target == BU_TARGET_RGBA32) {
                 const size_t real = (blocks_per_row >= 128 && (blocks_per_row & (blocks_per_row - 1)) == 0 && blocks_per_row <= ((size_t)1 << 20)) ? blocks_per_row : 0;
-                for (const size_t v : {real, (size_t)1024, (size_t)2048, (size_t)512, (size_t)256}) {
+                // (RGBA32 is an image: only its real pitch will do -- 64 atlases of 2^20 blocks in separate allocations 14.5 -> see profiles/r06_ab_rgba_multi_run_rectangles.txt)
+                const bool image = target == BU_TARGET_RGBA32;
+                for (const size_t v : {real, image ? (size_t)0 : (size_t)1024, image ? (size_t)0 : (size_t)2048, image ? (size_t)0 : (size_t)512, image ? (size_t)0 : (size_t)256}) {
                     if (v && r.n % (16 * v) == 0) {
                         vshift = 0;
                         while (((size_t)BU_RECT_W << vshift) < v) vshift++;

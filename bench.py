@@ -2037,6 +2037,35 @@ def run_atlas4096(env):
                                                                  "frac_of_hbm_peak": round(80 * N_BLOCKS / rg3 / 1e9 / HBM_PEAK_GBS, 4), "verified": rg3_ok}
         except Exception as e:
             extra["uastc_to_rgba32"]["in_flight_error"] = repr(e)
+        # ... and ONE bu_uastc_transcode_batch_device launch over the 16 atlases in their separate allocations (the multi-run kernel: whole runs of the image's own
+        # power-of-two pitch are tiled as 64 x 16-block rectangles, tiles drawn by ticket)
+        try:
+            SZr = ctypes.c_size_t * rg_n
+            rg_nn = SZr(*([N_BLOCKS] * rg_n))
+            for o_ in rg_out:
+                o_.zero_()
+
+            def rg_batch():
+                assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.RGBA32, rg_n, rg_in, rg_nn, rg_outp, NBX, None, None, sp) == 0
+
+            rg_t0 = time.perf_counter()
+            while (time.perf_counter() - rg_t0) * 1e3 < max(args.prewarm_ms, 1.0) * 2:
+                rg_batch()
+                torch.cuda.synchronize()
+            rg_e0, rg_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            rg_e0.record(stream)
+            for _ in range(12):
+                rg_batch()
+            rg_e1.record(stream)
+            torch.cuda.synchronize()
+            rgb_s = rg_e0.elapsed_time(rg_e1) / 1e3 / (12 * rg_n)
+            g_rg = torch.from_numpy(golden["rgba"]).to(dev)
+            rgb_ok = all(bool(torch.equal(rg_out[k].view(NBY, 4, NBX, 16).permute(0, 2, 1, 3).reshape(N_BLOCKS, 64), g_rg[idxs[k]])) for k in (0, rg_n - 1))
+            extra["uastc_to_rgba32"]["all_atlases_one_launch"] = {"atlases_per_launch": rg_n, "us_per_atlas": round(rgb_s * 1e6, 3), "gb_s": round(80 * N_BLOCKS / rgb_s / 1e9, 1),
+                                                                  "frac_of_hbm_peak": round(80 * N_BLOCKS / rgb_s / 1e9 / HBM_PEAK_GBS, 4), "verified": rgb_ok}
+            del g_rg
+        except Exception as e:
+            extra["uastc_to_rgba32"]["all_atlases_one_launch_error"] = repr(e)
         del rg_out
 
 

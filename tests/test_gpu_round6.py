@@ -353,6 +353,48 @@ def test_batch_device_long_walk_draws_tickets(golden, target):
     ctx.close()
 
 
+@pytest.mark.parametrize("bpr", [128, 256, 1024])
+def test_rgba32_multi_run_launch_tiles_whole_runs_as_rectangles(golden, bpr):
+    """bu_uastc_transcode_batch_device, RGBA32, slices in separate allocations: runs that are whole 64 x 16-block rectangles of the image's own power-of-two pitch are tiled that
+    way inside the multi-run launch (as the plain launch tiles them; an image has no virtual pitch), ragged ones as strips, both kinds in one launch -- short walks and a long
+    (ticketed) one, known answers per pixel row, lowest failing block"""
+    import torch
+
+    from basisu_rs_amd import BasisuError, Context
+
+    ctx = Context(0)
+    lib = ctx._lib
+    gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden["rgba"]).cuda()
+    for rows in ([64, 16, 160, 48, 1024 * 256 // bpr], [64, 40, 16, 7, 2048 * 256 // bpr, 33], [4096 * 1024 // bpr] * 9):
+        sizes = [r * bpr for r in rows]
+        n_s = len(sizes)
+        idxs = [torch.randint(0, 608, (n,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(900 + k)) for k, n in enumerate(sizes)]
+        ins = [gu[i].contiguous() for i in idxs]
+        outs = [torch.zeros((n // bpr * 4, bpr * 16), dtype=torch.uint8, device="cuda") for n in sizes]
+        status = torch.empty(1, dtype=torch.int64, device="cuda")
+        ctx.status_word_reset(status)
+        torch.cuda.synchronize()
+        VP, SZ = ctypes.c_void_p * n_s, ctypes.c_size_t * n_s
+        a = (n_s, VP(*[x.data_ptr() for x in ins]), SZ(*sizes), VP(*[x.data_ptr() for x in outs]))
+        for rep in range(2):
+            assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.RGBA32, a[0], a[1], a[2], a[3], bpr, None, ctypes.c_void_p(status.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        ctx.status_word_check(int(status.item()))
+        for k, n in enumerate(sizes):
+            got = outs[k].view(n // bpr, 4, bpr, 16).permute(0, 2, 1, 3).reshape(n, 64)
+            assert torch.equal(got, gt[idxs[k]]), (bpr, rows, k)
+        ins[n_s - 1][sizes[-1] - 1, 0] = 69
+        ins[1][3, 0] = 69
+        torch.cuda.synchronize()
+        assert lib.bu_uastc_transcode_batch_device(ctx.handle, _lib.RGBA32, a[0], a[1], a[2], a[3], bpr, None, ctypes.c_void_p(status.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        with pytest.raises(BasisuError) as e:
+            ctx.status_word_check(int(status.item()))
+        assert e.value.first_bad_block == sizes[0] + 3
+        del ins, outs
+    ctx.close()
+
+
 @pytest.mark.parametrize("target", ["bc7", "astc"])
 def test_virtual_pitch_tiles_without_a_block_grid(golden, target):
     """BC7 / ASTC without a usable blocks_per_row (0, or no multiple of 64): slices that are whole multiples of 16 x {1024, 2048, 512, 256} blocks are tiled as 64 x 16-block
