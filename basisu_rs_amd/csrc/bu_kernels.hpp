@@ -598,8 +598,10 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 // PREFETCH: the launch is a persistent grid whose workgroups walk many tiles (batches of large slices): the next tile's blocks -- of
 // whatever run it belongs to -- are loaded while the current tile is transcoded, as in the one-slice kernel.
 // WHOLE: every run of the table is tiled as whole rectangles (the host checked: BuRunDesc::vshift of all of them)
+// (ASTC, 512 threads: the register allocation is held to the 64 VGPRs at which FOUR such workgroups fit a CU -- left alone it takes 66, three fit, and a persistent grid of four
+//  per CU runs its fourth behind the others: 64 ragged slices of ~2^20 blocks 6.7 -> see profiles/r06_ab_astc_64_vgprs.txt)
 template <int TARGET, int WGS, int BPT, bool PREFETCH = false, bool WHOLE = false>
-__global__ __launch_bounds__(WGS, 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
+__global__ __launch_bounds__(WGS, (TARGET == BU_TGT_ASTC && WGS == 512) ? 8 : 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
                                                              const BuTablesAll* __restrict__ tables, unsigned* __restrict__ ticket)
 {
     static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");

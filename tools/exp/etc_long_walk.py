@@ -13,7 +13,7 @@ lib, tname = sys.argv[1], sys.argv[2]
 pol = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 TGT = {"astc": 0, "bc7": 1, "etc1": 2, "etc2": 3, "rgba": 4}
 t = TGT[tname]; OB = 8 if tname == "etc1" else (64 if tname == "rgba" else 16)
-N = 1 << 20; NBUF = 64
+N = int(os.environ.get("LW_N", 1 << 20)); NBUF = 64  # (LW_N: blocks per atlas, e.g. 1045504 = 1021 rows of 1024: no whole rectangles, strips)
 dev = torch.device("cuda", 0)
 g = synth.load_golden(os.path.join(ROOT, "tests", "golden", "uastc_kat.bin"))
 gu = torch.from_numpy(g["uastc"]).to(dev); gw = torch.from_numpy(g[tname]).to(dev) if tname != "rgba" else None  # (RGBA32: an image, timing only)
