@@ -222,34 +222,60 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
     unsigned long long* stw = reinterpret_cast<unsigned long long*>(d_status);
     for (size_t r0 = 0; r0 < n_runs;) {
         BuRunTable tb;
-        size_t k = 0, n_tiles = 0;
+        size_t k = 0, used = 0, n_tiles = 0;  // table entries, runs consumed, tiles
         bool all_whole = true;  // every run of this launch is tiled as whole rectangles: the kernel variant without per-lane validity tests
-        for (; r0 + k < n_runs && k < BU_MULTI_RUNS; k++) {
-            const BuRun& r = runs[r0 + k];
+        const size_t bb = bu_target_block_bytes(target);
+        // BC7 / ASTC / RGBA32: a run that is whole 64 x 16-block rectangles of a power-of-two grid is tiled that way -- the caller's blocks_per_row if it is one, else (block-
+        // linear targets; RGBA32 is an image and has only its real pitch) a virtual pitch (bu_launch_uastc has the story: 16 segments of 1 KiB at >= 4 KiB pitch load faster than
+        // 16 KiB in a row; multi-run launch over 32 slices of 2^20 blocks 6.0 -> 5.6 us per slice; RGBA32 14.8 -> 12.9: profiles/r06_ab_rgba_multi_run_rectangles.txt).
+        // *whole_pitch = the pitch n blocks are whole rectangles of (0: none); returns the largest pitch of the list with at least `min_rows16` tile rows in n (ragged runs: their
+        // whole PREFIX goes out as an entry of its own, the remainder as strips -- RGBA32 only: 64 ragged images of 1021 x 1024 blocks 15.0 -> 13.1 us per image, BC7 / ASTC unmoved:
+        // profiles/r06_ab_rgba_multi_run_rectangles.txt)
+        const bool rect_target = target == BU_TARGET_BC7 || target == BU_TARGET_ASTC || target == BU_TARGET_RGBA32;
+        const size_t real = (blocks_per_row >= 128 && (blocks_per_row & (blocks_per_row - 1)) == 0 && blocks_per_row <= ((size_t)1 << 20)) ? blocks_per_row : 0;
+        const size_t pitches[5] = {real, target == BU_TARGET_RGBA32 ? (size_t)0 : (size_t)1024, target == BU_TARGET_RGBA32 ? (size_t)0 : (size_t)2048,
+                                   target == BU_TARGET_RGBA32 ? (size_t)0 : (size_t)512, target == BU_TARGET_RGBA32 ? (size_t)0 : (size_t)256};
+        auto shift_of = [](size_t v) {
+            uint32_t sh = 0;
+            while (((size_t)BU_RECT_W << sh) < v) sh++;
+            return sh;
+        };
+        auto emit = [&](const uint8_t* in, uint8_t* out, uint64_t base, size_t n, uint32_t vshift) {
+            all_whole = all_whole && vshift != BU_RUN_STRIPS;
+            tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(in), out, base, (uint32_t)n, vshift};
+            tb.first_tile[k] = (uint32_t)n_tiles;
+            n_tiles += (n + 1023) / 1024;
+            k++;
+        };
+        for (; r0 + used < n_runs && k < BU_MULTI_RUNS; used++) {
+            const BuRun& r = runs[r0 + used];
             const size_t t = (r.n + 1023) / 1024;
-            if (n_tiles + t >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
-            // BC7 / ASTC: a run that is whole 64 x 16-block rectangles of a power-of-two grid is tiled that way -- the caller's blocks_per_row if it is one, else
-            // a virtual pitch (bu_launch_uastc has the story: 16 segments of 1 KiB at >= 4 KiB pitch load faster than 16 KiB in a row; multi-run launch over 32
-            // slices of 2^20 blocks 6.0 -> 5.6 us per slice)
-            uint32_t vshift = BU_RUN_STRIPS;
-            if (target == BU_TARGET_BC7 || target == BU_TARGET_ASTC || target == BU_TARGET_RGBA32) {
-                const size_t real = (blocks_per_row >= 128 && (blocks_per_row & (blocks_per_row - 1)) == 0 && blocks_per_row <= ((size_t)1 << 20)) ? blocks_per_row : 0;
-                // (RGBA32 is an image: only its real pitch will do -- 64 atlases of 2^20 blocks in separate allocations 14.5 -> see profiles/r06_ab_rgba_multi_run_rectangles.txt)
-                const bool image = target == BU_TARGET_RGBA32;
-                for (const size_t v : {real, image ? (size_t)0 : (size_t)1024, image ? (size_t)0 : (size_t)2048, image ? (size_t)0 : (size_t)512, image ? (size_t)0 : (size_t)256}) {
+            if (n_tiles + t + 1 >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
+            size_t whole_pitch = 0, prefix_pitch = 0;
+            if (rect_target) {
+                for (const size_t v : pitches)
                     if (v && r.n % (16 * v) == 0) {
-                        vshift = 0;
-                        while (((size_t)BU_RECT_W << vshift) < v) vshift++;
+                        whole_pitch = v;
                         break;
                     }
-                }
+                if (!whole_pitch && target == BU_TARGET_RGBA32 && k + 2 <= BU_MULTI_RUNS)  // (BC7 / ASTC gain nothing from the split: 5.95 / 6.3 us per slice either way)
+                    for (const size_t v : pitches)
+                        if (v && r.n >= 8 * 16 * v) {  // (at least eight tile rows of rectangles, or the split is not worth an entry)
+                            prefix_pitch = v;
+                            break;
+                        }
             }
-            all_whole = all_whole && vshift != BU_RUN_STRIPS;
-            tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(r.in), r.out, r.base, (uint32_t)r.n, vshift};
-            tb.first_tile[k] = (uint32_t)n_tiles;
-            n_tiles += t;
+            if (whole_pitch) {
+                emit(r.in, r.out, r.base, r.n, shift_of(whole_pitch));
+            } else if (prefix_pitch) {
+                const size_t prefix = r.n / (16 * prefix_pitch) * (16 * prefix_pitch);
+                emit(r.in, r.out, r.base, prefix, shift_of(prefix_pitch));
+                emit(r.in + prefix * 16, r.out + prefix * bb, r.base + prefix, r.n - prefix, BU_RUN_STRIPS);
+            } else {
+                emit(r.in, r.out, r.base, r.n, BU_RUN_STRIPS);
+            }
         }
-        if (k <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
+        if (used <= 1) {  // a run on its own (the last one of a long batch, or one of 2^32 blocks): the plain launch
             bu_status st = bu_launch_uastc(ctx, target, runs[r0].in, runs[r0].n, runs[r0].out, blocks_per_row, runs[r0].base, d_status, s, 0, policy);
             if (st) return st;
             r0 += 1;
@@ -305,7 +331,7 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return bu_fail(ctx, e, "multi-run launch");
-        r0 += k;
+        r0 += used;
     }
     return BU_OK;
 }
