@@ -365,7 +365,8 @@ def test_rgba32_multi_run_launch_tiles_whole_runs_as_rectangles(golden, bpr):
     ctx = Context(0)
     lib = ctx._lib
     gu, gt = torch.from_numpy(golden["uastc"]).cuda(), torch.from_numpy(golden["rgba"]).cuda()
-    for rows in ([64, 16, 160, 48, 1024 * 256 // bpr], [64, 40, 16, 7, 2048 * 256 // bpr, 33], [4096 * 1024 // bpr] * 9):
+    # (ragged images of 128 block rows or more go out as two table entries: the whole prefix as rectangles, the last rows as strips)
+    for rows in ([64, 16, 160, 48, 1024 * 256 // bpr], [64, 40, 16, 7, 2048 * 256 // bpr, 33], [149, 64, 1003, 16 * 20 + 15, 128, 129], [4096 * 1024 // bpr] * 9):
         sizes = [r * bpr for r in rows]
         n_s = len(sizes)
         idxs = [torch.randint(0, 608, (n,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(900 + k)) for k, n in enumerate(sizes)]
