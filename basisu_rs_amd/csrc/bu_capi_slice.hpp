@@ -240,17 +240,29 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
             while (((size_t)BU_RECT_W << sh) < v) sh++;
             return sh;
         };
+        // ETC1 / ETC2 batches of 2^20 blocks or more in runs long enough for them: 2048-block tiles, ONE tile per workgroup, dealt by the hardware dispatcher (512 x 4 under the
+        // shared shape's launch bounds, two resident per CU) -- what the plain launch does from 2^20 blocks on (bu_launch_sorted): 64 slices of 2^20 blocks in separate
+        // allocations 13.8 / 17.5 -> see profiles/r06_ab_etc_one_tile_workgroups.txt.  (Many short runs keep 1024-block tiles: a run's last tile is partly empty.)
+        size_t tile = 1024;
+        if (target == BU_TARGET_ETC1 || target == BU_TARGET_ETC2) {
+            size_t total = 0, tiles2 = 0;
+            for (size_t i = r0; i < n_runs && i < r0 + BU_MULTI_RUNS; i++) {
+                total += runs[i].n;
+                tiles2 += (runs[i].n + 2047) / 2048;
+            }
+            if (total >= ((size_t)1 << 20) && tiles2 * 2048 <= total + total / 8) tile = 2048;
+        }
         auto emit = [&](const uint8_t* in, uint8_t* out, uint64_t base, size_t n, uint32_t vshift) {
             all_whole = all_whole && vshift != BU_RUN_STRIPS;
             tb.run[k] = BuRunDesc{reinterpret_cast<const uint4*>(in), out, base, (uint32_t)n, vshift};
             tb.first_tile[k] = (uint32_t)n_tiles;
-            n_tiles += (n + 1023) / 1024;
+            n_tiles += (n + tile - 1) / tile;
             k++;
         };
         for (; r0 + used < n_runs && k < BU_MULTI_RUNS; used++) {
             const BuRun& r = runs[r0 + used];
-            const size_t t = (r.n + 1023) / 1024;
-            if (n_tiles + t + 1 >= ((size_t)1 << 22)) break;  // (tiles x 1024 is the launch's 32-bit block count)
+            const size_t t = (r.n + tile - 1) / tile;
+            if (n_tiles + t + 1 >= (((size_t)1 << 32) / tile)) break;  // (tiles x tile size is the launch's 32-bit block count)
             size_t whole_pitch = 0, prefix_pitch = 0;
             if (rect_target) {
                 for (const size_t v : pitches)
@@ -291,7 +303,7 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
         // TWO workgroups per CU (97 / 119 VGPRs: 16 waves are what fits): 64 slices of 2^20 blocks in separate allocations 15.4 / 19.4 -> 13.8 / 17.5 us per
         // slice against one-tile workgroups dealt by the dispatcher (tools/exp/etc_multi_persist.sh; their plain large shape sorts 4096-block tiles, the
         // table numbers 1024-block ones: 13.4 / 17.1 when the slices are adjacent and merge into one run).
-        const bool one_per_cu = n_tiles <= (size_t)ctx->cu_count;
+        const bool one_per_cu = tile == 1024 && n_tiles <= (size_t)ctx->cu_count;
         // Launch policy of a grouped launch.  Under the shared policy (launches of other streams run beside this one: bu_uastc_transcode_batch_in_flight
         // with groups of small runs) the PERSISTENT grid is capped at about half of every CU -- two workgroups of 512 threads for BC7 / ASTC (16 of the 32 wave
         // slots, 56 of the 160 KiB; four of 256 in the whole-tile shape below), one for RGBA32 -- so that two such launches fit side by side (ETC1 / ETC2: one of the two that fit; 64 slices of
@@ -314,7 +326,11 @@ bu_status bu_launch_runs(bu_context* ctx, bu_target target, const BuRun* runs, s
             // tile tickets for the long walks of a persistent grid that has the chip to itself, as bu_go_big (a batch of 64 slices of 2^20 blocks in
             // separate allocations: 64 tiles per workgroup)
             unsigned* const ticket = (PERSIST && !half && n_tiles >= BU_TICKET_MIN_WALK * (size_t)grid) ? bu_ticket_for(ctx, s) : nullptr;
-            if (one_per_cu)
+            if (ETC && tile == 2048) {
+                if constexpr (ETC)
+                    hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 512, 4>), dim3((unsigned)n_tiles), dim3(512), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables,
+                                       (unsigned*)nullptr);
+            } else if (one_per_cu)
                 hipLaunchKernelGGL((bu_uastc_multi_kernel<T, 1024, 1>), dim3(grid), dim3(1024), 0, s, tb, (unsigned)n_tiles, (unsigned)blocks_per_row, stw, ctx->d_tables, (unsigned*)nullptr);
             else if (whole) {
                 if constexpr (WHOLE_T)

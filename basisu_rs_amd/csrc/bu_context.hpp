@@ -250,7 +250,15 @@ void bu_launch_sorted(const BuPiece& p, unsigned cu_count, int policy, unsigned 
         // three launches in flight 6.07 / 5.7 us per 2^20-block atlas against 6.95 / 6.1 (shared) and 6.85 / 6.3 (exclusive); with four the persistent form wins
         // (5.60 against 5.77): profiles/r06_ab_bc7_shared_one_tile_workgroups.txt
         using SharedShape = BuBigShape<TARGET, BU_POLICY_SHARED>;
-        if (policy == BU_POLICY_SHARED_FEW && bu_big_from_one_tile_per_cu(TARGET))
+        if ((TARGET == BU_TGT_ETC1 || TARGET == BU_TGT_ETC2) && p.nb >= ((size_t)1 << 20))
+            // ETC1 / ETC2 from 2^20 blocks on, under EVERY policy: ONE-TILE workgroups of the shared shape (512 x 4 on a 2048-block tile, two resident per CU) dealt by the
+            // hardware dispatcher instead of a persistent grid -- the form in which four launches in flight reach 12.2 / 15.1 us per 2^20 blocks, in ONE launch.  Exclusive (was
+            // 1024 x 4, one per CU): 2^20 blocks 17.8 / 22.2 -> 17.5 / 20.6 us, 1.5 x 2^20 28.2 / 33.9 -> 23.8 / 28.1, 2^22 59.5 / 75.6 -> 54.1 / 65.1, 2^25 433 / 556 -> 394 / 479
+            // (12.3 / 15.0 per 2^20); shared (was 512 x 4 persistent, one per CU): one launch at a time 20.2 / 25.0 -> 17.6 / 20.6, two in flight 13.2 / 16.3 -> 12.1 / 15.0, three
+            // and four +-1 %.  Below 2^20 blocks the persistent grids stay ahead (0.8 x 2^20 exclusive: 16.2 / 19.4 against 17.8 / 21.0).  Walking 2 / 4 / 8 tiles per workgroup
+            // gives the gain back step by step (profiles/r06_ab_etc_one_tile_workgroups.txt; the copies of profiles/r06_copy_ceiling_by_size.txt behave the same way).
+            bu_go<TARGET, SharedShape>(p, (unsigned)((p.nb + SharedShape::TILE - 1) / SharedShape::TILE), 0u, (unsigned)SharedShape::TILE);
+        else if (policy == BU_POLICY_SHARED_FEW && bu_big_from_one_tile_per_cu(TARGET))
             bu_go_big<TARGET, BuShape<SharedShape::WGS, SharedShape::BPT, SharedShape::MINW, SharedShape::PREFETCH, SharedShape::RECT, 4>>(p, cu_count, false);
         else if (policy == BU_POLICY_SHARED || policy == BU_POLICY_SHARED_FEW) bu_go_big<TARGET, SharedShape>(p, cu_count, false);
         else if (TARGET == BU_TGT_ASTC && p.nb >= ((size_t)1 << 21))

@@ -600,13 +600,16 @@ __global__ __launch_bounds__(WGS, MINW) void bu_uastc_sorted_kernel(const uint4*
 // WHOLE: every run of the table is tiled as whole rectangles (the host checked: BuRunDesc::vshift of all of them)
 // (ASTC, 512 threads: the register allocation is held to the 64 VGPRs at which FOUR such workgroups fit a CU -- left alone it takes 66, three fit, and a persistent grid of four
 //  per CU runs its fourth behind the others: 64 ragged slices of ~2^20 blocks 6.7 -> see profiles/r06_ab_astc_64_vgprs.txt)
+// (ETC1 / ETC2 also as 512 x 4 on 2048-block tiles -- the host then numbers 2048-block tiles -- under the shared shape's __launch_bounds__(512, 4): two workgroups per CU)
+constexpr bool bu_multi_etc_2048(int target, int tile) { return (target == BU_TGT_ETC1 || target == BU_TGT_ETC2) && tile == 2048; }
 template <int TARGET, int WGS, int BPT, bool PREFETCH = false, bool WHOLE = false>
-__global__ __launch_bounds__(WGS, (TARGET == BU_TGT_ASTC && WGS == 512) ? 8 : 1) void bu_uastc_multi_kernel(const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status,
-                                                             const BuTablesAll* __restrict__ tables, unsigned* __restrict__ ticket)
+__global__ __launch_bounds__(WGS, (TARGET == BU_TGT_ASTC && WGS == 512) ? 8 : bu_multi_etc_2048(TARGET, WGS * BPT) ? 4 : 1) void bu_uastc_multi_kernel(
+    const BuRunTable table, unsigned n_tiles, unsigned bpr, unsigned long long* status, const BuTablesAll* __restrict__ tables, unsigned* __restrict__ ticket)
 {
-    static_assert(WGS * BPT == 1024, "the host numbers 1024-block tiles");
+    static_assert(WGS * BPT == 1024 || bu_multi_etc_2048(TARGET, WGS * BPT), "the host numbers 1024-block tiles (ETC1 / ETC2 large batches: 2048-block ones)");
     static_assert(sizeof(BuRunTable) + 40 <= 4096, "the run table and the other arguments share the 4 KiB of kernel arguments");
-    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, WHOLE ? BU_LAYOUT_MULTI_WHOLE : BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * 1024u, bpr, 0ull, status, tables, 0u, 1024u, &table, ticket);
+    bu_uastc_sorted_body<TARGET, WGS, BPT, PREFETCH, WHOLE ? BU_LAYOUT_MULTI_WHOLE : BU_LAYOUT_MULTI>(nullptr, nullptr, n_tiles * (unsigned)(WGS * BPT), bpr, 0ull, status, tables, 0u,
+                                                                                                        (unsigned)(WGS * BPT), &table, ticket);
 }
 
 // status words back to "no failing block".  A kernel, not hipMemsetAsync: the reset is part of what callers capture into
