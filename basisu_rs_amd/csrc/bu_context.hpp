@@ -137,6 +137,7 @@ struct BuShape {
 //               barriers and LDS round trips; 2048-block tiles +10 %, 4096 +35 %, 256 x 4 four per CU +18 %.
 //   ETC1 / ETC2 one 1024-thread workgroup per CU on a tile of up to 4096 blocks (99 / 121 VGPRs: 16 waves are all that fit);
 //               73 chunks per 4096 blocks where two 2048-block tiles have 83.
+//               (Only below 2^20 blocks since the end of round 6: from there on ETC launches are one-tile workgroups of the SHARED shape, bu_launch_sorted.)
 //   RGBA32      1024-block tiles (64 KiB of LDS for the four pixel rows), two workgroups per CU, 1024 x 1 up to 3 Mi blocks then 512 x 2.
 // BU_LAUNCH_SHARED -- several launches from different streams are in flight and should run SIDE BY SIDE on every CU, so that one
 // launch's load phase (3.4 us with the vector ALUs idle when it is alone) lies under another one's chunk phase (ALUs saturated, HBM
