@@ -88,8 +88,8 @@ size_t bu_target_block_bytes(bu_target target);
  *   BU_LAUNCH_EXCLUSIVE            a launch is shaped to fill the chip by itself: lowest latency for a single slice (UASTC->BC7,
  *                                  2^20 blocks: 8.4 us); 6.2-6.7 us per slice with 2-4 streams (head / tail overlap only)
  *   BU_LAUNCH_SHARED               a launch keeps at most half of every CU's wave slots, registers and LDS, so launches from different
- *                                  streams run side by side on each CU: 5.45-5.6 us per slice with 4 streams (BC7; ASTC 5.4), ETC1 17.7 -> 12.1,
- *                                  ETC2 22.1 -> 15.0, RGBA32 14.9 -> 13.1; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
+ *                                  streams run side by side on each CU: 5.45-5.6 us per slice with 4 streams (BC7; ASTC 5.4), ETC1 17.5 -> 12.1,
+ *                                  ETC2 20.6 -> 15.0, RGBA32 14.9 -> 13.1; alone on the chip such a launch is 15-40 % SLOWER than an exclusive one.
  *   BU_LAUNCH_AUTO (default)       chosen PER CALL by how many OTHER streams of the context have work that has not completed (enqueued there within
  *                                  the last 40 us of host time; if none was, one hipStreamQuery per stream ever used): none -> exclusive (a lone slice:
  *                                  8.4 us; also every launch on a stream of the caller's own, which the library cannot see beside); three or more ->
